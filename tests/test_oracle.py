@@ -1,0 +1,172 @@
+"""Known-answer and property tests that pin the CPU oracle.
+
+The reference holds no tests or golden vectors for this path (parity unpinned); these are the
+build-owned structural pins: parameter/tensor counts of the public SDv1.5 U-Net, scheduler and
+sinusoid known answers, shape walks, and algebraic properties of the scoring surface.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from diff_mining_amd import synth, unet_spec
+from oracle import unet_ref as R
+
+TINY = dict(block_out_channels=(32, 64, 64, 64), cross_attention_dim=48, num_heads=2, norm_num_groups=8)
+
+
+def tiny_cfgs():
+    return unet_spec.UNetConfig(**TINY), R.RefConfig(**TINY)
+
+
+def tiny_sd(seed=0):
+    cfg, _ = tiny_cfgs()
+    return {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg, seed).items()}
+
+
+def test_param_and_tensor_count():
+    spec = unet_spec.unet_tensor_spec()
+    assert len(spec) == 686
+    assert unet_spec.param_count() == 859_520_964
+    names = [n for n, _ in spec]
+    assert len(set(names)) == 686
+    shapes = dict(spec)
+    assert shapes["conv_in.weight"] == (320, 4, 3, 3)
+    assert shapes["up_blocks.1.resnets.2.conv1.weight"] == (1280, 1920, 3, 3)
+    assert shapes["up_blocks.2.resnets.0.conv_shortcut.weight"] == (640, 1920, 1, 1)
+    assert shapes["up_blocks.3.resnets.0.norm1.weight"] == (960,)
+    assert shapes["down_blocks.0.attentions.0.transformer_blocks.0.ff.net.0.proj.weight"] == (2560, 320)
+    assert shapes["mid_block.attentions.0.transformer_blocks.0.attn2.to_k.weight"] == (1280, 768)
+    assert "down_blocks.3.downsamplers.0.conv.weight" not in shapes
+    assert "up_blocks.3.upsamplers.0.conv.weight" not in shapes
+
+
+def test_scheduler_table_known_answers():
+    acp = R.alphas_cumprod()
+    ka = {0: 0.99914998, 161: 0.81210744, 261: 0.65566903, 500: 0.27633247, 999: 0.00466010}
+    for t, v in ka.items():
+        assert abs(acp[t].item() - v) < 2e-7, (t, acp[t].item())
+    # fp16 cast order (R3): sqrt(1 - fp16(acp[0])) == 0.03125 exactly, not 0.029155
+    x = torch.zeros(1, 4, 2, 2, dtype=torch.float16)
+    n = torch.ones(1, 4, 2, 2, dtype=torch.float16)
+    out = R.add_noise(x, n, torch.tensor([0]))
+    assert out.dtype == torch.float16 and out.flatten()[0].item() == 0.03125
+    out32 = R.add_noise(x.float(), n.float(), torch.tensor([0]))
+    assert abs(out32.flatten()[0].item() - 0.029155) < 1e-5
+
+
+def test_sinusoid_known_answers():
+    e = R.timestep_sinusoid(torch.tensor([161]), 320)[0]
+    assert e.shape == (320,)
+    np.testing.assert_allclose(e[:4].numpy(), [-0.71177477, 0.36481935, 0.52178627, -0.93009287], atol=2e-5)
+    np.testing.assert_allclose(e[160:164].numpy(), [-0.70240778, 0.93107831, -0.85307622, -0.36732447], atol=2e-5)
+    assert abs(e.sum().item() - 91.695999) < 1e-3
+    # t = 0 -> cos half is all ones, sin half all zeros (flip_sin_to_cos)
+    z = R.timestep_sinusoid(torch.tensor([0]), 320)[0]
+    assert torch.all(z[:160] == 1) and torch.all(z[160:] == 0)
+
+
+def test_forward_consumes_every_tensor_and_shapes():
+    cfg, rcfg = tiny_cfgs()
+    sd = tiny_sd()
+    used = set()
+    x = torch.randn(2, 4, 16, 16)
+    c = torch.randn(2, 77, 48)
+    y = R.unet_forward(sd, x, torch.tensor([10, 500]), c, rcfg, used_keys=used)
+    assert y.shape == (2, 4, 16, 16)
+    assert used == set(sd.keys())
+    # DIFT early exit: up_blocks[1] output includes its 2x upsampler -> h/2
+    ft = R.unet_forward(sd, x, torch.tensor(161), c, rcfg, up_ft_indices=[1])["up_ft"][1]
+    assert ft.shape == (2, 64, 8, 8)
+
+
+def test_odd_latent_size_walk():
+    """32x42 -> 16x21 -> 8x11 -> 4x6 and back through `upsample_size` (dift.py:54-56,146-147)."""
+    cfg, rcfg = tiny_cfgs()
+    sd = tiny_sd()
+    x = torch.randn(1, 4, 32, 42)
+    y = R.unet_forward(sd, x, torch.tensor([7]), torch.randn(1, 77, 48), rcfg)
+    assert y.shape == (1, 4, 32, 42)
+
+
+def test_algebraic_properties():
+    cfg, rcfg = tiny_cfgs()
+    sd = tiny_sd()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 4, 8, 8, generator=g)
+    t = torch.tensor([3, 400, 999])
+    c = torch.randn(3, 77, 48, generator=g)
+    y = R.unet_forward(sd, x, t, c, rcfg)
+    # batch-permutation equivariance
+    perm = torch.tensor([2, 0, 1])
+    yp = R.unet_forward(sd, x[perm], t[perm], c[perm], rcfg)
+    torch.testing.assert_close(yp, y[perm], atol=1e-5, rtol=1e-5)
+    # zero conv_out.weight => prediction equals the conv_out bias
+    sd0 = dict(sd)
+    sd0["conv_out.weight"] = torch.zeros_like(sd["conv_out.weight"])
+    y0 = R.unet_forward(sd0, x, t, c, rcfg)
+    torch.testing.assert_close(y0, sd["conv_out.bias"][None, :, None, None].expand_as(y0))
+    # conditioning matters
+    y2 = R.unet_forward(sd, x, t, c + 1.0, rcfg)
+    assert (y2 - y).abs().max() > 1e-4
+
+
+def test_compute_losses_layout_and_tiling():
+    """cond-major tiling of compute.py:150-155: row k*B+i = draw i under condition k."""
+    cfg, rcfg = tiny_cfgs()
+    sd = tiny_sd()
+    x = torch.randn(1, 4, 8, 8).half()
+    noises, ts = R.draw_noise_and_timesteps((1, 4, 8, 8), 5, 0.1, 0.7, seed=42)
+    assert noises.shape == (5, 4, 8, 8) and noises.dtype == torch.float16
+    assert ts.dtype == torch.int64 and int(ts.min()) >= 100 and int(ts.max()) < 700
+    c = torch.randn(2, 77, 48)
+    grid = R.compute_losses(sd, x, c, noises, ts, B=2, cfg=rcfg, autocast=False)
+    assert grid.shape == (5, 2, 4, 8, 8) and grid.dtype == torch.float16
+    # identical prompts in both slots => L[:,0] == L[:,1] bit-exact
+    grid_same = R.compute_losses(sd, x, torch.stack([c[0], c[0]]), noises, ts, B=2, cfg=rcfg)
+    assert torch.equal(grid_same[:, 0], grid_same[:, 1])
+    # one direct call reproduces element [3, 1] (fp32 mode: fp16 emulation is batch-order sensitive)
+    l = R.compute_loss(sd, x, noises[3:4], ts[3:4], c[1:2], rcfg, autocast=False)
+    torch.testing.assert_close(l[0].half(), grid[3, 1], atol=2e-3, rtol=2e-3)
+    # chunk size does not change the result beyond batch-order effects of CPU BLAS
+    grid5 = R.compute_losses(sd, x, c, noises, ts, B=5, cfg=rcfg, autocast=False)
+    torch.testing.assert_close(grid5.float(), grid.float(), atol=2e-3, rtol=2e-3)
+    # reductions
+    tm = R.typicality_map(grid)
+    assert tm.shape == (8, 8)
+    ref = (grid.float()[:, 1] - grid.float()[:, 0]).mean(dim=(0, 1))
+    torch.testing.assert_close(tm, ref, atol=1e-5, rtol=1e-5)
+
+
+def test_draws_are_seed_reproducible():
+    a = R.draw_noise_and_timesteps((1, 4, 8, 8), 4, 0.1, 0.7, seed=42)
+    b = R.draw_noise_and_timesteps((1, 4, 8, 8), 4, 0.1, 0.7, seed=42)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_autocast_emulation_is_close_to_fp32():
+    cfg, rcfg = tiny_cfgs()
+    sd = tiny_sd()
+    x = torch.randn(2, 4, 8, 8).half().float()
+    c = torch.randn(2, 77, 48).half().float()
+    t = torch.tensor([100, 650])
+    y32 = R.unet_forward(sd, x, t, c, rcfg, autocast=False)
+    y16 = R.unet_forward(sd, x, t, c, rcfg, autocast=True)
+    rel = ((y16 - y32).norm() / y32.norm()).item()
+    assert rel < 5e-3, rel
+    assert torch.equal(y16, y16.half().float())      # autocast output is fp16-representable
+
+
+def test_synth_weights_are_deterministic_and_fp16():
+    a = synth.synth_tensor("conv_in.weight", (320, 4, 3, 3), seed=0)
+    b = synth.synth_tensor("conv_in.weight", (320, 4, 3, 3), seed=0)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, a.astype(np.float16).astype(np.float32))
+    # pinned values: integer-hash generator must not drift across machines / NumPy versions
+    z = synth.hash_normal("conv_in.weight", 4, 0)
+    assert z.dtype == np.float64
+    np.testing.assert_allclose(z, synth._hash_normal_range(
+        np.uint64(synth.fnv1a64("conv_in.weight")) ^ synth._splitmix64(
+            np.array([0], dtype=np.uint64) + synth._GOLDEN)[0], 0, 4))
+    assert synth.fnv1a64("a") == 0xAF63DC4C8601EC8C
