@@ -1,0 +1,252 @@
+// attention.hip — K4/K5: flash-style attention on gfx950 MFMA for the SDv1.5 U-Net's
+// `Attention` layers (self: 4096/1024/256/64 tokens; cross: 77 text tokens), head_dim 40/80/160,
+// as executed under `unet(...)` at diffmining/typicality/compute.py:100.  No score matrix is
+// materialised; softmax is online, in fp32, on the fp32 MFMA accumulators; P is rounded to fp16 for
+// the PV product (what flash/xformers kernels do, compute.py:71-72).
+//
+// Work split: one block = 128 queries of one (sample, head); 4 waves x 32 queries.  KV tiles of 64
+// keys are staged global -> registers -> LDS (double buffered, one barrier per tile): K row-major
+// (padded rows), V transposed ([d][key]) so both MFMA operands are k-contiguous ds_read_b128/b64.
+//
+// Trick: the score tile is computed TRANSPOSED, S^T = K · Q^T (K fragment = MFMA A operand), so a
+// lane holds 4 keys x 1 query per fragment.  Those registers are exactly a valid B operand of the
+// PV product O^T = V^T · P^T under a permuted k order (the MFMA k index is a dummy: A and B only
+// have to agree), so P never moves between lanes and never touches LDS.  head_dim is zero padded
+// in LDS only (40 -> 64 for QK^T k, 40 -> 48 for the PV output rows), never in HBM.
+#include "dm_kernels.h"
+
+namespace dm {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int QB = 128;    // queries per block
+constexpr int KT = 64;     // keys per tile
+constexpr int NT = 256;
+
+template <int D>
+struct Cfg {
+    static constexpr int DP = ((D + 31) / 32) * 32;     // k extent of QK^T (zero padded)
+    static constexpr int DV = ((D + 15) / 16) * 16;     // PV output rows (zero padded)
+    static constexpr int KS = DP / 32;
+    static constexpr int EF = DV / 16;
+    static constexpr int NCH = D / 8;                    // 16-byte chunks per row in HBM
+    static constexpr int KSTR = DP * 2 + 16;             // K tile row stride (bytes), padded
+    static constexpr int VSTR = KT * 2 + 16;             // V^T tile row stride (bytes), padded
+    static constexpr int KBYTES = KT * KSTR;
+    static constexpr int VBYTES = DV * VSTR;
+    static constexpr int STAGE = KBYTES + VBYTES;
+    static constexpr int LD_IT = (KT * NCH + NT - 1) / NT;
+};
+
+template <int D>
+__global__ __launch_bounds__(NT)
+void attn_kernel(AttnParams p) {
+    using C = Cfg<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+    const int h = blockIdx.y;
+    const int b = blockIdx.z;
+    const int q0 = blockIdx.x * QB + wid * 32;
+    const int kvb = p.kv_slot ? p.kv_slot[b] : b;
+
+    const f16* Qb = p.Q + (size_t)b * p.bsq + h * D;
+    const f16* Kb = p.K + (size_t)kvb * p.bsk + h * D;
+    const f16* Vb = p.V + (size_t)kvb * p.bsv + h * D;
+    f16* Ob = p.O + (size_t)b * p.bso + h * D;
+
+    // ---- zero the LDS padding once (columns D..DP of K rows, rows D..DV of V^T) -----------------
+    for (int i = tid * 16; i < 2 * C::STAGE; i += NT * 16)
+        *reinterpret_cast<u32x4*>(smem + i) = u32x4{0u, 0u, 0u, 0u};
+
+    // ---- Q fragments (B operand): lane holds Q[q = 16 jq + l15][d = 32 s + 8 lg .. +8] ---------
+    half8 qf[2][C::KS];
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq) {
+        int q = q0 + 16 * jq + l15;
+        q = q < p.Tq ? q : p.Tq - 1;
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s) {
+            const int d = 32 * s + 8 * lg;
+            if (d < D)
+                qf[jq][s] = *reinterpret_cast<const half8*>(Qb + (size_t)q * p.ldq + d);
+            else
+                qf[jq][s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+
+    floatx4 oacc[C::EF][2];
+#pragma unroll
+    for (int e = 0; e < C::EF; ++e) { oacc[e][0] = floatx4{0, 0, 0, 0}; oacc[e][1] = floatx4{0, 0, 0, 0}; }
+    float m_run[2] = {-INFINITY, -INFINITY};
+    float l_run[2] = {0.f, 0.f};
+    const float sc = p.scale * 1.44269504088896340736f;   // scores live in the log2 domain
+
+    // ---- KV tile staging ------------------------------------------------------------------------
+    u32x4 kr[C::LD_IT], vr[C::LD_IT];
+    auto load_regs = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < C::LD_IT; ++it) {
+            const int idx = tid + it * NT;
+            const int key = idx / C::NCH, ch = idx - key * C::NCH;
+            if (idx < KT * C::NCH && k0 + key < p.Tk) {
+                kr[it] = *reinterpret_cast<const u32x4*>(Kb + (size_t)(k0 + key) * p.ldk + ch * 8);
+                vr[it] = *reinterpret_cast<const u32x4*>(Vb + (size_t)(k0 + key) * p.ldv + ch * 8);
+            } else {
+                kr[it] = u32x4{0u, 0u, 0u, 0u};
+                vr[it] = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    auto store_lds = [&](int buf) {
+        char* kt = smem + buf * C::STAGE;
+        char* vt = kt + C::KBYTES;
+#pragma unroll
+        for (int it = 0; it < C::LD_IT; ++it) {
+            const int idx = tid + it * NT;
+            const int key = idx / C::NCH, ch = idx - key * C::NCH;
+            if (idx < KT * C::NCH) {
+                *reinterpret_cast<u32x4*>(kt + key * C::KSTR + ch * 16) = kr[it];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    *reinterpret_cast<unsigned short*>(vt + (ch * 8 + jj) * C::VSTR + key * 2) =
+                        (unsigned short)((vr[it][jj >> 1] >> ((jj & 1) * 16)) & 0xFFFFu);
+            }
+        }
+    };
+
+    auto compute = [&](int buf, int k0) {
+        const char* kt = smem + buf * C::STAGE;
+        const char* vt = kt + C::KBYTES;
+        // S^T = K Q^T : sacc[f][jq][r] = score(key 16f + 4lg + r, query 16jq + l15)
+        floatx4 sacc[4][2];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { sacc[f][0] = floatx4{0, 0, 0, 0}; sacc[f][1] = floatx4{0, 0, 0, 0}; }
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const half8 kf = *reinterpret_cast<const half8*>(kt + (16 * f + l15) * C::KSTR + (32 * s + 8 * lg) * 2);
+                sacc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][s], sacc[f][0], 0, 0, 0);
+                sacc[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][s], sacc[f][1], 0, 0, 0);
+            }
+        }
+        const bool tail = (k0 + KT > p.Tk);
+        half8 pb[2][2];
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sv = sacc[f][jq][r] * sc;
+                    if (tail && (k0 + 16 * f + 4 * lg + r >= p.Tk)) sv = -INFINITY;
+                    sacc[f][jq][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[jq], mx);
+            const float alpha = exp2f(m_run[jq] - m_new);
+            m_run[jq] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = exp2f(sacc[f][jq][r] - m_new);
+                    ps += pv;
+                    pb[jq][f >> 1][(f & 1) * 4 + r] = (f16)pv;
+                }
+            l_run[jq] = l_run[jq] * alpha + ps;
+#pragma unroll
+            for (int e = 0; e < C::EF; ++e) oacc[e][jq] *= alpha;
+        }
+        // O^T += V^T P^T with k slot (lg, j) <-> key 32 s2 + 16 (j>>2) + 4 lg + (j&3)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int e = 0; e < C::EF; ++e) {
+                const char* vrow = vt + (16 * e + l15) * C::VSTR + (32 * s2 + 4 * lg) * 2;
+                const half4 v0 = *reinterpret_cast<const half4*>(vrow);
+                const half4 v1 = *reinterpret_cast<const half4*>(vrow + 32);
+                const half8 va = half8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                oacc[e][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[0][s2], oacc[e][0], 0, 0, 0);
+                oacc[e][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[1][s2], oacc[e][1], 0, 0, 0);
+            }
+        }
+    };
+
+    const int ntiles = (p.Tk + KT - 1) / KT;
+    load_regs(0);
+    __syncthreads();            // padding zero-fill complete before the first tile write
+    store_lds(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles - 1; ++t) {
+        const int cur = t & 1;
+        load_regs((t + 1) * KT);
+        compute(cur, t * KT);
+        store_lds(cur ^ 1);
+        __syncthreads();
+    }
+    compute((ntiles - 1) & 1, (ntiles - 1) * KT);
+
+    // ---- finalize: O[q][16e + 4lg + r] = oacc / l ------------------------------------------------
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq) {
+        float l = l_run[jq];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int q = q0 + 16 * jq + l15;
+        if (q >= p.Tq) continue;
+#pragma unroll
+        for (int e = 0; e < C::EF; ++e) {
+            const int d = 16 * e + 4 * lg;
+            if (d < D) {
+                const half4 o = half4{(f16)(oacc[e][jq][0] * inv), (f16)(oacc[e][jq][1] * inv),
+                                      (f16)(oacc[e][jq][2] * inv), (f16)(oacc[e][jq][3] * inv)};
+                *reinterpret_cast<half4*>(Ob + (size_t)q * p.ldo + d) = o;
+            }
+        }
+    }
+}
+
+template <int D>
+hipError_t launch_t(const AttnParams& p, hipStream_t s) {
+    using C = Cfg<D>;
+    dim3 grid((p.Tq + QB - 1) / QB, p.heads, p.B), block(NT);
+    const size_t lds = 2 * C::STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_kernel<D>, grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
+    if (p.Tq <= 0 || p.Tk <= 0 || p.B <= 0) return hipErrorInvalidValue;
+    switch (p.D) {
+        case 40: return launch_t<40>(p, s);
+        case 80: return launch_t<80>(p, s);
+        case 160: return launch_t<160>(p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace dm

@@ -1,0 +1,76 @@
+// dm_kernels.h — launcher prototypes of the hand-written gfx950 kernels (internal, C++).
+// The public boundary is include/dm_engine.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace dm {
+
+typedef _Float16 f16;
+
+// ---- K1/K2/K3: implicit-GEMM on MFMA (conv3x3 s1/s2/upsampled, 1x1 conv, linear) -------------
+enum IGemmMode { IG_DENSE = 0, IG_CONV3 = 1, IG_CONV3_S2 = 2, IG_CONV3_UP = 3 };
+enum IGemmEpi { EPI_PLAIN = 0, EPI_GEGLU = 1 };
+
+struct IGemmParams {
+    const f16* X;        // source 1, NHWC [N,H,W,C1] (dense: [M,C1])
+    const f16* X2;       // source 2 (channel concat), NHWC [N,H,W,Cin-C1], or nullptr
+    const f16* Wp;       // packed weights [Cout][taps*Cin], K order = (tap, cin)
+    const f16* bias;     // [Cout] or nullptr
+    const f16* temb;     // per-sample channel add [N][temb_ld] (already offset), or nullptr
+    const f16* res;      // residual [M][ldres] or nullptr
+    f16* Y;              // output [M][ldy] (already offset to the channel slot)
+    int M;               // output rows = N*OH*OW
+    int Cout, Cin, C1;   // Cin = C1 + C2
+    int H, W, OH, OW;    // source spatial dims / output spatial dims (dense: H=OH=1, W=OW=M)
+    int mode, epi;
+    int ldy, ldres, temb_ld;
+};
+hipError_t launch_igemm(const IGemmParams& p, hipStream_t s);
+
+// ---- K4/K5: flash attention (self and cross), head_dim 40/80/160 ------------------------------
+struct AttnParams {
+    const f16* Q; const f16* K; const f16* V; f16* O;
+    int ldq, ldk, ldv, ldo;          // row strides in elements
+    long long bsq, bsk, bsv, bso;    // batch strides in elements
+    const int32_t* kv_slot;          // optional: K/V batch index per sample (prompt slot)
+    int B, heads, Tq, Tk, D;
+    float scale;
+};
+hipError_t launch_attention(const AttnParams& p, hipStream_t s);
+
+// ---- K6: GroupNorm statistics + apply(+SiLU); K7: LayerNorm ----------------------------------
+// x = concat(X[...,C1], X2[...,C-C1]) NHWC; stats [N][G][2] = (mean, rstd) fp32
+hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, float eps,
+                           double* partial /* [N][chunks][G][2] */, float* stats, hipStream_t s);
+int gn_stats_chunks(int HW);
+hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G,
+                           const float* stats, const float* gamma, const float* beta, int silu,
+                           f16* Y, hipStream_t s);
+hipError_t launch_layernorm(const f16* X, int rows, int C, const float* gamma, const float* beta,
+                            float eps, f16* Y, hipStream_t s);
+
+// ---- K8/K9/K10/K11 and glue -------------------------------------------------------------------
+// temb0[b][320] = fp16(sinusoid table[t[b]])
+hipError_t launch_time_gather(const f16* table, const int64_t* t, int B, int dim, f16* out, hipStream_t s);
+hipError_t launch_silu(const f16* in, f16* out, long long n, hipStream_t s);
+// add_noise (fp16 arithmetic, table cast to fp16 first) fused with conv_in 3x3 (4 -> C0), NHWC out.
+// if acp16 == nullptr the sample is used as is (plain U-Net forward / DIFT).
+hipError_t launch_conv_in(const f16* x, const int32_t* x_index, const f16* eps, const int64_t* t,
+                          const f16* sqrt_acp16, const f16* sqrt_1macp16,
+                          const f16* w /* [C0][36] k=(c,ky,kx) */, const f16* bias,
+                          int B, int H, int W, int C0, f16* Y, hipStream_t s);
+// conv_out 3x3 (C0 -> 4) on the normalised activations, fused eps-MSE (wavefront shuffle reduce).
+// loss [B,4,H,W] fp32 = (float(fp16(conv)) - float(eps))^2 ; if eps == nullptr writes pred fp16 NCHW.
+hipError_t launch_conv_out(const f16* Xn /* NHWC [B,H,W,C0] */, const f16* w /* [4][9*C0] k=(tap,c) */,
+                           const f16* bias, const f16* eps, int B, int H, int W, int C0,
+                           float* loss, f16* pred, hipStream_t s);
+hipError_t launch_nhwc_to_nchw(const f16* X, int N, int HW, int C, f16* Y, hipStream_t s);
+// mean over groups of `ens` consecutive samples, NHWC fp16 -> NCHW fp32
+hipError_t launch_ensemble_mean(const f16* X, int groups, int ens, int HW, int C, float* Y, hipStream_t s);
+// typicality reductions of the loss grid
+hipError_t launch_typicality(const void* loss, int is_f16, int n_draws, int n_cond, int HW,
+                             float* map, float* scalar, hipStream_t s);
+
+}  // namespace dm

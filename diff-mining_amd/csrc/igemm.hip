@@ -1,0 +1,264 @@
+// igemm.hip — K1/K2/K3: implicit-GEMM on gfx950 MFMA for every matmul-shaped op of the SDv1.5
+// U-Net the reference calls at diffmining/typicality/compute.py:100 / dift.py:191:
+// 3x3 conv (stride 1, stride 2, nearest-upsampled input), 1x1 conv and Linear, with fused
+// bias / time-embedding / residual / GEGLU epilogues.
+//
+// Formulation: Y[m][co] = sum_k X~[m][k] * Wp[co][k], m = output pixel (NHWC row), k = (tap, cin).
+// The WEIGHT tile is the MFMA "A" operand (rows = output channels) and the ACTIVATION tile the "B"
+// operand (cols = pixels), so each lane ends up holding 4 consecutive output channels of one
+// pixel -> 8-byte channel-contiguous NHWC stores.
+//
+// Tile: 128 pixels x 160 channels x 64 k per step, 256 threads = 4 waves (2 channel halves x
+// 2 pixel halves), each wave 80 channels x 64 pixels = 5x4 fragments of v_mfma_f32_16x16x32_f16.
+// 160 divides every channel count of the network (320/640/1280/2560/5120/10240).
+// Operand tiles are staged global -> registers -> LDS (XOR-swizzled 128-byte rows, conflict-free
+// ds_read_b128), double buffered, one barrier per k step; the next tile's global loads are issued
+// before the MFMA block and written to LDS after it.
+#include "dm_kernels.h"
+
+namespace dm {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BP = 128;          // pixels per block
+constexpr int BC = 160;          // output channels per block
+constexpr int BK = 64;           // k per step (one tap, 64 input channels)
+constexpr int WT_BYTES = BC * BK * 2;
+constexpr int XT_BYTES = BP * BK * 2;
+constexpr int STAGE_BYTES = WT_BYTES + XT_BYTES;   // 36864
+constexpr int NTHREADS = 256;
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS, 2)
+void igemm_kernel(IGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wc = wid & 1;      // channel half of the block tile
+    const int wp = wid >> 1;     // pixel half
+
+    // ---- block -> tile, XCD aware: blocks that share a pixel tile run on the same XCD ----------
+    const int tiles_c = p.Cout / BC;
+    const int nblk = gridDim.x;
+    int v;
+    {
+        const int b = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = b & 7, loc = b >> 3;
+        v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int pt = v / tiles_c;
+    const int ct = v - pt * tiles_c;
+    const int p0 = pt * BP;
+    const int c0out = ct * BC;
+
+    const int C1 = p.C1;
+    const int C2 = p.Cin - C1;
+    const int ntaps = (p.mode == IG_DENSE) ? 1 : 9;
+    const int cpt = p.Cin / BK;            // k tiles per tap
+    const int nk = ntaps * cpt;
+    const int Ktot = ntaps * p.Cin;
+
+    // ---- per-thread staging coordinates -------------------------------------------------------
+    const int chunk = tid & 7;             // 16-byte chunk within the 128-byte k row
+    const int r0 = tid >> 3;               // rows r0 + 32 i
+    const int swz = (chunk ^ (r0 & 7)) << 4;
+
+    int xn[4], xoh[4], xow[4];
+    const int OHW = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = p0 + r0 + 32 * i;
+        if (m < p.M) {
+            const int n = m / OHW;
+            const int rem = m - n * OHW;
+            const int oh = rem / p.OW;
+            xn[i] = n; xoh[i] = oh; xow[i] = rem - oh * p.OW;
+        } else {
+            xn[i] = -1; xoh[i] = 0; xow[i] = 0;
+        }
+    }
+    const f16* wrow[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+        wrow[i] = p.Wp + (size_t)(c0out + r0 + 32 * i) * Ktot + chunk * 8;
+
+    const float sh = (float)p.H / (float)p.OH;     // nearest-upsample source scale (mode IG_CONV3_UP)
+    const float sw = (float)p.W / (float)p.OW;
+
+    long long xpix[4];                     // source pixel linear index for the current tap, -1 = zero
+    auto set_tap = [&](int tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long long off = -1;
+            if (xn[i] >= 0) {
+                if (p.mode == IG_DENSE) {
+                    off = (long long)(p0 + r0 + 32 * i);
+                } else if (p.mode == IG_CONV3 || p.mode == IG_CONV3_S2) {
+                    const int st = (p.mode == IG_CONV3_S2) ? 2 : 1;
+                    const int ih = xoh[i] * st + dy - 1, iw = xow[i] * st + dx - 1;
+                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                        off = ((long long)xn[i] * p.H + ih) * p.W + iw;
+                } else {   // conv on the nearest-upsampled image of size OH x OW
+                    const int uh = xoh[i] + dy - 1, uw = xow[i] + dx - 1;
+                    if (uh >= 0 && uh < p.OH && uw >= 0 && uw < p.OW) {
+                        int ih = (int)floorf((float)uh * sh); ih = ih < p.H - 1 ? ih : p.H - 1;
+                        int iw = (int)floorf((float)uw * sw); iw = iw < p.W - 1 ? iw : p.W - 1;
+                        off = ((long long)xn[i] * p.H + ih) * p.W + iw;
+                    }
+                }
+            }
+            xpix[i] = off;
+        }
+    };
+
+    u32x4 xr[4], wr[5];
+    int ld_tap = 0, ld_cc = 0;             // (tap, channel-tile) of the NEXT tile to load
+    auto load_regs = [&]() {
+        if (ld_cc == 0) set_tap(ld_tap);
+        const int c0 = ld_cc * BK;
+        const f16* src; int cs, cb;
+        if (c0 < C1) { src = p.X; cs = C1; cb = c0; } else { src = p.X2; cs = C2; cb = c0 - C1; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (xpix[i] >= 0)
+                xr[i] = *reinterpret_cast<const u32x4*>(src + xpix[i] * cs + cb + chunk * 8);
+            else
+                xr[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            wr[i] = *reinterpret_cast<const u32x4*>(wrow[i]);
+            wrow[i] += BK;
+        }
+        if (++ld_cc == cpt) { ld_cc = 0; ++ld_tap; }
+    };
+    auto store_lds = [&](int buf) {
+        char* wt = smem + buf * STAGE_BYTES;
+        char* xt = wt + WT_BYTES;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            *reinterpret_cast<u32x4*>(wt + (r0 + 32 * i) * 128 + swz) = wr[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<u32x4*>(xt + (r0 + 32 * i) * 128 + swz) = xr[i];
+    };
+
+    floatx4 acc[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+    const int a_row_off = (wc * 80 + l15) * 128;
+    const int b_row_off = (wp * 64 + l15) * 128;
+
+    auto compute = [&](int cur) {
+        const char* wt = smem + cur * STAGE_BYTES;
+        const char* xt = wt + WT_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int koff = (((4 * s + lg) ^ (l15 & 7)) << 4);
+            half8 a[5], b[4];
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                a[i] = *reinterpret_cast<const half8*>(wt + a_row_off + i * 16 * 128 + koff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                b[j] = *reinterpret_cast<const half8*>(xt + b_row_off + j * 16 * 128 + koff);
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    load_regs();
+    store_lds(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        const int cur = kt & 1;
+        load_regs();                 // next tile: global loads in flight under the MFMA block
+        compute(cur);
+        store_lds(cur ^ 1);
+        __syncthreads();
+    }
+    compute((nk - 1) & 1);
+
+    // ---- epilogue: D[row = channel (lg*4 + r)][col = pixel l15] --------------------------------
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = p0 + wp * 64 + 16 * j + l15;
+        if (m >= p.M) continue;
+        const int n = (p.temb != nullptr) ? (m / OHW) : 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int c = c0out + wc * 80 + 16 * i + 4 * lg;
+            float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+            if (p.bias) {
+                const half4 bv = *reinterpret_cast<const half4*>(p.bias + c);
+                v0 += (float)bv[0]; v1 += (float)bv[1]; v2 += (float)bv[2]; v3 += (float)bv[3];
+            }
+            if (EPI == EPI_GEGLU) {
+                // packed rows: [h0, h1, g0, g1]; out = fp16(h * fp16(gelu(g))) as fp16 autocast does
+                const f16 h0 = (f16)v0, h1 = (f16)v1, g0 = (f16)v2, g1 = (f16)v3;
+                const f16 q0 = (f16)gelu_erf((float)g0), q1 = (f16)gelu_erf((float)g1);
+                const f16 o0 = (f16)((float)h0 * (float)q0), o1 = (f16)((float)h1 * (float)q1);
+                const int oc = (c >> 4) * 8 + 2 * lg;
+                typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<half2_*>(p.Y + (size_t)m * p.ldy + oc) = half2_{o0, o1};
+            } else {
+                half4 o = half4{(f16)v0, (f16)v1, (f16)v2, (f16)v3};
+                if (p.temb) {
+                    const half4 tv = *reinterpret_cast<const half4*>(p.temb + (size_t)n * p.temb_ld + c);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (f16)((float)o[r] + (float)tv[r]);
+                }
+                if (p.res) {
+                    const half4 rv = *reinterpret_cast<const half4*>(p.res + (size_t)m * p.ldres + c);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (f16)((float)o[r] + (float)rv[r]);
+                }
+                *reinterpret_cast<half4*>(p.Y + (size_t)m * p.ldy + c) = o;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
+    if (p.Cout % BC != 0 || p.Cin % BK != 0 || p.C1 % BK != 0 || p.M <= 0) return hipErrorInvalidValue;
+    const int tiles_p = (p.M + BP - 1) / BP;
+    const int tiles_c = p.Cout / BC;
+    dim3 grid(tiles_p * tiles_c), block(NTHREADS);
+    const size_t lds = 2 * STAGE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<EPI_GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (p.epi == EPI_GEGLU)
+        hipLaunchKernelGGL(igemm_kernel<EPI_GEGLU>, grid, block, lds, s, p);
+    else
+        hipLaunchKernelGGL(igemm_kernel<EPI_PLAIN>, grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace dm

@@ -1,0 +1,267 @@
+// misc.hip — the small HBM-bound kernels around the U-Net of diff-mining's scoring path:
+//   K8  timestep-embedding row gather (sinusoid table precomputed on the host),
+//   K9  scheduler.add_noise (compute.py:99) fused into conv_in (4 -> 320, 3x3),
+//   K10 conv_out (320 -> 4, 3x3) fused with the per-element eps-MSE of compute.py:101
+//       (wavefront-shuffle reduction over the 2880-long dot products),
+//   K11 DIFT ensemble mean (dift.py:231) + NHWC->NCHW feature export,
+//   and the consumers' typicality reductions (cluster.py:125-137, xray/compute.py:210-218).
+#include "dm_kernels.h"
+
+namespace dm {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__global__ void time_gather_kernel(const f16* __restrict__ table, const int64_t* __restrict__ t, int B, int dim,
+                                   f16* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * dim) return;
+    const int b = i / dim, d = i - b * dim;
+    long long tt = t[b];
+    tt = tt < 0 ? 0 : (tt > 999 ? 999 : tt);
+    out[i] = table[tt * dim + d];
+}
+
+__global__ void silu_kernel(const f16* __restrict__ in, f16* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = (float)in[i];
+    out[i] = (f16)(x / (1.0f + __expf(-x)));
+}
+
+// One thread = one output pixel x 8 output channels.  Input is NCHW fp16 (4 channels), the
+// noisy latent is formed in fp16 arithmetic exactly as the fp16 scheduler does:
+//   noisy = fp16(fp16(sa * x) + fp16(sb * eps)),  sa = fp16(sqrt(fp16 acp[t])), sb likewise.
+__global__ void conv_in_kernel(const f16* __restrict__ x, const int32_t* __restrict__ x_index,
+                               const f16* __restrict__ eps, const int64_t* __restrict__ t,
+                               const f16* __restrict__ sa_tab, const f16* __restrict__ sb_tab,
+                               const f16* __restrict__ w, const f16* __restrict__ bias, int B, int H, int W, int C0,
+                               f16* __restrict__ Y) {
+    const int cg = C0 >> 3;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * H * W * cg;
+    if (i >= total) return;
+    const int cgi = (int)(i % cg);
+    const long long pix = i / cg;
+    const int HW = H * W;
+    const int b = (int)(pix / HW);
+    const int rem = (int)(pix - (long long)b * HW);
+    const int oh = rem / W, ow = rem - oh * W;
+    const bool noise = (sa_tab != nullptr);
+    f16 sa = (f16)1.0f, sb = (f16)0.0f;
+    if (noise) {
+        long long tt = t[b];
+        tt = tt < 0 ? 0 : (tt > 999 ? 999 : tt);
+        sa = sa_tab[tt]; sb = sb_tab[tt];
+    }
+    const int xb = x_index ? x_index[b] : b;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int c = 0; c < 4; ++c) {
+        for (int dy = 0; dy < 3; ++dy) {
+            const int ih = oh + dy - 1;
+            if (ih < 0 || ih >= H) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int iw = ow + dx - 1;
+                if (iw < 0 || iw >= W) continue;
+                f16 v = x[((size_t)xb * 4 + c) * HW + ih * W + iw];
+                if (noise) {
+                    const f16 e = eps[((size_t)b * 4 + c) * HW + ih * W + iw];
+                    const f16 p1 = sa * v;          // fp16 multiply, rounded
+                    const f16 p2 = sb * e;
+                    v = p1 + p2;                    // fp16 add, rounded
+                }
+                const float fv = (float)v;
+                const int kidx = c * 9 + dy * 3 + dx;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += fv * (float)w[(cgi * 8 + k) * 36 + kidx];
+            }
+        }
+    }
+    half8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (f16)(acc[k] + (float)bias[cgi * 8 + k]);
+    *reinterpret_cast<half8*>(Y + pix * C0 + cgi * 8) = o;
+}
+
+// conv_out + eps-MSE.  8 lanes cooperate on one pixel: lane j of the group walks the 16-byte
+// channel chunks j, j+8, ... of the 9 taps; the four 2880-long dot products are then reduced with
+// xor-shuffles inside the wavefront.  Weights [4][9*C0] are staged in LDS once per block.
+__global__ __launch_bounds__(256)
+void conv_out_kernel(const f16* __restrict__ Xn, const f16* __restrict__ w, const f16* __restrict__ bias,
+                     const f16* __restrict__ eps, int B, int H, int W, int C0, float* __restrict__ loss,
+                     f16* __restrict__ pred) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16* ws = reinterpret_cast<f16*>(smem);
+    const int K = 9 * C0;
+    for (int i = threadIdx.x * 8; i < 4 * K; i += blockDim.x * 8)
+        *reinterpret_cast<half8*>(ws + i) = *reinterpret_cast<const half8*>(w + i);
+    __syncthreads();
+    const int HW = H * W;
+    const long long npix = (long long)B * HW;
+    const int sub = threadIdx.x & 7;
+    const long long pix = (long long)blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);
+    const bool valid = pix < npix;
+    const long long pp = valid ? pix : 0;
+    const int b = (int)(pp / HW);
+    const int rem = (int)(pp - (long long)b * HW);
+    const int oh = rem / W, ow = rem - oh * W;
+    const int nch = C0 >> 3;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const int ih = oh + dy - 1, iw = ow + dx - 1;
+        if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+        const f16* src = Xn + (((size_t)b * H + ih) * W + iw) * C0;
+        for (int ch = sub; ch < nch; ch += 8) {
+            const half8 v = *reinterpret_cast<const half8*>(src + ch * 8);
+            const int kb = tap * C0 + ch * 8;
+            const half8 w0 = *reinterpret_cast<const half8*>(ws + kb);
+            const half8 w1 = *reinterpret_cast<const half8*>(ws + K + kb);
+            const half8 w2 = *reinterpret_cast<const half8*>(ws + 2 * K + kb);
+            const half8 w3 = *reinterpret_cast<const half8*>(ws + 3 * K + kb);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float f = (float)v[k];
+                a0 += f * (float)w0[k]; a1 += f * (float)w1[k]; a2 += f * (float)w2[k]; a3 += f * (float)w3[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); a3 += __shfl_xor(a3, o);
+    }
+    if (valid && sub < 4) {
+        const float a = sub == 0 ? a0 : (sub == 1 ? a1 : (sub == 2 ? a2 : a3));
+        const f16 pr = (f16)(a + (float)bias[sub]);
+        const size_t oidx = ((size_t)b * 4 + sub) * HW + rem;
+        if (eps) {
+            const float d = (float)pr - (float)eps[oidx];
+            loss[oidx] = d * d;
+        }
+        if (pred) pred[oidx] = pr;
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const f16* __restrict__ X, int HW, int C, f16* __restrict__ Y) {
+    __shared__ f16 tile[32][33];
+    const int n = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        tile[r][tx] = (p < HW && c < C) ? X[((size_t)n * HW + p) * C + c] : (f16)0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (p < HW && c < C) Y[((size_t)n * C + c) * HW + p] = tile[tx][r];
+    }
+}
+
+__global__ void ensemble_mean_kernel(const f16* __restrict__ X, int ens, int HW, int C, float* __restrict__ Y) {
+    __shared__ float tile[32][33];
+    const int g = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        float s = 0.f;
+        if (p < HW && c < C)
+            for (int e = 0; e < ens; ++e) s += (float)X[(((size_t)g * ens + e) * HW + p) * C + c];
+        tile[r][tx] = s / (float)ens;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (p < HW && c < C) Y[((size_t)g * C + c) * HW + p] = tile[tx][r];
+    }
+}
+
+// map[p] = mean_n( mean_c L[n, last, c, p] - mean_c L[n, 0, c, p] ); deterministic (fixed order).
+template <typename T>
+__global__ void typicality_map_kernel(const T* __restrict__ L, int n_draws, int n_cond, int HW, float* __restrict__ map) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    float acc = 0.f;
+    for (int n = 0; n < n_draws; ++n) {
+        const T* l0 = L + ((size_t)n * n_cond + 0) * 4 * HW;
+        const T* l1 = L + ((size_t)n * n_cond + (n_cond - 1)) * 4 * HW;
+        float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { m0 += (float)l0[(size_t)c * HW + p]; m1 += (float)l1[(size_t)c * HW + p]; }
+        acc += (m1 - m0) * 0.25f;
+    }
+    map[p] = acc / (float)n_draws;
+}
+
+__global__ void mean_reduce_kernel(const float* __restrict__ map, int n, float* __restrict__ out) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)map[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(sh[0] / (double)n);
+}
+
+}  // namespace
+
+hipError_t launch_time_gather(const f16* table, const int64_t* t, int B, int dim, f16* out, hipStream_t s) {
+    hipLaunchKernelGGL(time_gather_kernel, dim3((B * dim + 255) / 256), dim3(256), 0, s, table, t, B, dim, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_silu(const f16* in, f16* out, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_in(const f16* x, const int32_t* x_index, const f16* eps, const int64_t* t,
+                          const f16* sa, const f16* sb, const f16* w, const f16* bias, int B, int H, int W,
+                          int C0, f16* Y, hipStream_t s) {
+    const long long total = (long long)B * H * W * (C0 / 8);
+    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x_index, eps, t,
+                       sa, sb, w, bias, B, H, W, C0, Y);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_out(const f16* Xn, const f16* w, const f16* bias, const f16* eps, int B, int H, int W,
+                           int C0, float* loss, f16* pred, hipStream_t s) {
+    const long long npix = (long long)B * H * W;
+    const size_t lds = (size_t)4 * 9 * C0 * sizeof(f16);
+    hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)((npix + 31) / 32)), dim3(256), lds, s, Xn, w, bias, eps,
+                       B, H, W, C0, loss, pred);
+    return hipGetLastError();
+}
+
+hipError_t launch_nhwc_to_nchw(const f16* X, int N, int HW, int C, f16* Y, hipStream_t s) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((HW + 31) / 32, (C + 31) / 32, N), dim3(256), 0, s, X, HW, C, Y);
+    return hipGetLastError();
+}
+
+hipError_t launch_ensemble_mean(const f16* X, int groups, int ens, int HW, int C, float* Y, hipStream_t s) {
+    hipLaunchKernelGGL(ensemble_mean_kernel, dim3((HW + 31) / 32, (C + 31) / 32, groups), dim3(256), 0, s, X, ens,
+                       HW, C, Y);
+    return hipGetLastError();
+}
+
+hipError_t launch_typicality(const void* loss, int is_f16, int n_draws, int n_cond, int HW, float* map,
+                             float* scalar, hipStream_t s) {
+    if (is_f16)
+        hipLaunchKernelGGL(typicality_map_kernel<f16>, dim3((HW + 255) / 256), dim3(256), 0, s, (const f16*)loss,
+                           n_draws, n_cond, HW, map);
+    else
+        hipLaunchKernelGGL(typicality_map_kernel<float>, dim3((HW + 255) / 256), dim3(256), 0, s,
+                           (const float*)loss, n_draws, n_cond, HW, map);
+    if (scalar) hipLaunchKernelGGL(mean_reduce_kernel, dim3(1), dim3(256), 0, s, map, HW, scalar);
+    return hipGetLastError();
+}
+
+}  // namespace dm

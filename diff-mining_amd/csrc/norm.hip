@@ -1,0 +1,206 @@
+// norm.hip — K6 GroupNorm (fp32 statistics, two-stage deterministic reduction; apply + optional
+// SiLU) and K7 LayerNorm for the SDv1.5 U-Net (`ResnetBlock2D.norm1/2`, `Transformer2DModel.norm`,
+// `BasicTransformerBlock.norm1/2/3`, `conv_norm_out`), reached from compute.py:100 / dift.py:191.
+// Under the reference's fp16 autocast these ops are promoted to fp32; here inputs are the fp16
+// residual stream (NHWC), statistics are fp32 per thread and combined in fp64 (no atomics: the
+// scored outputs must be run-to-run deterministic), outputs are rounded to fp16 once, at the point
+// where the reference's next conv/linear would cast them.
+// All kernels are HBM-bound: 16-byte loads/stores, one pass for stats, one for apply.
+#include "dm_kernels.h"
+
+namespace dm {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int GN_PIX = 64;          // pixels per stats block
+
+// grid (chunks, N); block = (C/8 column threads) x R row groups, <= 320 threads.
+// The channel concat cat([X, X2]) of the up blocks is read in place (never materialised).
+__global__ void gn_stats_partial(const f16* __restrict__ X, const f16* __restrict__ X2, int HW, int C, int C1,
+                                 int G, int R, double* __restrict__ partial) {
+    extern __shared__ float sh[];   // [R][C][2]
+    const int cols = C >> 3;
+    const int n = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const int t = threadIdx.x;
+    const int col = t % cols;
+    const int rg = t / cols;
+    const int px0 = chunk * GN_PIX;
+    const int px1 = min(HW, px0 + GN_PIX);
+    float s[8], q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s[k] = 0.f; q[k] = 0.f; }
+    const int c = col * 8;
+    const int C2 = C - C1;
+    if (rg < R) {
+        for (int px = px0 + rg; px < px1; px += R) {
+            const size_t pix = (size_t)n * HW + px;
+            const f16* src = (c < C1) ? (X + pix * C1 + c) : (X2 + pix * C2 + (c - C1));
+            const half8 v = *reinterpret_cast<const half8*>(src);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float f = (float)v[k]; s[k] += f; q[k] += f * f; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            sh[((size_t)rg * C + c + k) * 2 + 0] = s[k];
+            sh[((size_t)rg * C + c + k) * 2 + 1] = q[k];
+        }
+    }
+    __syncthreads();
+    if (t < G) {
+        const int cpg = C / G;
+        double ds = 0.0, dq = 0.0;
+        for (int r = 0; r < R; ++r)
+            for (int k = 0; k < cpg; ++k) {
+                ds += (double)sh[((size_t)r * C + t * cpg + k) * 2 + 0];
+                dq += (double)sh[((size_t)r * C + t * cpg + k) * 2 + 1];
+            }
+        double* out = partial + (((size_t)n * gridDim.x + chunk) * G + t) * 2;
+        out[0] = ds; out[1] = dq;
+    }
+}
+
+__global__ void gn_stats_final(const double* __restrict__ partial, int total, int chunks, int G, double count,
+                               float eps, float* __restrict__ stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // n*G + g
+    if (i >= total) return;
+    const int n = i / G, g = i - n * G;
+    double ds = 0.0, dq = 0.0;
+    for (int c = 0; c < chunks; ++c) {
+        const double* in = partial + (((size_t)n * chunks + c) * G + g) * 2;
+        ds += in[0]; dq += in[1];
+    }
+    const double mean = ds / count;
+    double var = dq / count - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    stats[(size_t)i * 2 + 0] = (float)mean;
+    stats[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// one thread = 8 channels of one pixel
+__global__ void gn_apply_kernel(const f16* __restrict__ X, const f16* __restrict__ X2, long long total8, int HW,
+                                int C, int C1, int G, const float* __restrict__ stats,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
+                                f16* __restrict__ Y) {
+    const int cols = C >> 3;
+    const int cpg = C / G;
+    const int C2 = C - C1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total8;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i / cols;
+        const int c = (int)(i - pix * cols) * 8;
+        const int n = (int)(pix / HW);
+        const f16* src = (c < C1) ? (X + pix * C1 + c) : (X2 + pix * C2 + (c - C1));
+        const half8 v = *reinterpret_cast<const half8*>(src);
+        half8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ch = c + k;
+            const int g = ch / cpg;
+            const float mean = stats[((size_t)n * G + g) * 2 + 0];
+            const float rstd = stats[((size_t)n * G + g) * 2 + 1];
+            float y = ((float)v[k] - mean) * rstd * gamma[ch] + beta[ch];
+            if (silu) y = silu_f(y);
+            o[k] = (f16)y;
+        }
+        *reinterpret_cast<half8*>(Y + pix * C + c) = o;
+    }
+}
+
+// LayerNorm: one wavefront per row, the row lives in registers (C <= 1280 -> <= 3 vectors/lane),
+// two-pass (mean, then centred variance) with wavefront xor-shuffles.
+template <int NV>
+__global__ void layernorm_kernel(const f16* __restrict__ X, int rows, int C, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float eps, f16* __restrict__ Y) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const f16* x = X + (size_t)row * C;
+    const int nvec = C >> 3;
+    half8 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = lane + 64 * i;
+        if (vi < nvec) {
+            v[i] = *reinterpret_cast<const half8*>(x + vi * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += (float)v[i][k];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = lane + 64 * i;
+        if (vi < nvec) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float d = (float)v[i][k] - mean; q += d * d; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    f16* y = Y + (size_t)row * C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = lane + 64 * i;
+        if (vi < nvec) {
+            half8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                o[k] = (f16)(((float)v[i][k] - mean) * rstd * gamma[vi * 8 + k] + beta[vi * 8 + k]);
+            *reinterpret_cast<half8*>(y + vi * 8) = o;
+        }
+    }
+}
+
+}  // namespace
+
+int gn_stats_chunks(int HW) { return (HW + GN_PIX - 1) / GN_PIX; }
+
+hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, float eps,
+                           double* partial, float* stats, hipStream_t s) {
+    if (C % 8 || C % G || C1 % 8) return hipErrorInvalidValue;
+    const int cols = C / 8;
+    int R = 320 / cols; if (R < 1) R = 1; if (R > 8) R = 8;
+    const int threads = ((cols * R + 63) / 64) * 64;
+    if (threads > 1024) return hipErrorInvalidValue;
+    const int chunks = gn_stats_chunks(HW);
+    const size_t lds = (size_t)R * C * 2 * sizeof(float);
+    hipLaunchKernelGGL(gn_stats_partial, dim3(chunks, N), dim3(threads), lds, s, X, X2 ? X2 : X, HW, C, C1, G, R, partial);
+    const int tot = N * G;
+    hipLaunchKernelGGL(gn_stats_final, dim3((tot + 63) / 64), dim3(64), 0, s, partial, tot, chunks, G,
+                       (double)HW * (double)(C / G), eps, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, const float* stats,
+                           const float* gamma, const float* beta, int silu, f16* Y, hipStream_t s) {
+    const long long total8 = (long long)N * HW * (C / 8);
+    long long blocks = (total8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, X2 ? X2 : X, total8, HW, C, C1, G,
+                       stats, gamma, beta, silu, Y);
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm(const f16* X, int rows, int C, const float* gamma, const float* beta, float eps,
+                            f16* Y, hipStream_t s) {
+    if (C % 8 || C > 64 * 8 * 3) return hipErrorInvalidValue;
+    const int wpb = 4;
+    dim3 grid((rows + wpb - 1) / wpb), block(64 * wpb);
+    const int nvec = C / 8;
+    if (nvec <= 64) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, X, rows, C, gamma, beta, eps, Y);
+    else if (nvec <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, X, rows, C, gamma, beta, eps, Y);
+    else hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, X, rows, C, gamma, beta, eps, Y);
+    return hipGetLastError();
+}
+
+}  // namespace dm

@@ -1,0 +1,272 @@
+"""ctypes binding of libdm_engine.so (C ABI: include/dm_engine.h) — PyTorch-ROCm is used only for
+device memory, streams and `torch.distributed`; every FLOP of the U-Net runs in the HIP library.
+
+There is NO fallback path: if the library is missing or no GPU is present, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdm_engine.so")
+_lib = None
+
+# every symbol include/dm_engine.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "dm_version", "dm_scheduler_alphas_cumprod", "dm_timestep_sinusoid", "dm_engine_create",
+    "dm_engine_destroy", "dm_last_error", "dm_engine_load_weight", "dm_engine_finalize",
+    "dm_engine_set_prompts", "dm_score", "dm_unet_forward", "dm_dift", "dm_dift_shape",
+    "dm_reduce_typicality", "dm_prof_enable", "dm_prof_read", "dm_engine_memory",
+    "dm_op_igemm", "dm_op_attention", "dm_op_groupnorm", "dm_op_layernorm",
+]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Load libdm_engine.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise EngineError(
+            f"{p} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+            "The typicality engine has no CPU / PyTorch fallback.")
+    lib = C.CDLL(p)
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    lib.dm_version.restype = C.c_char_p
+    lib.dm_last_error.restype = C.c_char_p
+    lib.dm_last_error.argtypes = [vp]
+    lib.dm_scheduler_alphas_cumprod.argtypes = [i32, C.c_float, C.c_float, C.POINTER(C.c_float)]
+    lib.dm_timestep_sinusoid.argtypes = [i32, i32, C.POINTER(C.c_float)]
+    lib.dm_engine_create.argtypes = [i32, C.POINTER(vp)]
+    lib.dm_engine_destroy.argtypes = [vp]
+    lib.dm_engine_destroy.restype = None
+    lib.dm_engine_load_weight.argtypes = [vp, C.c_char_p, vp, i32, C.POINTER(i64), i32]
+    lib.dm_engine_finalize.argtypes = [vp]
+    lib.dm_engine_set_prompts.argtypes = [vp, vp, i32, vp]
+    lib.dm_score.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.dm_unet_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    lib.dm_dift.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
+    lib.dm_dift_shape.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.dm_reduce_typicality.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.dm_prof_enable.argtypes = [vp, i32]
+    lib.dm_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64),
+                                 C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
+    lib.dm_engine_memory.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.dm_op_igemm.argtypes = [vp] * 8 + [i32] * 11
+    lib.dm_op_attention.argtypes = [vp] * 5 + [i32] * 4 + [i64] * 4 + [vp] + [i32] * 5 + [C.c_float]
+    lib.dm_op_groupnorm.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, C.c_float, vp, vp, i32, vp]
+    lib.dm_op_layernorm.argtypes = [vp, vp, i32, i32, vp, vp, C.c_float, vp]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def scheduler_alphas_cumprod(n: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012) -> np.ndarray:
+    """Host-only: the engine's own ᾱ table (no GPU needed)."""
+    lib = load_library()
+    out = np.empty(n, dtype=np.float32)
+    if lib.dm_scheduler_alphas_cumprod(n, beta_start, beta_end, out.ctypes.data_as(C.POINTER(C.c_float))):
+        raise EngineError("dm_scheduler_alphas_cumprod failed")
+    return out
+
+
+def timestep_sinusoid(t: int, dim: int = 320) -> np.ndarray:
+    lib = load_library()
+    out = np.empty(dim, dtype=np.float32)
+    if lib.dm_timestep_sinusoid(int(t), dim, out.ctypes.data_as(C.POINTER(C.c_float))):
+        raise EngineError("dm_timestep_sinusoid failed")
+    return out
+
+
+def dift_shape(h: int, w: int, up_ft_index: int = 1) -> Tuple[int, int, int]:
+    lib = load_library()
+    c, oh, ow = C.c_int(), C.c_int(), C.c_int()
+    if lib.dm_dift_shape(h, w, up_ft_index, C.byref(c), C.byref(oh), C.byref(ow)):
+        raise EngineError("dm_dift_shape failed")
+    return c.value, oh.value, ow.value
+
+
+class UNetEngine:
+    """One engine per GPU (the reference is one process per GPU, compute.py:215)."""
+
+    def __init__(self, device: int = 0):
+        import torch
+        self._torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise EngineError("no GPU visible: the MI355X typicality engine has no CPU fallback")
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        h = C.c_void_p()
+        if self.lib.dm_engine_create(self.device_index, C.byref(h)):
+            raise EngineError("dm_engine_create: " + self.lib.dm_last_error(None).decode())
+        self._h = h
+        self.n_prompts = 0
+        self._finalized = False
+
+    # -- plumbing --------------------------------------------------------------------------------
+    def _check(self, rc: int, what: str):
+        if rc:
+            raise EngineError(f"{what}: {self.lib.dm_last_error(self._h).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.dm_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights ---------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, "np.ndarray"]):
+        """sd: diffusers-named U-Net state dict (numpy or torch tensors, fp16/fp32/bf16)."""
+        torch = self._torch
+        for name, t in sd.items():
+            if hasattr(t, "detach"):
+                t = t.detach().to("cpu")
+                t = t.to(torch.float32).numpy() if t.dtype not in (torch.float16, torch.float32) else t.numpy()
+            a = np.ascontiguousarray(t)
+            if a.dtype == np.float16:
+                dt = 0
+            elif a.dtype == np.float32:
+                dt = 1
+            else:
+                a = a.astype(np.float32)
+                dt = 1
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            self._check(self.lib.dm_engine_load_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), dt,
+                                                       shape, a.ndim), f"load_weight({name})")
+        self._check(self.lib.dm_engine_finalize(self._h), "finalize")
+        self._finalized = True
+
+    def load_safetensors(self, path: str):
+        """`unet/diffusion_pytorch_model.safetensors` of a diffusers pipeline directory (the format
+        the reference's `--export-only` writes, finetuning/base.py:245-250)."""
+        from safetensors.numpy import load_file
+        self.load_state_dict(load_file(path))
+
+    # -- prompts ---------------------------------------------------------------------------------
+    def set_prompts(self, ctx):
+        """ctx [P,77,768]: distinct prompt embeddings; precomputes cross-attention K/V for them."""
+        torch = self._torch
+        ctx = ctx.to(self.device, torch.float16).contiguous()
+        assert ctx.dim() == 3 and ctx.shape[1] == 77 and ctx.shape[2] == 768, ctx.shape
+        self._check(self.lib.dm_engine_set_prompts(self._h, C.c_void_p(ctx.data_ptr()), ctx.shape[0], self._stream()),
+                    "set_prompts")
+        self._ctx_keepalive = ctx
+        self.n_prompts = ctx.shape[0]
+
+    def _slots(self, slots, batch):
+        torch = self._torch
+        s = torch.as_tensor(slots, device=self.device).to(torch.int32).contiguous()
+        assert s.shape == (batch,), (s.shape, batch)
+        return s
+
+    # -- hot path --------------------------------------------------------------------------------
+    def score(self, x, eps, t, slots, x_index=None):
+        """SD.compute_loss (compute.py:95-102) fused: returns loss [B,4,h,w] fp32 on the GPU."""
+        torch = self._torch
+        x = x.to(self.device, torch.float16).contiguous()
+        eps = eps.to(self.device, torch.float16).contiguous()
+        B, _, h, w = eps.shape
+        t = t.to(self.device, torch.int64).contiguous()
+        assert t.shape == (B,)
+        s = self._slots(slots, B)
+        xi = None
+        if x_index is not None:
+            xi = torch.as_tensor(x_index, device=self.device).to(torch.int32).contiguous()
+            assert xi.shape == (B,)
+        elif x.shape[0] != B:
+            assert x.shape[0] == 1, "x must have 1 or B rows when x_index is not given"
+            xi = torch.zeros(B, dtype=torch.int32, device=self.device)
+        out = torch.empty(B, 4, h, w, dtype=torch.float32, device=self.device)
+        self._check(self.lib.dm_score(self._h, C.c_void_p(x.data_ptr()),
+                                      C.c_void_p(xi.data_ptr()) if xi is not None else None,
+                                      C.c_void_p(eps.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(s.data_ptr()),
+                                      B, x.shape[0], h, w, C.c_void_p(out.data_ptr()), self._stream()), "dm_score")
+        return out
+
+    def unet(self, sample, t, slots):
+        """`unet(sample, t, ctx).sample` (compute.py:100) -> [B,4,h,w] fp16."""
+        torch = self._torch
+        sample = sample.to(self.device, torch.float16).contiguous()
+        B, _, h, w = sample.shape
+        t = torch.as_tensor(t, device=self.device).to(torch.int64).reshape(-1)
+        if t.numel() == 1:
+            t = t.expand(B)
+        t = t.contiguous()
+        s = self._slots(slots, B)
+        out = torch.empty(B, 4, h, w, dtype=torch.float16, device=self.device)
+        self._check(self.lib.dm_unet_forward(self._h, C.c_void_p(sample.data_ptr()), C.c_void_p(t.data_ptr()),
+                                             C.c_void_p(s.data_ptr()), B, h, w, C.c_void_p(out.data_ptr()),
+                                             self._stream()), "dm_unet_forward")
+        return out
+
+    def dift(self, noisy, t, slots, up_ft_index: int = 1, ensemble: Optional[int] = None):
+        """MyUNet2DConditionModel.forward tap (dift.py:24-169).  Returns (features fp16 [B,C,h',w'],
+        ensemble mean fp32 [B/ens,C,h',w'] or None)."""
+        torch = self._torch
+        noisy = noisy.to(self.device, torch.float16).contiguous()
+        B, _, h, w = noisy.shape
+        t = torch.as_tensor(t, device=self.device).to(torch.int64).reshape(-1)
+        if t.numel() == 1:
+            t = t.expand(B)
+        t = t.contiguous()
+        s = self._slots(slots, B)
+        c, oh, ow = dift_shape(h, w, up_ft_index)
+        feat = torch.empty(B, c, oh, ow, dtype=torch.float16, device=self.device)
+        mean = None
+        if ensemble:
+            mean = torch.empty(B // ensemble, c, oh, ow, dtype=torch.float32, device=self.device)
+        self._check(self.lib.dm_dift(self._h, C.c_void_p(noisy.data_ptr()), C.c_void_p(t.data_ptr()),
+                                     C.c_void_p(s.data_ptr()), B, h, w, up_ft_index, C.c_void_p(feat.data_ptr()),
+                                     C.c_void_p(mean.data_ptr()) if mean is not None else None,
+                                     int(ensemble or 1), self._stream()), "dm_dift")
+        return feat, mean
+
+    def reduce_typicality(self, grid):
+        """grid [N,n_cond,4,h,w] (fp32 or fp16, on the GPU) -> (map [h,w] fp32, scalar [1] fp32)."""
+        torch = self._torch
+        grid = grid.to(self.device).contiguous()
+        assert grid.dim() == 5 and grid.shape[2] == 4
+        assert grid.dtype in (torch.float16, torch.float32)
+        N, nc, _, h, w = grid.shape
+        m = torch.empty(h, w, dtype=torch.float32, device=self.device)
+        sc = torch.empty(1, dtype=torch.float32, device=self.device)
+        self._check(self.lib.dm_reduce_typicality(self._h, C.c_void_p(grid.data_ptr()),
+                                                  1 if grid.dtype == torch.float16 else 0, N, nc, h, w,
+                                                  C.c_void_p(m.data_ptr()), C.c_void_p(sc.data_ptr()), self._stream()),
+                    "dm_reduce_typicality")
+        return m, sc
+
+    # -- measurement -----------------------------------------------------------------------------
+    def prof_enable(self, on: bool = True):
+        self._check(self.lib.dm_prof_enable(self._h, 1 if on else 0), "prof_enable")
+
+    def prof_read(self) -> dict:
+        a, b, c2 = C.c_double(), C.c_double(), C.c_int64()
+        d, e, f = C.c_double(), C.c_double(), C.c_int64()
+        self._check(self.lib.dm_prof_read(self._h, C.byref(a), C.byref(b), C.byref(c2), C.byref(d), C.byref(e),
+                                          C.byref(f)), "prof_read")
+        return {"igemm_ms": a.value, "igemm_flops": b.value, "igemm_launches": c2.value,
+                "attn_ms": d.value, "attn_flops": e.value, "attn_launches": f.value}
+
+    def memory(self) -> dict:
+        a, b = C.c_size_t(), C.c_size_t()
+        self._check(self.lib.dm_engine_memory(self._h, C.byref(a), C.byref(b)), "memory")
+        return {"weights_bytes": a.value, "arena_bytes": b.value}

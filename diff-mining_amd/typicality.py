@@ -1,0 +1,164 @@
+"""Host-side mirror of the reference's scoring surface over the HIP engine.
+
+    reference                                         here
+    ------------------------------------------------  -----------------------------------------
+    SD.compute_loss          compute.py:95-102        TypicalityScorer.compute_loss
+    D.noising                compute.py:115-124       TypicalityScorer.noising / draw
+    D.compute_losses         compute.py:134-160       TypicalityScorer.compute_losses
+    D.get_path / np.save     compute.py:162-163,192   TypicalityScorer.save_grid (same .npy layout)
+    Typicallity.compute      xray/compute.py:210-218  TypicalityScorer.heatmap / typicality_scalar
+    unet(sample, t, c).sample compute.py:100          UNetCallable (assignable over `pipe.unet`)
+
+Same names, argument meaning and output layout ([N, n_cond, 4, h, w] float16, cond 0 = c,
+1 = null); differences are stated where they exist:
+  * the engine starts from the latent `x` (the VAE encode of compute.py:137 is outside the path);
+  * all N draws of an image are scored in as few U-Net batches as the engine's workspace allows
+    instead of B-sized chunks with a D2H copy each (compute.py:145-156) — `B` is accepted and
+    ignored for the result (it never changes the math, only the chunking);
+  * (eps, t) are drawn on the CPU generator by default so the values are reproducible across
+    devices; the reference's device-Philox draws are launch-geometry dependent.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from .engine import UNetEngine
+
+
+class _Sample:
+    """`unet(...).sample` result object."""
+
+    def __init__(self, sample):
+        self.sample = sample
+
+
+class UNetCallable:
+    """Drop-in for `pipe.unet` on the scoring path: `unet(sample, timestep, encoder_hidden_states).sample`.
+
+    Distinct prompts are detected by row equality (the reference tiles n_cond prompts over 2B rows,
+    compute.py:152); their cross-attention K/V are computed once."""
+
+    def __init__(self, engine: UNetEngine):
+        self.engine = engine
+        self._ctx_key = None
+
+    def _slots_for(self, c: torch.Tensor):
+        flat = c.reshape(c.shape[0], -1)
+        uniq, inv = torch.unique(flat, dim=0, return_inverse=True)
+        if self._ctx_key is None or self._ctx_key.shape != uniq.shape or not torch.equal(self._ctx_key, uniq):
+            self.engine.set_prompts(uniq.reshape(uniq.shape[0], c.shape[1], c.shape[2]))
+            self._ctx_key = uniq
+        return inv.to(torch.int32)
+
+    def __call__(self, sample, timestep, encoder_hidden_states, **_):
+        eng = self.engine
+        c = encoder_hidden_states.to(eng.device, torch.float16)
+        slots = self._slots_for(c)
+        t = torch.as_tensor(timestep, device=eng.device).reshape(-1)
+        if t.numel() == 1:
+            t = t.expand(sample.shape[0])
+        return _Sample(eng.unet(sample, t, slots))
+
+
+class TypicalityScorer:
+    """`SD` + `D` of diffmining/typicality/compute.py:56-160 on the MI355X engine."""
+
+    def __init__(self, engine: UNetEngine, seed: int = 42, N: int = 100, t_min: float = 0.0, t_max: float = 1.0,
+                 num_train_timesteps: int = 1000, generator_device: str = "cpu"):
+        self.engine = engine
+        self.device = engine.device
+        self.seed, self.N, self.t_min, self.t_max = seed, N, t_min, t_max
+        self.num_train_timesteps = num_train_timesteps
+        self.generator_device = generator_device
+        self.unet = UNetCallable(engine)
+
+    # -- SD.compute_loss (compute.py:95-102) -----------------------------------------------------
+    @torch.no_grad()
+    def compute_loss(self, x, noise, timesteps, c):
+        """x [1 or 2B,4,h,w]; noise [2B,4,h,w]; timesteps [2B]; c [2B,77,768] -> loss [2B,4,h,w] fp32."""
+        n = c.shape[0]
+        noise = noise.expand(n, -1, -1, -1)
+        timesteps = timesteps.expand(n)
+        slots = self.unet._slots_for(c.to(self.device, torch.float16))
+        return self.engine.score(x, noise, timesteps, slots)
+
+    # -- D.noising (compute.py:115-124) ----------------------------------------------------------
+    def draw(self, shape, N: Optional[int] = None):
+        """N interleaved (randn_like, randint) draws after manual_seed(seed) (compute.py:139-141)."""
+        N = self.N if N is None else N
+        g = torch.Generator(device=self.generator_device)
+        g.manual_seed(self.seed)
+        lo, hi = int(self.t_min * self.num_train_timesteps), int(self.t_max * self.num_train_timesteps)
+        noises, ts = [], []
+        for _ in range(N):
+            noises.append(torch.randn(tuple(shape), generator=g, dtype=torch.float32,
+                                      device=self.generator_device).to(torch.float16))
+            ts.append(torch.randint(lo, hi, (1,), generator=g, device=self.generator_device).long())
+        return torch.cat(noises, 0), torch.cat(ts, 0)
+
+    # -- D.compute_losses (compute.py:134-160) ---------------------------------------------------
+    @torch.no_grad()
+    def compute_losses(self, x, country_embeds, B: int = 10, noises=None, timesteps=None, to_host: bool = True):
+        """x [1,4,h,w] latent (fp16); country_embeds [n_cond,77,768] (0 = c, 1 = null).
+        Returns [N, n_cond, 4, h, w] float16 (on the host like the reference, or on the GPU)."""
+        eng = self.engine
+        if noises is None or timesteps is None:
+            noises, timesteps = self.draw(x.shape)
+        N = noises.shape[0]
+        n_cond = country_embeds.shape[0]
+        eng.set_prompts(country_embeds)
+        self.unet._ctx_key = None
+        # sample row k*N + i = draw i under condition k  -> view as [n_cond, N] then transpose
+        n_batch = torch.cat([noises.to(self.device)] * n_cond, 0)
+        t_batch = torch.cat([timesteps.to(self.device)] * n_cond, 0)
+        slots = torch.arange(n_cond, dtype=torch.int32, device=self.device).repeat_interleave(N)
+        loss = eng.score(x, n_batch, t_batch, slots)                       # [n_cond*N,4,h,w] fp32
+        grid = loss.view(n_cond, N, *loss.shape[1:]).transpose(0, 1).to(torch.float16)   # compute.py:155,160
+        return grid.cpu() if to_host else grid.contiguous()
+
+    # -- D.get_path / np.save (compute.py:162-163,192) -------------------------------------------
+    @staticmethod
+    def get_path(typicality_path: str, path: str) -> str:
+        return os.path.join(typicality_path, os.path.split(path)[1].replace(".jpg", ".npy").replace(".png", ".npy"))
+
+    def save_grid(self, typicality_path: str, image_path: str, grid) -> str:
+        out = self.get_path(typicality_path, image_path)
+        os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+        np.save(open(out, "wb"), grid.cpu().numpy())
+        return out
+
+    # -- consumers' reductions (xray/compute.py:210-218, cluster.py:517-531) on the GPU ----------
+    def heatmap(self, grid):
+        return self.engine.reduce_typicality(grid)[0]
+
+    def typicality_scalar(self, grid):
+        return self.engine.reduce_typicality(grid)[1]
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> Sequence[int]:
+    """Image-major sharding `subs[i::sub_split]` of compute.py:339."""
+    return list(range(rank, n_items, world))
+
+
+def gather_scores(local_scores: torch.Tensor, n_items: int, rank: int, world: int) -> torch.Tensor:
+    """Single all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests) of the per-image T(x|c)
+    scalars; returns them in global image order.  No other collective exists on the path."""
+    import torch.distributed as dist
+    per = (n_items + world - 1) // world
+    buf = torch.full((per,), float("nan"), dtype=torch.float32, device=local_scores.device)
+    buf[: local_scores.numel()] = local_scores.to(torch.float32)
+    if world == 1 or not dist.is_initialized():
+        allv = buf[None]
+    else:
+        out = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(out, buf)
+        allv = torch.stack(out, 0)
+    res = torch.empty(n_items, dtype=torch.float32, device=local_scores.device)
+    for r in range(world):
+        idx = shard_indices(n_items, r, world)
+        res[idx] = allv[r, : len(idx)]
+    return res

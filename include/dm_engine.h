@@ -1,0 +1,140 @@
+/*
+ * dm_engine.h — C ABI of the MI355X typicality-scoring engine (libdm_engine.so).
+ *
+ * This is the drop-in boundary for diff-mining's hot path.  The reference has no FFI of its own:
+ * its seam is the Python attribute `self.model.unet` / `self.pipe.unet` (a diffusers
+ * `UNet2DConditionModel`), driven from
+ *     diffmining/typicality/compute.py:95-102   SD.compute_loss   (add_noise -> unet -> mse_loss)
+ *     diffmining/typicality/compute.py:134-160  D.compute_losses  ([N,2,4,h,w] fp16 grid)
+ *     diffmining/typicality/dift.py:24-169      MyUNet2DConditionModel.forward (up_ft tap)
+ *     diffmining/typicality/dift.py:214-232     SDFeaturizer.forward (ensemble mean)
+ * Each entry point below names the reference call it replaces.  Signatures use plain pointers and
+ * sizes only (no torch types); the Python shim in diff-mining_amd/engine.py binds them with ctypes
+ * and INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, nonzero on failure; dm_last_error() gives the message.
+ *   - *_dev pointers are device (HBM) addresses owned by the caller; `stream` is a hipStream_t
+ *     (NULL = default stream).  Calls are asynchronous on that stream.
+ *   - tensors at the boundary are NCHW like the reference; the engine is NHWC fp16 inside.
+ *   - one engine per device, not re-entrant (the reference is single-stream, compute.py:215).
+ */
+#ifndef DM_ENGINE_H
+#define DM_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dm_engine dm_engine;
+
+enum { DM_F16 = 0, DM_F32 = 1 };
+
+/* Library version / build info string (host only; usable without a GPU). */
+const char* dm_version(void);
+
+/* Host-only helpers, callable without a GPU (used by the CPU test tier).
+ * dm_scheduler_alphas_cumprod: the `scaled_linear` ᾱ table of the SDv1.5 scheduler whose
+ *   `add_noise` the reference calls at compute.py:99 / dift.py:190.  out[n] fp32.
+ * dm_timestep_sinusoid: diffusers `Timesteps(320, flip_sin_to_cos=True, shift=0)` row for
+ *   integer t (dift.py:84), out[dim] fp32 = [cos | sin]. */
+int dm_scheduler_alphas_cumprod(int num_train_timesteps, float beta_start, float beta_end, float* out);
+int dm_timestep_sinusoid(int t, int dim, float* out);
+
+/* Create an engine for the SDv1.5 U-Net architecture on HIP device `device`.
+ * Replaces: StableDiffusionPipeline.from_pretrained(...).unet (compute.py:65-73). */
+int dm_engine_create(int device, dm_engine** out);
+void dm_engine_destroy(dm_engine* e);
+const char* dm_last_error(dm_engine* e);   /* e may be NULL: last create() error */
+
+/* Hand one diffusers-named tensor (e.g. "down_blocks.0.resnets.0.conv1.weight") to the engine.
+ * `host_ptr` is host memory in the PyTorch layout ([Cout,Cin,kh,kw] / [out,in] / [C]);
+ * dtype is DM_F16 or DM_F32 (values are rounded to fp16: the reference loads the pipeline with
+ * torch_dtype=float16, compute.py:69).  Replaces: from_pretrained's state-dict load. */
+int dm_engine_load_weight(dm_engine* e, const char* name, const void* host_ptr, int dtype,
+                          const int64_t* shape, int ndim);
+
+/* Check that all 686 tensors arrived, pack them into the MFMA-friendly HBM layout, upload. */
+int dm_engine_finalize(dm_engine* e);
+
+/* Register the distinct prompt embeddings of the next calls and precompute the cross-attention
+ * K/V of all 16 transformer blocks for them (K/V depend only on the prompt, not on (t, eps)).
+ * ctx_dev: [n_prompts, 77, 768] fp16.  Replaces: the `c` argument of compute_loss
+ * (compute.py:96,100) / `encoder_hidden_states` (dift.py:191), which the reference re-projects
+ * for every sample. */
+int dm_engine_set_prompts(dm_engine* e, const void* ctx_dev, int n_prompts, void* stream);
+
+/* SD.compute_loss (compute.py:95-102), fused: noisy = add_noise(x[x_index[b]], eps[b], t[b]);
+ * eps_hat = UNet(noisy, t, prompt[slot[b]]); loss = (float(eps_hat) - float(eps))^2.
+ *   x_dev        [n_x,4,h,w] fp16 (n_x images; the reference broadcasts one x over 2B rows)
+ *   x_index_dev  [batch] int32 row of x for sample b, or NULL for identity (n_x == batch)
+ *   eps_dev      [batch,4,h,w] fp16
+ *   t_dev        [batch] int64 in [0,1000)
+ *   slot_dev     [batch] int32 prompt slot (see dm_engine_set_prompts)
+ *   loss_out_dev [batch,4,h,w] fp32 (NCHW, as F.mse_loss(reduction='none') returns)
+ */
+int dm_score(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, const void* eps_dev,
+             const int64_t* t_dev, const int32_t* slot_dev, int batch, int n_x, int h, int w,
+             void* loss_out_dev, void* stream);
+
+/* `unet(sample, t, encoder_hidden_states).sample` (compute.py:100) without the fused
+ * add_noise / loss: sample_dev [batch,4,h,w] fp16 -> out_dev [batch,4,h,w] fp16 (NCHW). */
+int dm_unet_forward(dm_engine* e, const void* sample_dev, const int64_t* t_dev, const int32_t* slot_dev,
+                    int batch, int h, int w, void* out_dev, void* stream);
+
+/* MyUNet2DConditionModel.forward(latents_noisy, t, [up_ft_index], prompt_embeds) (dift.py:24-169):
+ * early exit after up_blocks[up_ft_index]; feat_out_dev [batch, C_i, h_i, w_i] fp16 NCHW where
+ * (C_i,h_i,w_i) = dm_dift_shape().  If mean_out_dev != NULL also writes the ensemble mean over
+ * every consecutive group of `ensemble` samples (SDFeaturizer.forward, dift.py:231) as
+ * [batch/ensemble, C_i, h_i, w_i] fp32. */
+int dm_dift(dm_engine* e, const void* noisy_dev, const int64_t* t_dev, const int32_t* slot_dev,
+            int batch, int h, int w, int up_ft_index, void* feat_out_dev,
+            void* mean_out_dev, int ensemble, void* stream);
+int dm_dift_shape(int h, int w, int up_ft_index, int* c_out, int* h_out, int* w_out);
+
+/* Consumers' reductions of the loss grid (cluster.py:125-137, xray/compute.py:210-218) on device:
+ * loss_dev [n_draws, n_cond, 4, h, w] fp32 (or fp16 when loss_is_f16) ->
+ *   map_out_dev [h,w] fp32 = mean_N( mean_C(L[:,n_cond-1]) - mean_C(L[:,0]) ), and
+ *   scalar_out_dev [1] fp32 = mean over pixels of the map (T(x|c)).  Either may be NULL. */
+int dm_reduce_typicality(dm_engine* e, const void* loss_dev, int loss_is_f16, int n_draws, int n_cond,
+                         int h, int w, void* map_out_dev, void* scalar_out_dev, void* stream);
+
+/* Profiling support for bench.py: when enabled, every launch of the dominant (implicit-GEMM)
+ * kernel is bracketed by hipEvents on the launch stream.  dm_prof_read synchronises and returns
+ * the accumulated kernel milliseconds, launch count and algorithmic FLOPs since the last reset. */
+int dm_prof_enable(dm_engine* e, int on);
+int dm_prof_read(dm_engine* e, double* igemm_ms, double* igemm_flops, int64_t* igemm_launches,
+                 double* attn_ms, double* attn_flops, int64_t* attn_launches);
+
+/* Bytes of device memory currently held by the engine (weights + workspace arena). */
+int dm_engine_memory(dm_engine* e, size_t* weights_bytes, size_t* arena_bytes);
+
+/* ---- operator-level entry points ------------------------------------------------------------------
+ * The individual gfx950 kernels behind the U-Net, exposed so that every op can be parity-tested
+ * against the matching torch.nn.functional op.  All buffers are device
+ * pointers; activations are NHWC fp16; weights are in the engine's packed layout:
+ *   igemm : Y[m][co] = sum_k X~[m][k] Wp[co][k], k = (tap, cin); Wp [Cout][taps*Cin] fp16.
+ *           mode 0 dense (1x1 conv / Linear), 1 conv3x3 s1 p1, 2 conv3x3 s2 p1,
+ *           3 conv3x3 on the nearest-upsampled (OH x OW) image.  X2 = optional second source
+ *           (channel concat cat([X, X2]), as the up blocks do).  epi 1 = GEGLU on quad-interleaved rows.
+ *   attention : softmax(Q K^T * scale) V per head, head_dim D in {40, 80, 160}; strides in elements.
+ *   groupnorm : (optionally concat) GroupNorm(G) (+SiLU), fp32 statistics; gamma/beta fp32.
+ *   layernorm : per-row LayerNorm over C; gamma/beta fp32.                                        */
+int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, const void* bias, const void* temb,
+                const void* res, void* Y, int N, int H, int W, int C1, int C2, int Cout, int OH, int OW,
+                int mode, int epi, int temb_ld);
+int dm_op_attention(void* stream, const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv,
+                    int ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso, const int32_t* kv_slot,
+                    int B, int heads, int Tq, int Tk, int D, float scale);
+int dm_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, int C, int C1, int G, float eps,
+                    const float* gamma, const float* beta, int silu, void* Y);
+int dm_op_layernorm(void* stream, const void* X, int rows, int C, const float* gamma, const float* beta, float eps,
+                    void* Y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DM_ENGINE_H */

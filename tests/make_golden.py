@@ -1,0 +1,51 @@
+"""Generates the committed golden vectors under tests/golden/ from the CPU oracle.
+
+    python tests/make_golden.py
+
+Inputs come from the integer-hash generator (diff-mining_amd/synth.py), weights are NOT stored
+(regenerated deterministically, seed 0); outputs are the oracle's.  The reference itself cannot
+be imported here (diffusers/torchvision absent), so these vectors pin the
+engine to the oracle, not to diffusers — parity stays "unpinned" in that sense."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from diff_mining_amd import synth  # noqa: E402
+from oracle import unet_ref as R  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    sd = {k: torch.from_numpy(v).float() for k, v in synth.synth_state_dict(seed=0, dtype=np.float16).items()}
+    # scoring, latent 8x8, 2 draws x 2 prompts
+    x, eps, t, c = synth.synth_inputs(1, 2, 8, 8)
+    xt, et, tt, ct = (torch.from_numpy(a) for a in (x, eps, t, c))
+    nb = torch.cat([et] * 2)
+    tb = torch.cat([tt] * 2)
+    cc = torch.cat([ct[k:k + 1].expand(2, -1, -1) for k in range(2)])
+    la = R.compute_loss(sd, xt, nb, tb, cc, autocast=True).numpy()
+    l32 = R.compute_loss(sd, xt, nb, tb, cc, autocast=False).numpy()
+    np.savez_compressed(os.path.join(OUT, "score_8x8.npz"), x=x, eps=eps, t=t, c=c, loss_autocast=la, loss_fp32=l32)
+    # compute_losses grid [4,2,4,8,8] from CPU-generator draws (seed 42, t in [100,700))
+    noises, ts = R.draw_noise_and_timesteps((1, 4, 8, 8), 4, 0.1, 0.7, seed=42)
+    grid = R.compute_losses(sd, xt, ct.float(), noises, ts, B=4).numpy()
+    np.savez_compressed(os.path.join(OUT, "grid_8x8.npz"), x=x, c=c, noises=noises.numpy(), timesteps=ts.numpy(), grid=grid)
+    # DIFT tap at latent 16x16, ensemble 2, t=161 (fp32 oracle like the reference's fp32 DIFT path)
+    x16, eps16, _, c16 = synth.synth_inputs(1, 2, 16, 16)
+    noisy = R.add_noise(torch.from_numpy(x16).float().expand(2, -1, -1, -1), torch.from_numpy(eps16).float(),
+                        torch.tensor(161)).half()
+    ft, _ = R.dift_features(sd, noisy.float(), 161, torch.from_numpy(c16[:1]).float().expand(2, -1, -1), 1)
+    np.savez_compressed(os.path.join(OUT, "dift_16x16.npz"), noisy=noisy.numpy(), t=np.int64(161), prompt=c16[:1],
+                        feat_fp32=ft.half().numpy())
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

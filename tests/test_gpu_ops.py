@@ -1,0 +1,189 @@
+"""Per-op parity: every hand-written gfx950 kernel vs the matching torch.nn.functional op evaluated
+in fp32 on the CPU from the same fp16 inputs.  Runs on the GPU box only.
+
+Tolerances: kernels accumulate in fp32 and round the output once to fp16, so the bound is fp16
+output rounding: rel-L2 <= 2e-3 and max|err| <= 2e-3 * max|ref| (fp16 eps = 9.8e-4)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from tests import gpu_util as U  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+
+
+@pytest.mark.parametrize("M,K,Cout", [(300, 320, 320), (384, 768, 640), (20, 1280, 1280), (1000, 64, 160)])
+def test_igemm_dense_bias_residual(M, K, Cout):
+    x = U.f16_randn(1, 1, M, K, seed=1)
+    w = U.f16_randn(Cout, K, seed=2, scale=K ** -0.5)
+    b = U.f16_randn(Cout, seed=3, scale=0.1)
+    r = U.f16_randn(1, 1, M, Cout, seed=4)
+    ref = F.linear(x.float().view(M, K), w.float(), b.float())
+    d = U.dev()
+    y = U.op_igemm(x.to(d), w.to(d), b.to(d))
+    U.assert_close_fp16(y.view(M, Cout), ref, "dense+bias")
+    y = U.op_igemm(x.to(d), w.to(d), b.to(d), res=r.to(d))
+    ref2 = (ref.half().float() + r.float().view(M, Cout))
+    U.assert_close_fp16(y.view(M, Cout), ref2, "dense+bias+res")
+    y = U.op_igemm(x.to(d), w.to(d))
+    U.assert_close_fp16(y.view(M, Cout), F.linear(x.float().view(M, K), w.float()), "dense no bias")
+
+
+def test_igemm_identity_asymmetric():
+    """A = I check with an asymmetric operand: catches row/col swaps in the MFMA C layout."""
+    K = Cout = 320
+    w = torch.eye(K).half()
+    x = (torch.arange(256 * K).view(1, 1, 256, K) % 97).half() / 16
+    d = U.dev()
+    y = U.op_igemm(x.to(d), w.to(d))
+    assert torch.equal(y.cpu().view(256, K), x.view(256, K))
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 9, 7, 64, 160), (1, 16, 16, 320, 320), (3, 8, 8, 128, 640)])
+def test_igemm_conv3x3(N, H, W, Cin, Cout):
+    x = U.f16_randn(N, Cin, H, W, seed=5)
+    w = U.f16_randn(Cout, Cin, 3, 3, seed=6, scale=(9 * Cin) ** -0.5)
+    b = U.f16_randn(Cout, seed=7, scale=0.1)
+    temb = U.f16_randn(N, Cout + 160, seed=8)
+    res = U.f16_randn(N, Cout, H, W, seed=9)
+    d = U.dev()
+    xg, wg, bg = U.to_nhwc(x).to(d), U.pack_conv3(w).to(d), b.to(d)
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+    y = U.op_igemm(xg, wg, bg, mode=1)
+    U.assert_close_fp16(U.to_nchw(y), ref, "conv3x3")
+    # + time-embedding channel add (fp16 add after the fp16 conv output) on a strided table
+    tg = temb.to(d)
+    y = U.op_igemm(xg, wg, bg, temb=tg[:, 160:], mode=1)   # non-contiguous view: ld = Cout+160
+    ref_t = ref.half().float() + temb[:, 160:].float()[:, :, None, None]
+    U.assert_close_fp16(U.to_nchw(y), ref_t, "conv3x3+temb")
+    y = U.op_igemm(xg, wg, bg, res=U.to_nhwc(res).to(d), mode=1)
+    U.assert_close_fp16(U.to_nchw(y), ref.half().float() + res.float(), "conv3x3+res")
+    # stride 2, pad 1
+    ref_s2 = F.conv2d(x.float(), w.float(), b.float(), stride=2, padding=1)
+    y = U.op_igemm(xg, wg, bg, mode=2, OH=ref_s2.shape[2], OW=ref_s2.shape[3])
+    U.assert_close_fp16(U.to_nchw(y), ref_s2, "conv3x3 s2")
+    # nearest 2x upsample + conv
+    up = F.interpolate(x.float(), scale_factor=2.0, mode="nearest")
+    ref_up = F.conv2d(up, w.float(), b.float(), padding=1)
+    y = U.op_igemm(xg, wg, bg, mode=3, OH=2 * H, OW=2 * W)
+    U.assert_close_fp16(U.to_nchw(y), ref_up, "upsample2x+conv3x3")
+    # forced output size (odd latent sizes: dift.py:146-147 `upsample_size`)
+    oh, ow = 2 * H - 1, 2 * W - 1
+    up = F.interpolate(x.float(), size=(oh, ow), mode="nearest")
+    ref_up = F.conv2d(up, w.float(), b.float(), padding=1)
+    y = U.op_igemm(xg, wg, bg, mode=3, OH=oh, OW=ow)
+    U.assert_close_fp16(U.to_nchw(y), ref_up, "upsample(size)+conv3x3")
+
+
+def test_igemm_concat_sources():
+    N, H, W, C1, C2, Cout = 2, 8, 8, 128, 64, 320
+    x1, x2 = U.f16_randn(N, C1, H, W, seed=10), U.f16_randn(N, C2, H, W, seed=11)
+    w = U.f16_randn(Cout, C1 + C2, 3, 3, seed=12, scale=(9 * (C1 + C2)) ** -0.5)
+    w1 = U.f16_randn(Cout, C1 + C2, seed=13, scale=(C1 + C2) ** -0.5)
+    d = U.dev()
+    cat = torch.cat([x1, x2], 1).float()
+    y = U.op_igemm(U.to_nhwc(x1).to(d), U.pack_conv3(w).to(d), X2=U.to_nhwc(x2).to(d), mode=1)
+    U.assert_close_fp16(U.to_nchw(y), F.conv2d(cat, w.float(), padding=1), "concat conv3x3")
+    y = U.op_igemm(U.to_nhwc(x1).to(d), w1.to(d), X2=U.to_nhwc(x2).to(d), mode=0)
+    U.assert_close_fp16(U.to_nchw(y), F.conv2d(cat, w1.float()[:, :, None, None]), "concat 1x1")
+
+
+def test_igemm_geglu():
+    M, Cc = 200, 320
+    x = U.f16_randn(1, 1, M, Cc, seed=14)
+    w = U.f16_randn(8 * Cc, Cc, seed=15, scale=Cc ** -0.5)
+    b = U.f16_randn(8 * Cc, seed=16, scale=0.1)
+    proj = F.linear(x.float().view(M, Cc), w.float(), b.float()).half().float()
+    a, g = proj.chunk(2, dim=-1)
+    ref = a * F.gelu(g).half().float()
+    wp, bp = U.pack_geglu(w, b)
+    d = U.dev()
+    y = U.op_igemm(x.to(d), wp.to(d), bp.to(d), epi=1)
+    assert y.shape[-1] == 4 * Cc
+    U.assert_close_fp16(y.view(M, 4 * Cc), ref, "geglu", rel=3e-3, abs_frac=3e-3)
+
+
+@pytest.mark.parametrize("D,Tq,Tk", [(40, 256, 256), (40, 200, 200), (80, 336, 336), (160, 64, 64), (40, 4096, 4096)])
+def test_attention_self(D, Tq, Tk):
+    heads, B = 8, 2
+    Cc = heads * D
+    qkv = U.f16_randn(B, Tq, 3 * Cc, seed=17)
+    q, k, v = qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:]
+
+    def split(t):
+        return t.float().view(B, -1, heads, D).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(split(q), split(k), split(v)).transpose(1, 2).reshape(B, Tq, Cc)
+    g = qkv.to(U.dev())
+    o = U.op_attention(g[..., :Cc], g[..., Cc:2 * Cc], g[..., 2 * Cc:], heads)   # strided views of fused QKV
+    U.assert_close_fp16(o, ref, f"self-attn D={D} T={Tq}", rel=3e-3, abs_frac=4e-3)
+
+
+@pytest.mark.parametrize("D", [40, 80, 160])
+def test_attention_cross_with_prompt_slots(D):
+    heads, B, Tq, Tk, P = 8, 5, 150, 77, 3
+    Cc = heads * D
+    q = U.f16_randn(B, Tq, Cc, seed=18)
+    kv = U.f16_randn(P, Tk, 2 * Cc, seed=19)
+    slots = torch.tensor([2, 0, 1, 1, 2], dtype=torch.int32)
+    k, v = kv[..., :Cc][slots.long()], kv[..., Cc:][slots.long()]
+
+    def split(t, T):
+        return t.float().view(B, T, heads, D).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(split(q, Tq), split(k, Tk), split(v, Tk)).transpose(1, 2).reshape(B, Tq, Cc)
+    d = U.dev()
+    kvg = kv.to(d)
+    o = U.op_attention(q.to(d), kvg[..., :Cc], kvg[..., Cc:], heads, slots=slots.to(d))
+    U.assert_close_fp16(o, ref, f"cross-attn D={D}", rel=3e-3, abs_frac=4e-3)
+
+
+def test_attention_large_logits_online_softmax():
+    """Force the running-max rescale path: one key per row dominates at a late tile."""
+    heads, B, T, D = 8, 1, 320, 40
+    Cc = heads * D
+    q = U.f16_randn(B, T, Cc, seed=20)
+    k = U.f16_randn(B, T, Cc, seed=21)
+    v = U.f16_randn(B, T, Cc, seed=22)
+    k[:, 300] = q[:, 5] * 4.0          # spikes q.k at key 300 (tile 4) for query 5 and correlated rows
+
+    def split(t):
+        return t.float().view(B, T, heads, D).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(split(q), split(k), split(v)).transpose(1, 2).reshape(B, T, Cc)
+    d = U.dev()
+    o = U.op_attention(q.to(d), k.to(d), v.to(d), heads)
+    U.assert_close_fp16(o, ref, "attn spike", rel=3e-3, abs_frac=4e-3)
+
+
+@pytest.mark.parametrize("C1,C2,silu,eps", [(320, 0, True, 1e-5), (640, 0, False, 1e-6), (1280, 640, True, 1e-5),
+                                            (640, 320, True, 1e-5), (1280, 1280, True, 1e-5)])
+def test_groupnorm(C1, C2, silu, eps):
+    N, H, W = 3, 9, 7
+    x1 = U.f16_randn(N, C1, H, W, seed=23) * 2 + 0.5
+    x2 = (U.f16_randn(N, C2, H, W, seed=24) * 0.5 - 1.0) if C2 else None
+    Ct = C1 + C2
+    g = torch.randn(Ct, generator=torch.Generator().manual_seed(25)) * 0.1 + 1
+    b = torch.randn(Ct, generator=torch.Generator().manual_seed(26)) * 0.1
+    cat = torch.cat([x1, x2], 1).float() if C2 else x1.float()
+    ref = F.group_norm(cat, 32, g, b, eps)
+    if silu:
+        ref = F.silu(ref)
+    d = U.dev()
+    y = U.op_groupnorm(U.to_nhwc(x1).to(d), g.to(d), b.to(d), 32, eps, silu,
+                       X2=U.to_nhwc(x2).to(d) if C2 else None)
+    U.assert_close_fp16(U.to_nchw(y), ref, f"groupnorm C={Ct}")
+
+
+@pytest.mark.parametrize("Cc", [320, 640, 1280])
+def test_layernorm(Cc):
+    rows = 777
+    x = U.f16_randn(rows, Cc, seed=27) * 3 + 1
+    g = torch.randn(Cc, generator=torch.Generator().manual_seed(28)) * 0.1 + 1
+    b = torch.randn(Cc, generator=torch.Generator().manual_seed(29)) * 0.1
+    ref = F.layer_norm(x.float(), (Cc,), g, b, 1e-5)
+    d = U.dev()
+    y = U.op_layernorm(x.to(d), g.to(d), b.to(d))
+    U.assert_close_fp16(y, ref, f"layernorm C={Cc}")
