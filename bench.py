@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""bench.py — typicality-scored images/sec/node (BASELINE.json metric) on N MI355X of one node.
+
+One "step" = one pass of the hot path over one batch of synthetic input PER GPU:
+    8 images of 512x512 (latent 4x64x64), each scored with 10 (t, eps) draws x 2 prompts
+    = 160 SDv1.5 U-Net forwards of the fused add_noise -> U-Net -> eps-MSE path (dm_score), then the
+    on-device typicality reduction (dm_reduce_typicality) per image; N > 1: plus ONE all-gather of
+    the per-image T(x|c) scalars (RCCL over xGMI).  This is BASELINE.json configs[1] (and [2] for N>1).
+Inputs (latents, draws, prompt embeddings) and the synthetic fp16 weights are resident in HBM
+before the timed region.  Weak scaling: every rank scores its own 8 images.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     — dominant kernel = the implicit-GEMM MFMA kernel (igemm.hip, 85% of the FLOPs):
+                 achieved = its algorithmic FLOPs / its summed launch time, measured with HIP events
+                 on the launch stream over the timed steps (dm_prof_*); peak = 2.5 PFLOP/s dense fp16.
+  cpu_baseline — the oracle (fp32 PyTorch-CPU restatement; kind "port") timed on this host's cores on
+                 a bounded sample (2 U-Net forwards @64x64 = 1/10 of one image's work).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FLOP_PER_FORWARD_64 = 803.27e9          # SURVEY.md §8d (2 FLOP/MAC, attention included)
+N_IMG, N_DRAWS, N_COND, LAT = 8, 10, 2, 64
+PEAK_TFLOPS = 2500.0                    # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--images", type=int, default=N_IMG)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = torch.device("cuda", local_rank)
+
+    from diff_mining_amd import synth
+    from diff_mining_amd.engine import UNetEngine
+    from diff_mining_amd.typicality import gather_scores
+
+    sd = synth.synth_state_dict(seed=0, dtype=np.float16)
+    eng = UNetEngine(local_rank)
+    eng.load_state_dict(sd)
+
+    n_img = args.images
+    x, eps, t, c = synth.synth_inputs(n_img * world, N_DRAWS, LAT, LAT)
+    x = torch.from_numpy(x)[rank * n_img:(rank + 1) * n_img].to(dev)          # this rank's images
+    eps = torch.from_numpy(eps).to(dev)
+    t = torch.from_numpy(t).to(dev)
+    c = torch.from_numpy(c).to(dev)
+    eng.set_prompts(c)
+    # sample order per image: cond-major tiling of compute.py:150-152 (row k*N+i = draw i, cond k)
+    per_img = N_DRAWS * N_COND
+    eps_b = eps.repeat(N_COND, 1, 1, 1).repeat(n_img, 1, 1, 1).contiguous()     # same draws for every image
+    t_b = t.repeat(N_COND).repeat(n_img).contiguous()
+    slots = torch.arange(N_COND, dtype=torch.int32, device=dev).repeat_interleave(N_DRAWS).repeat(n_img).contiguous()
+    x_index = torch.arange(n_img, dtype=torch.int32, device=dev).repeat_interleave(per_img).contiguous()
+    scores = torch.empty(n_img, dtype=torch.float32, device=dev)
+
+    def step():
+        loss = eng.score(x, eps_b, t_b, slots, x_index=x_index)              # [n_img*20,4,64,64] fp32
+        grid = loss.view(n_img, N_COND, N_DRAWS, 4, LAT, LAT)
+        for i in range(n_img):
+            g = grid[i].transpose(0, 1).contiguous()                          # [N,2,4,h,w]
+            scores[i] = eng.reduce_typicality(g)[1][0]
+        return gather_scores(scores, n_img * world, rank, world)
+
+    for _ in range(args.warmup):
+        step()
+    eng.prof_enable(True)
+    eng.prof_read()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        all_scores = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = eng.prof_read()
+    eng.prof_enable(False)
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = tt.item()
+
+    if rank == 0:
+        total_images = n_img * world * args.steps
+        value = total_images / dt
+        ig_tf = prof["igemm_flops"] / (prof["igemm_ms"] * 1e-3) / 1e12 if prof["igemm_ms"] > 0 else 0.0
+        at_tf = prof["attn_flops"] / (prof["attn_ms"] * 1e-3) / 1e12 if prof["attn_ms"] > 0 else 0.0
+        out = {
+            "metric": "typicality-scored images/sec/node (512px, 10 t×2 prompts)",
+            "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "configs[1]: SDv1.5 U-Net fp16, 512x512 (latent 64x64), 10 t-samples x 2 prompts, "
+                                   f"batch {n_img} images/GPU = {n_img * per_img} U-Net forwards/step/GPU, synthetic weights",
+                       "images_per_gpu_per_step": n_img, "unet_forwards_per_image": per_img,
+                       "parallelism": f"image-sharded x{world}, one all-gather of T(x|c)"},
+            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv3x3/1x1/linear)",
+                         "achieved": round(ig_tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ig_tf / PEAK_TFLOPS, 4), "traffic": None,
+                         "launches": prof["igemm_launches"], "kernel_ms_total": round(prof["igemm_ms"], 3),
+                         "whole_path_tflops": round(value / world * per_img * FLOP_PER_FORWARD_64 / 1e12, 2),
+                         "whole_path_frac": round(value / world * per_img * FLOP_PER_FORWARD_64 / 1e12 / PEAK_TFLOPS, 4),
+                         "attention_tflops": round(at_tf, 2), "attention_ms_total": round(prof["attn_ms"], 3)},
+            "scores_checksum": float(all_scores.double().sum().item()),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sd)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sd):
+    """Oracle (fp32 PyTorch CPU) on a bounded sample: 1 draw x 2 prompts of one 64x64 latent."""
+    from diff_mining_amd import synth
+    from oracle import unet_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sdt = {k: torch.from_numpy(v).float() for k, v in sd.items()}
+    x, eps, t, c = (torch.from_numpy(a) for a in synth.synth_inputs(1, 1, LAT, LAT))
+    nb, tb = torch.cat([eps] * 2), torch.cat([t] * 2)
+    cc = torch.cat([c[0:1], c[1:2]]).float()
+    with torch.no_grad():
+        R.compute_loss(sdt, x[:, :, :16, :16], nb[:, :, :16, :16], tb, cc, autocast=False)     # warm-up (small)
+        t0 = time.perf_counter()
+        R.compute_loss(sdt, x, nb, tb, cc, autocast=False)
+        dt = time.perf_counter() - t0
+    forwards = 2
+    return {"value": round(forwards / (N_DRAWS * N_COND) / dt, 6), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{forwards} U-Net forwards @64x64 (1/10 of one image) in {dt:.1f}s, fp32 oracle, torch threads={cores}",
+            "gflops": round(forwards * FLOP_PER_FORWARD_64 / dt / 1e9, 1)}
+
+
+if __name__ == "__main__":
+    main()
