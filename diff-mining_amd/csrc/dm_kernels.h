@@ -41,12 +41,12 @@ struct AttnParams {
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 
 // ---- K6: GroupNorm statistics + apply(+SiLU); K7: LayerNorm ----------------------------------
-// x = concat(X[...,C1], X2[...,C-C1]) NHWC; stats [N][G][2] = (mean, rstd) fp32
+// x = concat(X[...,C1], X2[...,C-C1]) NHWC; ab [N][C][2] = per-sample per-channel affine (a, b): y = x*a + b
 hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, float eps,
-                           double* partial /* [N][chunks][G][2] */, float* stats, hipStream_t s);
+                           const float* gamma, const float* beta,
+                           double* partial /* [N][chunks][G][2] */, float* ab /* [N][C][2] */, hipStream_t s);
 int gn_stats_chunks(int HW);
-hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G,
-                           const float* stats, const float* gamma, const float* beta, int silu,
+hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, int C1, const float* ab, int silu,
                            f16* Y, hipStream_t s);
 hipError_t launch_layernorm(const f16* X, int rows, int C, const float* gamma, const float* beta,
                             float eps, f16* Y, hipStream_t s);
@@ -55,12 +55,12 @@ hipError_t launch_layernorm(const f16* X, int rows, int C, const float* gamma, c
 // temb0[b][320] = fp16(sinusoid table[t[b]])
 hipError_t launch_time_gather(const f16* table, const int64_t* t, int B, int dim, f16* out, hipStream_t s);
 hipError_t launch_silu(const f16* in, f16* out, long long n, hipStream_t s);
-// add_noise (fp16 arithmetic, table cast to fp16 first) fused with conv_in 3x3 (4 -> C0), NHWC out.
-// if acp16 == nullptr the sample is used as is (plain U-Net forward / DIFT).
-hipError_t launch_conv_in(const f16* x, const int32_t* x_index, const f16* eps, const int64_t* t,
-                          const f16* sqrt_acp16, const f16* sqrt_1macp16,
-                          const f16* w /* [C0][36] k=(c,ky,kx) */, const f16* bias,
-                          int B, int H, int W, int C0, f16* Y, hipStream_t s);
+// add_noise (fp16 arithmetic, table cast to fp16 first) fused with the im2col of conv_in (3x3, 4 ch):
+// out [B*H*W][64] fp16, k = c*9 + ky*3 + kx for k < 36, zero after; conv_in itself is then one igemm.
+// if sqrt_acp16 == nullptr the sample is used as is (plain U-Net forward / DIFT).
+hipError_t launch_im2col_in(const f16* x, const int32_t* x_index, const f16* eps, const int64_t* t,
+                            const f16* sqrt_acp16, const f16* sqrt_1macp16, int B, int H, int W, f16* out,
+                            hipStream_t s);
 // conv_out 3x3 (C0 -> 4) on the normalised activations, fused eps-MSE (wavefront shuffle reduce).
 // loss [B,4,H,W] fp32 = (float(fp16(conv)) - float(eps))^2 ; if eps == nullptr writes pred fp16 NCHW.
 hipError_t launch_conv_out(const f16* Xn /* NHWC [B,H,W,C0] */, const f16* w /* [4][9*C0] k=(tap,c) */,

@@ -419,12 +419,11 @@ struct Fwd {
         const int chunks = gn_stats_chunks(HW);
         size_t poff, soff; void *pp, *sp;
         DM_TRY(alloc_raw((size_t)x.N * chunks * GROUPS * 2 * sizeof(double), &poff, &pp));
-        DM_TRY(alloc_raw((size_t)x.N * GROUPS * 2 * sizeof(float), &soff, &sp));
+        DM_TRY(alloc_raw((size_t)x.N * C * 2 * sizeof(float), &soff, &sp));
         DM_TRY(alloc(y, x.N, x.H, x.W, C));
         if (!dry) {
-            DM_HIP(e, launch_gn_stats(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, GROUPS, eps, (double*)pp, (float*)sp, s));
-            DM_HIP(e, launch_gn_apply(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, GROUPS, (const float*)sp, nw.g, nw.b,
-                                      silu ? 1 : 0, y->p, s));
+            DM_HIP(e, launch_gn_stats(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, GROUPS, eps, nw.g, nw.b, (double*)pp, (float*)sp, s));
+            DM_HIP(e, launch_gn_apply(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, (const float*)sp, silu ? 1 : 0, y->p, s));
         }
         free_raw(poff); free_raw(soff);
         return 0;
@@ -536,9 +535,14 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
 
     // ---- conv_in (+ fused add_noise) ------------------------------------------------------------
     Tensor h;
-    DM_TRY(F.alloc(&h, B, A.H, A.W, BOC[0]));
-    if (!dry) DM_HIP(e, launch_conv_in(A.x, A.x_index, A.eps, A.t, A.add_noise ? e->sa_tab : nullptr,
-                                       A.add_noise ? e->sb_tab : nullptr, e->conv_in.w, e->conv_in.b, B, A.H, A.W, BOC[0], h.p, s));
+    {
+        Tensor col;
+        DM_TRY(F.alloc(&col, B, A.H, A.W, 64));
+        if (!dry) DM_HIP(e, launch_im2col_in(A.x, A.x_index, A.eps, A.t, A.add_noise ? e->sa_tab : nullptr,
+                                             A.add_noise ? e->sb_tab : nullptr, B, A.H, A.W, col.p, s));
+        DM_TRY(F.dense(e->conv_in, col, nullptr, nullptr, EPI_PLAIN, &h));
+        F.free(col);
+    }
     std::vector<Tensor> skips;
     skips.push_back(h);
     // ---- down -----------------------------------------------------------------------------------
@@ -719,12 +723,15 @@ int dm_engine_finalize(dm_engine* e) {
     Packer P{e, {}};
     std::vector<f16> tw, tb;
     e->n_tf = 0; e->tfs.clear();
-    // conv_in: keep PyTorch order [C0][c*9 + ky*3 + kx]
+    // conv_in as a dense GEMM over the im2col rows: [C0][64], k = c*9 + ky*3 + kx (PyTorch order), zero padded
     {
         HostTensor* w = P.get("conv_in.weight", {BOC[0], 4, 3, 3});
         if (!w) return 1;
-        e->conv_in.w = as_ptr(P.put(w->data.data(), w->data.size() * 2));
-        e->conv_in.cin = 4; e->conv_in.cout = BOC[0]; e->conv_in.k = 3;
+        std::vector<f16> pk((size_t)BOC[0] * 64, (f16)0.f);
+        for (int co = 0; co < BOC[0]; ++co)
+            for (int k = 0; k < 36; ++k) pk[(size_t)co * 64 + k] = w->data[(size_t)co * 36 + k];
+        e->conv_in.w = as_ptr(P.put(pk.data(), pk.size() * 2));
+        e->conv_in.cin = 64; e->conv_in.cout = BOC[0]; e->conv_in.k = 1;
         DM_TRY(pack_bias(P, "conv_in", BOC[0], &e->conv_in.b));
     }
     DM_TRY(pack_dense(P, "time_embedding.linear_1", TEMB, BOC[0], false, true, &e->time1));
@@ -1011,14 +1018,14 @@ int dm_op_attention(void* stream, const void* Q, const void* K, const void* V, v
 int dm_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, int C, int C1, int G, float eps,
                     const float* gamma, const float* beta, int silu, void* Y) {
     hipStream_t s = (hipStream_t)stream;
-    double* partial = nullptr; float* stats = nullptr;
+    double* partial = nullptr; float* ab = nullptr;
     const int chunks = gn_stats_chunks(HW);
     if (hipMalloc((void**)&partial, (size_t)N * chunks * G * 2 * sizeof(double)) != hipSuccess) return 1;
-    if (hipMalloc((void**)&stats, (size_t)N * G * 2 * sizeof(float)) != hipSuccess) { (void)hipFree(partial); return 1; }
-    hipError_t r = launch_gn_stats((const f16*)X, (const f16*)X2, N, HW, C, C1, G, eps, partial, stats, s);
-    if (r == hipSuccess) r = launch_gn_apply((const f16*)X, (const f16*)X2, N, HW, C, C1, G, stats, gamma, beta, silu, (f16*)Y, s);
+    if (hipMalloc((void**)&ab, (size_t)N * C * 2 * sizeof(float)) != hipSuccess) { (void)hipFree(partial); return 1; }
+    hipError_t r = launch_gn_stats((const f16*)X, (const f16*)X2, N, HW, C, C1, G, eps, gamma, beta, partial, ab, s);
+    if (r == hipSuccess) r = launch_gn_apply((const f16*)X, (const f16*)X2, N, HW, C, C1, ab, silu, (f16*)Y, s);
     (void)hipStreamSynchronize(s);
-    (void)hipFree(partial); (void)hipFree(stats);
+    (void)hipFree(partial); (void)hipFree(ab);
     return r == hipSuccess ? 0 : 1;
 }
 

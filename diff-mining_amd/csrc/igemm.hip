@@ -15,6 +15,7 @@
 // ds_read_b128), double buffered, one barrier per k step; the next tile's global loads are issued
 // before the MFMA block and written to LDS after it.
 #include "dm_kernels.h"
+#include <cstdlib>
 
 namespace dm {
 
@@ -35,6 +36,50 @@ constexpr int NTHREADS = 256;
 
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+
+template <int EPI>
+__device__ __forceinline__ void epilogue(const IGemmParams& p, floatx4 (&acc)[5][4], int p0, int c0out, int wc,
+                                         int wp, int l15, int lg, int OHW) {
+    // ---- epilogue: D[row = channel (lg*4 + r)][col = pixel l15] --------------------------------
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = p0 + wp * 64 + 16 * j + l15;
+        if (m >= p.M) continue;
+        const int n = (p.temb != nullptr) ? (m / OHW) : 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int c = c0out + wc * 80 + 16 * i + 4 * lg;
+            float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+            if (p.bias) {
+                const half4 bv = *reinterpret_cast<const half4*>(p.bias + c);
+                v0 += (float)bv[0]; v1 += (float)bv[1]; v2 += (float)bv[2]; v3 += (float)bv[3];
+            }
+            if (EPI == EPI_GEGLU) {
+                // packed rows: [h0, h1, g0, g1]; out = fp16(h * fp16(gelu(g))) as fp16 autocast does
+                const f16 h0 = (f16)v0, h1 = (f16)v1, g0 = (f16)v2, g1 = (f16)v3;
+                const f16 q0 = (f16)gelu_erf((float)g0), q1 = (f16)gelu_erf((float)g1);
+                const f16 o0 = (f16)((float)h0 * (float)q0), o1 = (f16)((float)h1 * (float)q1);
+                const int oc = (c >> 4) * 8 + 2 * lg;
+                typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<half2_*>(p.Y + (size_t)m * p.ldy + oc) = half2_{o0, o1};
+            } else {
+                half4 o = half4{(f16)v0, (f16)v1, (f16)v2, (f16)v3};
+                if (p.temb) {
+                    const half4 tv = *reinterpret_cast<const half4*>(p.temb + (size_t)n * p.temb_ld + c);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (f16)((float)o[r] + (float)tv[r]);
+                }
+                if (p.res) {
+                    const half4 rv = *reinterpret_cast<const half4*>(p.res + (size_t)m * p.ldres + c);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (f16)((float)o[r] + (float)rv[r]);
+                }
+                *reinterpret_cast<half4*>(p.Y + (size_t)m * p.ldy + c) = o;
+            }
+        }
+    }
 }
 
 template <int EPI>
@@ -200,50 +245,213 @@ void igemm_kernel(IGemmParams p) {
     }
     compute((nk - 1) & 1);
 
-    // ---- epilogue: D[row = channel (lg*4 + r)][col = pixel l15] --------------------------------
+    epilogue<EPI>(p, acc, p0, c0out, wc, wp, l15, lg, OHW);
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// glds variant: operand tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging,
+// no ds_write).  The LDS image is lane-linear per wave instruction (8 rows x 128 B), so the XOR
+// swizzle is applied on the per-lane SOURCE address (chunk ^= row&7) and again on the ds_read.
+// Zero padding of the 3x3 halo = lanes pointed at a 128-byte zero page.
+// Block tile = (64*WP pixels) x (80*WC channels); each wave still owns 64 px x 80 ch.
+// ---------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int WP, int WC, int EPI>
+__global__ __launch_bounds__(64 * WP * WC, (WP * WC) / 4 * 2 >= 2 ? 2 : 2)
+void igemm_glds_kernel(IGemmParams p) {
+    constexpr int NW = WP * WC;
+    constexpr int TP = 64 * WP, TC = 80 * WC;
+    constexpr int WBYTES = TC * 128, XBYTES = TP * 128, STAGE = WBYTES + XBYTES;
+    constexpr int WG = TC / 8, XG = TP / 8;                 // 8-row groups (one glds instruction each)
+    constexpr int WI = (WG + NW - 1) / NW, XI = (XG + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wid % WC;
+    const int wp = wid / WC;
+
+    const int tiles_c = p.Cout / TC;
+    const int nblk = gridDim.x;
+    int v;
+    {
+        const int b = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = b & 7, loc = b >> 3;
+        v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int pt = v / tiles_c;
+    const int ct = v - pt * tiles_c;
+    const int p0 = pt * TP;
+    const int c0out = ct * TC;
+
+    const int C1 = p.C1;
+    const int C2 = p.Cin - C1;
+    const int ntaps = (p.mode == IG_DENSE) ? 1 : 9;
+    const int cpt = p.Cin / BK;
+    const int nk = ntaps * cpt;
+    const int Ktot = ntaps * p.Cin;
+    const int OHW = p.OH * p.OW;
+
+    const int lrow = lane >> 3;                              // row within the 8-row group
+    const int lchunk = ((lane & 7) ^ lrow) * 8;              // swizzled source chunk (elements)
+
+    // weight rows of this lane (group g = wid + k*NW)
+    const f16* wsrc[WI];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = p0 + wp * 64 + 16 * j + l15;
-        if (m >= p.M) continue;
-        const int n = (p.temb != nullptr) ? (m / OHW) : 0;
+    for (int k = 0; k < WI; ++k) {
+        const int g = wid + k * NW;
+        wsrc[k] = p.Wp + (size_t)(c0out + (g < WG ? g : 0) * 8 + lrow) * Ktot + lchunk;
+    }
+    // pixel rows of this lane
+    int xn[XI], xoh[XI], xow[XI];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int c = c0out + wc * 80 + 16 * i + 4 * lg;
-            float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-            if (p.bias) {
-                const half4 bv = *reinterpret_cast<const half4*>(p.bias + c);
-                v0 += (float)bv[0]; v1 += (float)bv[1]; v2 += (float)bv[2]; v3 += (float)bv[3];
+    for (int k = 0; k < XI; ++k) {
+        const int g = wid + k * NW;
+        const int m = p0 + g * 8 + lrow;
+        if (g < XG && m < p.M) {
+            const int n = m / OHW;
+            const int rem = m - n * OHW;
+            const int oh = rem / p.OW;
+            xn[k] = n; xoh[k] = oh; xow[k] = rem - oh * p.OW;
+        } else { xn[k] = -1; xoh[k] = 0; xow[k] = 0; }
+    }
+    const float sh = (float)p.H / (float)p.OH;
+    const float sw = (float)p.W / (float)p.OW;
+    long long xpix[XI];
+    auto set_tap = [&](int tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+        for (int k = 0; k < XI; ++k) {
+            long long off = -1;
+            if (xn[k] >= 0) {
+                if (p.mode == IG_DENSE) {
+                    off = (long long)(p0 + (wid + k * NW) * 8 + lrow);
+                } else if (p.mode == IG_CONV3 || p.mode == IG_CONV3_S2) {
+                    const int st = (p.mode == IG_CONV3_S2) ? 2 : 1;
+                    const int ih = xoh[k] * st + dy - 1, iw = xow[k] * st + dx - 1;
+                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) off = ((long long)xn[k] * p.H + ih) * p.W + iw;
+                } else {
+                    const int uh = xoh[k] + dy - 1, uw = xow[k] + dx - 1;
+                    if (uh >= 0 && uh < p.OH && uw >= 0 && uw < p.OW) {
+                        int ih = (int)floorf((float)uh * sh); ih = ih < p.H - 1 ? ih : p.H - 1;
+                        int iw = (int)floorf((float)uw * sw); iw = iw < p.W - 1 ? iw : p.W - 1;
+                        off = ((long long)xn[k] * p.H + ih) * p.W + iw;
+                    }
+                }
             }
-            if (EPI == EPI_GEGLU) {
-                // packed rows: [h0, h1, g0, g1]; out = fp16(h * fp16(gelu(g))) as fp16 autocast does
-                const f16 h0 = (f16)v0, h1 = (f16)v1, g0 = (f16)v2, g1 = (f16)v3;
-                const f16 q0 = (f16)gelu_erf((float)g0), q1 = (f16)gelu_erf((float)g1);
-                const f16 o0 = (f16)((float)h0 * (float)q0), o1 = (f16)((float)h1 * (float)q1);
-                const int oc = (c >> 4) * 8 + 2 * lg;
-                typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
-                *reinterpret_cast<half2_*>(p.Y + (size_t)m * p.ldy + oc) = half2_{o0, o1};
-            } else {
-                half4 o = half4{(f16)v0, (f16)v1, (f16)v2, (f16)v3};
-                if (p.temb) {
-                    const half4 tv = *reinterpret_cast<const half4*>(p.temb + (size_t)n * p.temb_ld + c);
+            xpix[k] = off;
+        }
+    };
+
+    const f16* zero = reinterpret_cast<const f16*>(g_zero_page) + lchunk;
+    int ld_tap = 0, ld_cc = 0;
+    auto issue = [&](int buf) {
+        if (ld_cc == 0) set_tap(ld_tap);
+        const int c0 = ld_cc * BK;
+        const f16* src; int cs, cb;
+        if (c0 < C1) { src = p.X; cs = C1; cb = c0; } else { src = p.X2; cs = C2; cb = c0 - C1; }
+        char* wt = smem + buf * STAGE;
+        char* xt = wt + WBYTES;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (f16)((float)o[r] + (float)tv[r]);
-                }
-                if (p.res) {
-                    const half4 rv = *reinterpret_cast<const half4*>(p.res + (size_t)m * p.ldres + c);
+        for (int k = 0; k < WI; ++k) {
+            const int g = wid + k * NW;
+            if (g < WG) {
+                __builtin_amdgcn_global_load_lds((gptr_t)wsrc[k], (lptr_t)(wt + g * 1024), 16, 0, 0);
+            }
+            wsrc[k] += BK;
+        }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (f16)((float)o[r] + (float)rv[r]);
-                }
-                *reinterpret_cast<half4*>(p.Y + (size_t)m * p.ldy + c) = o;
+        for (int k = 0; k < XI; ++k) {
+            const int g = wid + k * NW;
+            if (g < XG) {
+                const f16* a = (xpix[k] >= 0) ? (src + xpix[k] * cs + cb + lchunk) : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(xt + g * 1024), 16, 0, 0);
             }
         }
+        if (++ld_cc == cpt) { ld_cc = 0; ++ld_tap; }
+    };
+
+    floatx4 acc[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+    const int a_row_off = (wc * 80 + l15) * 128;
+    const int b_row_off = (wp * 64 + l15) * 128;
+
+    issue(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();             // tile kt landed for every wave; buffer cur^1 is free again
+        if (kt + 1 < nk) issue(cur ^ 1);
+        const char* wt = smem + cur * STAGE;
+        const char* xt = wt + WBYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int koff = (((4 * s + lg) ^ (l15 & 7)) << 4);
+            half8 a[5], b[4];
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                a[i] = *reinterpret_cast<const half8*>(wt + a_row_off + i * 16 * 128 + koff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                b[j] = *reinterpret_cast<const half8*>(xt + b_row_off + j * 16 * 128 + koff);
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
     }
+    epilogue<EPI>(p, acc, p0, c0out, wc, wp, l15, lg, OHW);
 }
 
 }  // namespace
 
+template <int WP, int WC>
+static hipError_t launch_glds(const IGemmParams& p, hipStream_t s) {
+    constexpr int TP = 64 * WP, TC = 80 * WC;
+    constexpr size_t lds = 2 * (size_t)(TP + TC) * 128;
+    const int tiles_p = (p.M + TP - 1) / TP;
+    const int tiles_c = p.Cout / TC;
+    dim3 grid(tiles_p * tiles_c), block(64 * WP * WC);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)igemm_glds_kernel<WP, WC, EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_glds_kernel<WP, WC, EPI_GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (p.epi == EPI_GEGLU)
+        hipLaunchKernelGGL((igemm_glds_kernel<WP, WC, EPI_GEGLU>), grid, block, lds, s, p);
+    else
+        hipLaunchKernelGGL((igemm_glds_kernel<WP, WC, EPI_PLAIN>), grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
+int igemm_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DM_IGEMM"); v = e ? atoi(e) : 3; }
+    return v;
+}
+
 hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
     if (p.Cout % BC != 0 || p.Cin % BK != 0 || p.C1 % BK != 0 || p.M <= 0) return hipErrorInvalidValue;
+    const int var = igemm_variant();
+    if (var == 1) return launch_glds<2, 2>(p, s);
+    if (var == 2) return launch_glds<4, 2>(p, s);
+    if (var == 3 && p.Cout % 320 == 0) return launch_glds<2, 4>(p, s);
+    if (var == 3) return launch_glds<2, 2>(p, s);
     const int tiles_p = (p.M + BP - 1) / BP;
     const int tiles_c = p.Cout / BC;
     dim3 grid(tiles_p * tiles_c), block(NTHREADS);

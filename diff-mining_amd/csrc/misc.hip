@@ -31,21 +31,16 @@ __global__ void silu_kernel(const f16* __restrict__ in, f16* __restrict__ out, l
     out[i] = (f16)(x / (1.0f + __expf(-x)));
 }
 
-// One thread = one output pixel x 8 output channels.  Input is NCHW fp16 (4 channels), the
-// noisy latent is formed in fp16 arithmetic exactly as the fp16 scheduler does:
-//   noisy = fp16(fp16(sa * x) + fp16(sb * eps)),  sa = fp16(sqrt(fp16 acp[t])), sb likewise.
-__global__ void conv_in_kernel(const f16* __restrict__ x, const int32_t* __restrict__ x_index,
-                               const f16* __restrict__ eps, const int64_t* __restrict__ t,
-                               const f16* __restrict__ sa_tab, const f16* __restrict__ sb_tab,
-                               const f16* __restrict__ w, const f16* __restrict__ bias, int B, int H, int W, int C0,
-                               f16* __restrict__ Y) {
-    const int cg = C0 >> 3;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)B * H * W * cg;
-    if (i >= total) return;
-    const int cgi = (int)(i % cg);
-    const long long pix = i / cg;
+// One thread = one pixel: forms the 36 (zero padded) noisy inputs of its 3x3x4 patch and writes one
+// 128-byte im2col row.  The noisy latent is formed in fp16 arithmetic exactly as the fp16 scheduler
+// does:  noisy = fp16(fp16(sa * x) + fp16(sb * eps)),  sa = fp16(sqrt(fp16 acp[t])), sb likewise.
+__global__ void im2col_in_kernel(const f16* __restrict__ x, const int32_t* __restrict__ x_index,
+                                 const f16* __restrict__ eps, const int64_t* __restrict__ t,
+                                 const f16* __restrict__ sa_tab, const f16* __restrict__ sb_tab, int B, int H, int W,
+                                 f16* __restrict__ out) {
+    const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int HW = H * W;
+    if (pix >= (long long)B * HW) return;
     const int b = (int)(pix / HW);
     const int rem = (int)(pix - (long long)b * HW);
     const int oh = rem / W, ow = rem - oh * W;
@@ -57,34 +52,36 @@ __global__ void conv_in_kernel(const f16* __restrict__ x, const int32_t* __restr
         sa = sa_tab[tt]; sb = sb_tab[tt];
     }
     const int xb = x_index ? x_index[b] : b;
-    float acc[8];
+    f16 row[64];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-    for (int c = 0; c < 4; ++c) {
-        for (int dy = 0; dy < 3; ++dy) {
-            const int ih = oh + dy - 1;
-            if (ih < 0 || ih >= H) continue;
+    for (int k = 0; k < 64; ++k) row[k] = (f16)0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const int iw = ow + dx - 1;
-                if (iw < 0 || iw >= W) continue;
-                f16 v = x[((size_t)xb * 4 + c) * HW + ih * W + iw];
-                if (noise) {
-                    const f16 e = eps[((size_t)b * 4 + c) * HW + ih * W + iw];
-                    const f16 p1 = sa * v;          // fp16 multiply, rounded
-                    const f16 p2 = sb * e;
-                    v = p1 + p2;                    // fp16 add, rounded
+                const int ih = oh + dy - 1, iw = ow + dx - 1;
+                f16 v = (f16)0.f;
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
+                    v = x[((size_t)xb * 4 + c) * HW + ih * W + iw];
+                    if (noise) {
+                        const f16 e = eps[((size_t)b * 4 + c) * HW + ih * W + iw];
+                        const f16 p1 = sa * v;          // fp16 multiply, rounded (-ffp-contract=off)
+                        const f16 p2 = sb * e;
+                        v = p1 + p2;                    // fp16 add, rounded
+                    }
                 }
-                const float fv = (float)v;
-                const int kidx = c * 9 + dy * 3 + dx;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] += fv * (float)w[(cgi * 8 + k) * 36 + kidx];
+                row[c * 9 + dy * 3 + dx] = v;
             }
-        }
-    }
-    half8 o;
+    half8* dst = reinterpret_cast<half8*>(out + pix * 64);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = (f16)(acc[k] + (float)bias[cgi * 8 + k]);
-    *reinterpret_cast<half8*>(Y + pix * C0 + cgi * 8) = o;
+    for (int k = 0; k < 8; ++k) {
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = row[k * 8 + j];
+        dst[k] = o;
+    }
 }
 
 // conv_out + eps-MSE.  8 lanes cooperate on one pixel: lane j of the group walks the 16-byte
@@ -223,12 +220,11 @@ hipError_t launch_silu(const f16* in, f16* out, long long n, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_conv_in(const f16* x, const int32_t* x_index, const f16* eps, const int64_t* t,
-                          const f16* sa, const f16* sb, const f16* w, const f16* bias, int B, int H, int W,
-                          int C0, f16* Y, hipStream_t s) {
-    const long long total = (long long)B * H * W * (C0 / 8);
-    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x_index, eps, t,
-                       sa, sb, w, bias, B, H, W, C0, Y);
+hipError_t launch_im2col_in(const f16* x, const int32_t* x_index, const f16* eps, const int64_t* t, const f16* sa,
+                            const f16* sb, int B, int H, int W, f16* out, hipStream_t s) {
+    const long long total = (long long)B * H * W;
+    hipLaunchKernelGGL(im2col_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x_index, eps, t, sa, sb,
+                       B, H, W, out);
     return hipGetLastError();
 }
 

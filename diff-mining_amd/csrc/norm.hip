@@ -62,8 +62,11 @@ __global__ void gn_stats_partial(const f16* __restrict__ X, const f16* __restric
     }
 }
 
-__global__ void gn_stats_final(const double* __restrict__ partial, int total, int chunks, int G, double count,
-                               float eps, float* __restrict__ stats) {
+// one thread per (n, g): mean/rstd in fp64, then the per-channel affine of that group:
+//   y = x * a + b,  a = rstd * gamma[c],  b = beta[c] - mean * a      (ab[n][c] = {a, b})
+__global__ void gn_stats_final(const double* __restrict__ partial, int total, int chunks, int G, int C, double count,
+                               float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               float* __restrict__ ab) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;   // n*G + g
     if (i >= total) return;
     const int n = i / G, g = i - n * G;
@@ -75,35 +78,45 @@ __global__ void gn_stats_final(const double* __restrict__ partial, int total, in
     const double mean = ds / count;
     double var = dq / count - mean * mean;
     var = var > 0.0 ? var : 0.0;
-    stats[(size_t)i * 2 + 0] = (float)mean;
-    stats[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const int cpg = C / G;
+    for (int k = 0; k < cpg; ++k) {
+        const int c = g * cpg + k;
+        const double a = rstd * (double)gamma[c];
+        ab[((size_t)n * C + c) * 2 + 0] = (float)a;
+        ab[((size_t)n * C + c) * 2 + 1] = (float)((double)beta[c] - mean * a);
+    }
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
-// one thread = 8 channels of one pixel
-__global__ void gn_apply_kernel(const f16* __restrict__ X, const f16* __restrict__ X2, long long total8, int HW,
-                                int C, int C1, int G, const float* __restrict__ stats,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
-                                f16* __restrict__ Y) {
+// grid (pixel chunks, N); thread = fixed 8-channel column (its affine lives in registers) x row group.
+__global__ void gn_apply_kernel(const f16* __restrict__ X, const f16* __restrict__ X2, int HW, int C, int C1, int R,
+                                int pix_per_block, const float* __restrict__ ab, int silu, f16* __restrict__ Y) {
     const int cols = C >> 3;
-    const int cpg = C / G;
+    const int n = blockIdx.y;
+    const int t = threadIdx.x;
+    const int col = t % cols;
+    const int rg = t / cols;
+    if (rg >= R) return;
+    const int c = col * 8;
     const int C2 = C - C1;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total8;
-         i += (long long)gridDim.x * blockDim.x) {
-        const long long pix = i / cols;
-        const int c = (int)(i - pix * cols) * 8;
-        const int n = (int)(pix / HW);
+    float a[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a[k] = ab[((size_t)n * C + c + k) * 2 + 0];
+        b[k] = ab[((size_t)n * C + c + k) * 2 + 1];
+    }
+    const int px0 = blockIdx.x * pix_per_block;
+    const int px1 = min(HW, px0 + pix_per_block);
+    for (int px = px0 + rg; px < px1; px += R) {
+        const size_t pix = (size_t)n * HW + px;
         const f16* src = (c < C1) ? (X + pix * C1 + c) : (X2 + pix * C2 + (c - C1));
         const half8 v = *reinterpret_cast<const half8*>(src);
         half8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int ch = c + k;
-            const int g = ch / cpg;
-            const float mean = stats[((size_t)n * G + g) * 2 + 0];
-            const float rstd = stats[((size_t)n * G + g) * 2 + 1];
-            float y = ((float)v[k] - mean) * rstd * gamma[ch] + beta[ch];
+            float y = fmaf((float)v[k], a[k], b[k]);
             if (silu) y = silu_f(y);
             o[k] = (f16)y;
         }
@@ -165,29 +178,34 @@ __global__ void layernorm_kernel(const f16* __restrict__ X, int rows, int C, con
 
 int gn_stats_chunks(int HW) { return (HW + GN_PIX - 1) / GN_PIX; }
 
-hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, float eps,
-                           double* partial, float* stats, hipStream_t s) {
-    if (C % 8 || C % G || C1 % 8) return hipErrorInvalidValue;
+static void gn_geometry(int C, int* R, int* threads) {
     const int cols = C / 8;
-    int R = 320 / cols; if (R < 1) R = 1; if (R > 8) R = 8;
-    const int threads = ((cols * R + 63) / 64) * 64;
+    int r = 320 / cols; if (r < 1) r = 1; if (r > 8) r = 8;
+    *R = r; *threads = ((cols * r + 63) / 64) * 64;
+}
+
+hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, float eps,
+                           const float* gamma, const float* beta, double* partial, float* ab, hipStream_t s) {
+    if (C % 8 || C % G || C1 % 8) return hipErrorInvalidValue;
+    int R, threads; gn_geometry(C, &R, &threads);
     if (threads > 1024) return hipErrorInvalidValue;
     const int chunks = gn_stats_chunks(HW);
     const size_t lds = (size_t)R * C * 2 * sizeof(float);
     hipLaunchKernelGGL(gn_stats_partial, dim3(chunks, N), dim3(threads), lds, s, X, X2 ? X2 : X, HW, C, C1, G, R, partial);
     const int tot = N * G;
-    hipLaunchKernelGGL(gn_stats_final, dim3((tot + 63) / 64), dim3(64), 0, s, partial, tot, chunks, G,
-                       (double)HW * (double)(C / G), eps, stats);
+    hipLaunchKernelGGL(gn_stats_final, dim3((tot + 63) / 64), dim3(64), 0, s, partial, tot, chunks, G, C,
+                       (double)HW * (double)(C / G), eps, gamma, beta, ab);
     return hipGetLastError();
 }
 
-hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, const float* stats,
-                           const float* gamma, const float* beta, int silu, f16* Y, hipStream_t s) {
-    const long long total8 = (long long)N * HW * (C / 8);
-    long long blocks = (total8 + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, X2 ? X2 : X, total8, HW, C, C1, G,
-                       stats, gamma, beta, silu, Y);
+hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, int C1, const float* ab, int silu,
+                           f16* Y, hipStream_t s) {
+    int R, threads; gn_geometry(C, &R, &threads);
+    // enough blocks to fill the chip, few enough that the per-thread affine load amortises
+    int ppb = 64;
+    while (ppb > 8 && (long long)N * ((HW + ppb - 1) / ppb) < 2048) ppb >>= 1;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + ppb - 1) / ppb, N), dim3(threads), 0, s, X, X2 ? X2 : X, HW, C, C1, R,
+                       ppb, ab, silu, Y);
     return hipGetLastError();
 }
 
