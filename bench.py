@@ -136,23 +136,26 @@ def main():
 
 
 def cpu_baseline(sd):
-    """Oracle (fp32 PyTorch CPU) on a bounded sample: 1 draw x 2 prompts of one 64x64 latent."""
+    """Oracle (fp32 PyTorch CPU, kind "port") on a bounded sample of the same workload: 2 draws x 2
+    prompts of one 64x64 latent = 4 of the 20 U-Net forwards of one image.  Thread count: the fp32
+    oracle peaks at 16 threads on the GPU box's host (measured 681 / 500 / 169 / 78 GFLOP/s at
+    16 / 32 / 64 / 128 threads), so 16 are used and reported as `cores`."""
     from diff_mining_amd import synth
     from oracle import unet_ref as R
-    cores = os.cpu_count() or 1
+    cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     sdt = {k: torch.from_numpy(v).float() for k, v in sd.items()}
-    x, eps, t, c = (torch.from_numpy(a) for a in synth.synth_inputs(1, 1, LAT, LAT))
+    x, eps, t, c = (torch.from_numpy(a) for a in synth.synth_inputs(1, 2, LAT, LAT))
     nb, tb = torch.cat([eps] * 2), torch.cat([t] * 2)
-    cc = torch.cat([c[0:1], c[1:2]]).float()
+    cc = torch.cat([c[0:1].expand(2, -1, -1), c[1:2].expand(2, -1, -1)]).float()
     with torch.no_grad():
         R.compute_loss(sdt, x[:, :, :16, :16], nb[:, :, :16, :16], tb, cc, autocast=False)     # warm-up (small)
         t0 = time.perf_counter()
         R.compute_loss(sdt, x, nb, tb, cc, autocast=False)
         dt = time.perf_counter() - t0
-    forwards = 2
+    forwards = 4
     return {"value": round(forwards / (N_DRAWS * N_COND) / dt, 6), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{forwards} U-Net forwards @64x64 (1/10 of one image) in {dt:.1f}s, fp32 oracle, torch threads={cores}",
+            "sample": f"{forwards} U-Net forwards @64x64 (1/5 of one image's 20) in {dt:.1f}s, fp32 oracle, torch threads={cores}",
             "gflops": round(forwards * FLOP_PER_FORWARD_64 / dt / 1e9, 1)}
 
 

@@ -14,6 +14,7 @@
 // have to agree), so P never moves between lanes and never touches LDS.  head_dim is zero padded
 // in LDS only (40 -> 64 for QK^T k, 40 -> 48 for the PV output rows), never in HBM.
 #include "dm_kernels.h"
+#include <cstdlib>
 
 namespace dm {
 
@@ -27,6 +28,7 @@ namespace {
 
 constexpr int QB = 128;    // queries per block
 constexpr int KT = 64;     // keys per tile
+constexpr float RESCALE_THR = 8.0f;   // log2 units (attention v2 lazy rescale)
 constexpr int NT = 256;
 
 template <int D>
@@ -237,10 +239,329 @@ hipError_t launch_t(const AttnParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// v2: K and V tiles go HBM/L2 -> LDS directly with global_load_lds (row-major [key][D], no VGPR
+// staging, no transposing ds_write); the PV A operand (V^T, k-contiguous) is produced by the LDS
+// transpose read ds_read_b64_tr_b16 (each 16-lane group reads a 4-key x 16-d block and receives it
+// transposed: lane i gets 4 consecutive keys of column d = i).  head_dim padding (40->64 for the QK^T
+// k extent, 40->48 for PV rows) is realised by pointing the out-of-range lanes at a zeroed LDS slot.
+// QF = 16-query fragments per wave (queries per block = 64*QF).
+// ---------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) unsigned char g_attn_zero[256];
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+template <int D, int QF, int KTL, bool GLDS>
+__global__ __launch_bounds__(NT)
+void attn2_kernel(AttnParams p) {
+    constexpr int DP = ((D + 31) / 32) * 32, DV = ((D + 15) / 16) * 16;
+    constexpr int KS = DP / 32, EF = DV / 16, NCH = D / 8;
+    constexpr int RS = D * 2;                      // LDS row stride (bytes), rows contiguous
+    constexpr int TBYTES = KTL * RS;               // one K (or V) tile
+    constexpr int ZREL = 2 * TBYTES;               // zeroed 64-byte slot at the end of each stage
+    constexpr int STAGE = 2 * TBYTES + 64;
+    constexpr int NI = 2 * NCH * (KTL / 64);       // glds instructions per KV tile (K then V)
+    constexpr int MI = (NI + 3) / 4;               // per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+    const int h = blockIdx.y;
+    const int b = blockIdx.z;
+    const int q0 = blockIdx.x * (64 * QF) + wid * (16 * QF);
+    const int kvb = p.kv_slot ? p.kv_slot[b] : b;
+
+    const f16* Qb = p.Q + (size_t)b * p.bsq + h * D;
+    const f16* Kb = p.K + (size_t)kvb * p.bsk + h * D;
+    const f16* Vb = p.V + (size_t)kvb * p.bsv + h * D;
+    f16* Ob = p.O + (size_t)b * p.bso + h * D;
+
+    if (tid < 32) *reinterpret_cast<unsigned*>(smem + (tid >> 4) * STAGE + ZREL + (tid & 15) * 4) = 0u;
+
+    // ---- Q fragments ----------------------------------------------------------------------------
+    half8 qf[QF][KS];
+#pragma unroll
+    for (int jq = 0; jq < QF; ++jq) {
+        int q = q0 + 16 * jq + l15;
+        q = q < p.Tq ? q : p.Tq - 1;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int d = 32 * s + 8 * lg;
+            if (d < D) qf[jq][s] = *reinterpret_cast<const half8*>(Qb + (size_t)q * p.ldq + d);
+            else qf[jq][s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+
+    // ---- glds bookkeeping: instruction j = wid + 4*i covers elements idx = (j % NCH ... ) ----------
+    // K tile = instructions 0..NI/2-1, V tile = NI/2..NI-1; instruction jj of a tile writes LDS bytes
+    // [jj*1024, +1024) = 16-byte chunks idx = jj*64 + lane -> (key = idx / NCH, ch = idx % NCH)
+    const f16* gsrc[MI];
+    int gkey[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int j = wid + 4 * i;
+        const int jj = (j < NI / 2) ? j : j - NI / 2;
+        const int idx = jj * 64 + lane;
+        const int key = idx / NCH, ch = idx - key * NCH;
+        gkey[i] = key;
+        gsrc[i] = ((j < NI / 2) ? Kb : Vb) + (size_t)key * ((j < NI / 2) ? p.ldk : p.ldv) + ch * 8;
+    }
+    const f16* zero = reinterpret_cast<const f16*>(g_attn_zero);
+    u32x4 stg[MI];                                 // register staging (GLDS == false)
+    auto issue = [&](int buf, int k0) {            // GLDS: HBM/L2 -> LDS directly; else -> registers
+        char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int j = wid + 4 * i;
+            if (j < NI) {
+                const bool ok = (k0 + gkey[i] < p.Tk);
+                if (GLDS) {
+                    const f16* a = ok ? gsrc[i] : zero;
+                    __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(base + j * 1024), 16, 0, 0);
+                } else {
+                    stg[i] = ok ? *reinterpret_cast<const u32x4*>(gsrc[i]) : u32x4{0u, 0u, 0u, 0u};
+                }
+                gsrc[i] += (size_t)KTL * ((j < NI / 2) ? p.ldk : p.ldv);
+            }
+        }
+    };
+    auto commit = [&](int buf) {                   // registers -> LDS (same lane-linear image as glds)
+        char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int j = wid + 4 * i;
+            if (j < NI) *reinterpret_cast<u32x4*>(base + j * 1024 + lane * 16) = stg[i];
+        }
+    };
+
+    // ---- LDS read offsets (tile-relative; lanes beyond head_dim read the zero slot) ---------------
+    int koff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) koff[s] = (32 * s + 8 * lg < D) ? (l15 * RS + 64 * s + 16 * lg) : ZREL;
+    int voff[EF];
+#pragma unroll
+    for (int e = 0; e < EF; ++e)
+        voff[e] = (16 * e + 4 * (l15 & 3) < D) ? (TBYTES + (4 * lg + (l15 >> 2)) * RS + 32 * e + 8 * (l15 & 3)) : ZREL;
+    // a lane either reads real rows (offset advances with the fragment) or the zero slot (it does not)
+    // NOTE: sub-tile 1 adds 64*RS to every address, so the zero slot is 64 bytes at ZREL and another
+    // 64 bytes at ZREL + 64*RS is needed; instead lanes that read zeros subtract the sub offset again.
+    int kstep[KS], vstep[EF];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) kstep[s] = (koff[s] == ZREL) ? 0 : 16 * RS;
+#pragma unroll
+    for (int e = 0; e < EF; ++e) vstep[e] = (voff[e] == ZREL) ? 0 : 16 * RS;
+
+    floatx4 oacc[EF][QF];
+#pragma unroll
+    for (int e = 0; e < EF; ++e)
+#pragma unroll
+        for (int jq = 0; jq < QF; ++jq) oacc[e][jq] = floatx4{0, 0, 0, 0};
+    float m_run[QF], l_run[QF];
+#pragma unroll
+    for (int jq = 0; jq < QF; ++jq) { m_run[jq] = -INFINITY; l_run[jq] = 0.f; }
+    const float sc = p.scale * 1.44269504088896340736f;
+
+    auto compute = [&](int buf, int sub, int k0, bool tail) {
+        const char* kt = smem + buf * STAGE + sub * (64 * RS);
+        floatx4 sacc[4][QF];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int jq = 0; jq < QF; ++jq) sacc[f][jq] = floatx4{0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const half8 kf = *reinterpret_cast<const half8*>(kt + koff[s] + f * kstep[s] - (kstep[s] ? 0 : sub * (64 * RS)));
+#pragma unroll
+                for (int jq = 0; jq < QF; ++jq)
+                    sacc[f][jq] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[jq][s], sacc[f][jq], 0, 0, 0);
+            }
+        }
+        half8 pb[QF][2];
+#ifdef DM_EXP_NOSOFTMAX
+#pragma unroll
+        for (int jq = 0; jq < QF; ++jq)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pb[jq][f >> 1][(f & 1) * 4 + r] = (f16)sacc[f][jq][r];
+#else
+#pragma unroll
+        for (int jq = 0; jq < QF; ++jq) {
+            if (tail) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + 16 * f + 4 * lg + r >= p.Tk) sacc[f][jq][r] = -INFINITY;
+            }
+            float mx = sacc[0][jq][0];
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = __builtin_fmaxf(mx, sacc[f][jq][r]);
+            mx = __builtin_fmaxf(mx, __shfl_xor(mx, 16));
+            mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32));
+            // lazy rescale: keep the stale running max while no row of the wave grew by more than
+            // 2^RESCALE_THR; P is then bounded by 2^RESCALE_THR (exact in fp32, fp16 keeps 11 bits).
+            const float mxs = mx * sc;
+            if (__builtin_amdgcn_ballot_w64(mxs > m_run[jq] + RESCALE_THR) != 0ull) {
+                const float m_new = __builtin_fmaxf(m_run[jq], mxs);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[jq] - m_new);
+                m_run[jq] = m_new;
+                l_run[jq] *= alpha;
+#pragma unroll
+                for (int e = 0; e < EF; ++e) oacc[e][jq] *= alpha;
+            }
+            const float m_use = m_run[jq];
+            float ps = 0.f;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#ifdef DM_EXP_NOEXP
+                    const float pv = __builtin_fmaf(sacc[f][jq][r], sc, -m_use) * 1e-3f;
+#else
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[f][jq][r], sc, -m_use));
+#endif
+                    ps += pv;
+                    pb[jq][f >> 1][(f & 1) * 4 + r] = (f16)pv;
+                }
+            l_run[jq] += ps;
+        }
+#endif
+        // PV: the transpose reads are issued through inline asm — the builtin form makes hipcc drain
+        // vmcnt(0) (the in-flight LDS-DMA of the NEXT tile) before every LDS transpose read, which
+        // serialises the prefetch.  All 4*EF reads are issued, then one lgkmcnt(0), then the MFMAs.
+        u32x2 vraw[2][EF][2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int e = 0; e < EF; ++e)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const unsigned a = (unsigned)(size_t)(kt + voff[e] + (2 * s2 + hh) * vstep[e] - (vstep[e] ? 0 : sub * (64 * RS)));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vraw[s2][e][hh]) : "v"(a) : "memory");
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int e = 0; e < EF; ++e) {
+                half8 va;
+                __builtin_memcpy(&va, &vraw[s2][e][0], 8);
+                __builtin_memcpy(reinterpret_cast<char*>(&va) + 8, &vraw[s2][e][1], 8);
+#ifdef DM_EXP_NOPV
+                asm volatile("" :: "v"(va));
+#else
+#pragma unroll
+                for (int jq = 0; jq < QF; ++jq)
+                    oacc[e][jq] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[jq][s2], oacc[e][jq], 0, 0, 0);
+#endif
+            }
+#ifdef DM_EXP_NOPV
+#pragma unroll
+        for (int jq = 0; jq < QF; ++jq) { asm volatile("" :: "v"(pb[jq][0]), "v"(pb[jq][1])); }
+#endif
+    };
+
+    const int ntiles = (p.Tk + KTL - 1) / KTL;
+    auto compute_tile = [&](int cur, int k0) {
+        if (k0 + 64 > p.Tk) compute(cur, 0, k0, true); else compute(cur, 0, k0, false);
+        if (KTL == 128 && k0 + 64 < p.Tk) {
+            if (k0 + 128 > p.Tk) compute(cur, 1, k0 + 64, true); else compute(cur, 1, k0 + 64, false);
+        }
+    };
+    if (GLDS) {
+        issue(0, 0);
+        for (int t = 0; t < ntiles; ++t) {
+            const int cur = t & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + 1 < ntiles) issue(cur ^ 1, (t + 1) * KTL);
+            compute_tile(cur, t * KTL);
+        }
+    } else {
+        issue(0, 0);
+        __syncthreads();            // zero slots written
+        commit(0);
+        __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < ntiles) issue(cur ^ 1, (t + 1) * KTL);     // global loads in flight under compute
+            compute_tile(cur, t * KTL);
+            if (t + 1 < ntiles) commit(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int jq = 0; jq < QF; ++jq) {
+        float l = l_run[jq];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int q = q0 + 16 * jq + l15;
+        if (q >= p.Tq) continue;
+#pragma unroll
+        for (int e = 0; e < EF; ++e) {
+            const int d = 16 * e + 4 * lg;
+            if (d < D) {
+                const half4 o = half4{(f16)(oacc[e][jq][0] * inv), (f16)(oacc[e][jq][1] * inv),
+                                      (f16)(oacc[e][jq][2] * inv), (f16)(oacc[e][jq][3] * inv)};
+                *reinterpret_cast<half4*>(Ob + (size_t)q * p.ldo + d) = o;
+            }
+        }
+    }
+}
+
+template <int D, int QF, int KTL, bool GLDS>
+hipError_t launch2_t(const AttnParams& p, hipStream_t s) {
+    constexpr int QBLK = 64 * QF;
+    dim3 grid((p.Tq + QBLK - 1) / QBLK, p.heads, p.B), block(NT);
+    const size_t lds = 2 * (2 * (size_t)KTL * D * 2 + 64);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn2_kernel<D, QF, KTL, GLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn2_kernel<D, QF, KTL, GLDS>), grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
+static int attn_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DM_ATTN"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 }  // namespace
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.Tq <= 0 || p.Tk <= 0 || p.B <= 0) return hipErrorInvalidValue;
+    const int var = attn_variant();
+    if (var >= 1) {
+        switch (p.D * 10 + var) {
+            case 401: return launch2_t<40, 2, 64, true>(p, s);
+            case 403: return launch2_t<40, 2, 64, false>(p, s);
+            case 404: return launch2_t<40, 2, 128, false>(p, s);
+            case 405: return launch2_t<40, 2, 128, true>(p, s);
+            default: break;
+        }
+        switch (p.D) {
+            case 40: return launch2_t<40, 2, 64, true>(p, s);
+            case 80: return launch2_t<80, 2, 64, true>(p, s);
+            case 160: return launch2_t<160, 2, 64, true>(p, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (p.D) {
         case 40: return launch_t<40>(p, s);
         case 80: return launch_t<80>(p, s);

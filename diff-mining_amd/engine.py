@@ -34,7 +34,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("DM_ENGINE_LIB") or LIB_PATH   # DM_ENGINE_LIB: kernel A/B experiments
     if not os.path.exists(p):
         raise EngineError(
             f"{p} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "

@@ -1,0 +1,15 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 --pmc CSV output (counter_collection.csv): mean counter value per kernel."""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, cs in acc.items():
+    print(k)
+    for c, v in sorted(cs.items()):
+        print(f"   {c:28s} n={len(v):4d} mean={sum(v)/len(v):.4g}")
