@@ -254,7 +254,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 template <int D, int QF, int KTL, bool GLDS>
-__global__ __launch_bounds__(NT)
+__global__ __launch_bounds__(NT, (D > 80 ? 1 : 2))
 void attn2_kernel(AttnParams p) {
     constexpr int DP = ((D + 31) / 32) * 32, DV = ((D + 15) / 16) * 16;
     constexpr int KS = DP / 32, EF = DV / 16, NCH = D / 8;
@@ -313,7 +313,7 @@ void attn2_kernel(AttnParams p) {
     }
     const f16* zero = reinterpret_cast<const f16*>(g_attn_zero);
     u32x4 stg[MI];                                 // register staging (GLDS == false)
-    auto issue = [&](int buf, int k0) {            // GLDS: HBM/L2 -> LDS directly; else -> registers
+    auto issue = [&](int buf, int k0) __attribute__((always_inline)) {            // GLDS: HBM/L2 -> LDS directly; else -> registers
         char* base = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -330,7 +330,7 @@ void attn2_kernel(AttnParams p) {
             }
         }
     };
-    auto commit = [&](int buf) {                   // registers -> LDS (same lane-linear image as glds)
+    auto commit = [&](int buf) __attribute__((always_inline)) {                   // registers -> LDS (same lane-linear image as glds)
         char* base = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -366,7 +366,7 @@ void attn2_kernel(AttnParams p) {
     for (int jq = 0; jq < QF; ++jq) { m_run[jq] = -INFINITY; l_run[jq] = 0.f; }
     const float sc = p.scale * 1.44269504088896340736f;
 
-    auto compute = [&](int buf, int sub, int k0, bool tail) {
+    auto compute = [&](int buf, int sub, int k0, bool tail) __attribute__((always_inline)) {
         const char* kt = smem + buf * STAGE + sub * (64 * RS);
         floatx4 sacc[4][QF];
 #pragma unroll
@@ -439,33 +439,40 @@ void attn2_kernel(AttnParams p) {
         // PV: the transpose reads are issued through inline asm — the builtin form makes hipcc drain
         // vmcnt(0) (the in-flight LDS-DMA of the NEXT tile) before every LDS transpose read, which
         // serialises the prefetch.  All 4*EF reads are issued, then one lgkmcnt(0), then the MFMAs.
-        u32x2 vraw[2][EF][2];
+        // (for large head_dim the reads are batched per 32-key half to bound the register footprint)
+        constexpr int NB = (EF <= 5) ? 1 : 2;          // batches
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+        for (int bt = 0; bt < NB; ++bt) {
+            u32x2 vraw[2 / NB][EF][2];
 #pragma unroll
-            for (int e = 0; e < EF; ++e)
+            for (int s2 = 0; s2 < 2 / NB; ++s2)
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const unsigned a = (unsigned)(size_t)(kt + voff[e] + (2 * s2 + hh) * vstep[e] - (vstep[e] ? 0 : sub * (64 * RS)));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vraw[s2][e][hh]) : "v"(a) : "memory");
-                }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+                for (int e = 0; e < EF; ++e)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int ss = bt * (2 / NB) + s2;
+                        const unsigned a = (unsigned)(size_t)(kt + voff[e] + (2 * ss + hh) * vstep[e] - (vstep[e] ? 0 : sub * (64 * RS)));
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vraw[s2][e][hh]) : "v"(a) : "memory");
+                    }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < EF; ++e) {
-                half8 va;
-                __builtin_memcpy(&va, &vraw[s2][e][0], 8);
-                __builtin_memcpy(reinterpret_cast<char*>(&va) + 8, &vraw[s2][e][1], 8);
+            for (int s2 = 0; s2 < 2 / NB; ++s2)
+#pragma unroll
+                for (int e = 0; e < EF; ++e) {
+                    const int ss = bt * (2 / NB) + s2;
+                    half8 va;
+                    __builtin_memcpy(&va, &vraw[s2][e][0], 8);
+                    __builtin_memcpy(reinterpret_cast<char*>(&va) + 8, &vraw[s2][e][1], 8);
 #ifdef DM_EXP_NOPV
-                asm volatile("" :: "v"(va));
+                    asm volatile("" :: "v"(va));
 #else
 #pragma unroll
-                for (int jq = 0; jq < QF; ++jq)
-                    oacc[e][jq] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[jq][s2], oacc[e][jq], 0, 0, 0);
+                    for (int jq = 0; jq < QF; ++jq)
+                        oacc[e][jq] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[jq][ss], oacc[e][jq], 0, 0, 0);
 #endif
-            }
+                }
+        }
 #ifdef DM_EXP_NOPV
 #pragma unroll
         for (int jq = 0; jq < QF; ++jq) { asm volatile("" :: "v"(pb[jq][0]), "v"(pb[jq][1])); }
@@ -473,7 +480,7 @@ void attn2_kernel(AttnParams p) {
     };
 
     const int ntiles = (p.Tk + KTL - 1) / KTL;
-    auto compute_tile = [&](int cur, int k0) {
+    auto compute_tile = [&](int cur, int k0) __attribute__((always_inline)) {
         if (k0 + 64 > p.Tk) compute(cur, 0, k0, true); else compute(cur, 0, k0, false);
         if (KTL == 128 && k0 + 64 < p.Tk) {
             if (k0 + 128 > p.Tk) compute(cur, 1, k0 + 64, true); else compute(cur, 1, k0 + 64, false);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Summarise rocprofv3 --pmc CSV output (counter_collection.csv): mean counter value per kernel."""
+"""Summarise rocprofv3 --pmc CSV output (counter_collection.csv): per (kernel, grid) mean counters."""
 import csv
 import glob
 import sys
@@ -8,7 +8,11 @@ from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        name = r["Kernel_Name"]
+        if "dm::" not in name and "_ZN2dm" not in name:
+            continue
+        name = name.split("(")[0][-60:]
+        acc[(name, r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
     print(k)
     for c, v in sorted(cs.items()):
