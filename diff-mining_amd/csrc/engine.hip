@@ -12,6 +12,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -645,7 +646,9 @@ int ensure_arena(dm_engine* e, const FwdArgs& A, hipStream_t s) {
 
 int max_chunk(int h, int w) {
     const long long px = (long long)h * w;
-    long long b = (160LL * 4096) / px;
+    static long long budget = -1;           // samples of 64x64 per U-Net batch (DM_CHUNK overrides)
+    if (budget < 0) { const char* e = getenv("DM_CHUNK"); budget = e ? atoll(e) : 160; if (budget < 1) budget = 1; }
+    long long b = (budget * 4096) / px;
     if (b < 1) b = 1;
     return (int)b;
 }

@@ -34,10 +34,23 @@ constexpr int XT_BYTES = BP * BK * 2;
 constexpr int STAGE_BYTES = WT_BYTES + XT_BYTES;   // 36864
 constexpr int NTHREADS = 256;
 
+// erf-GELU  x * Phi(x),  Phi via Abramowitz-Stegun 7.1.26 (|erf error| < 1.5e-7, far below the fp16
+// rounding of the result): 1 rcp + 1 exp2 + 7 FMAs instead of libm erff (~40 instructions), which
+// dominated the GEGLU epilogue (40 calls per lane per tile).  The negative tail is formed as
+// 0.5*poly*e directly (no 1 - 1 cancellation).
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    const float ax = __builtin_fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+    float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    poly = __builtin_fmaf(t, poly, 1.421413741f);
+    poly = __builtin_fmaf(t, poly, -0.284496736f);
+    poly = __builtin_fmaf(t, poly, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
+    const float half_tail = 0.5f * poly * e;                 // = 0.5 * (1 - erf(|x|/sqrt2))
+    const float phi = (x < 0.f) ? half_tail : 1.0f - half_tail;
+    return x * phi;
 }
-
 
 template <int EPI>
 __device__ __forceinline__ void epilogue(const IGemmParams& p, floatx4 (&acc)[5][4], int p0, int c0out, int wc,
@@ -79,6 +92,69 @@ __device__ __forceinline__ void epilogue(const IGemmParams& p, floatx4 (&acc)[5]
                 *reinterpret_cast<half4*>(p.Y + (size_t)m * p.ldy + c) = o;
             }
         }
+    }
+}
+
+// Epilogue staged through LDS: fragments (bias / time-embedding / GEGLU applied, rounded to fp16) are
+// written to an LDS tile [TP px][TCO ch] (row stride padded by 8 B: conflict-free ds_write_b64 /
+// b32), then copied out as whole rows with 16-byte stores (+ the residual read the same way).
+// The direct fragment stores write 8-byte (GEGLU: 4-byte) pieces of 16 different 128-byte lines per
+// instruction; on the wide, short-K linears that partial-line traffic bound the whole kernel.
+template <int EPI, int NTH, int TP, int TC>
+__device__ __forceinline__ void epilogue_lds(const IGemmParams& p, floatx4 (&acc)[5][4], char* smem, int p0,
+                                             int c0out, int wc, int wp, int l15, int lg, int OHW) {
+    constexpr int TCO = (EPI == EPI_GEGLU) ? TC / 2 : TC;     // output channels of the tile
+    constexpr int ROWB = TCO * 2 + 8;
+    __syncthreads();                                           // every wave is done with the operand tiles
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pr = wp * 64 + 16 * j + l15;
+        const int m = p0 + pr;
+        const int n = (p.temb != nullptr && m < p.M) ? (m / OHW) : 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int cl = wc * 80 + 16 * i + 4 * lg;              // tile-local channel
+            const int c = c0out + cl;
+            float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+            if (p.bias) {
+                const half4 bv = *reinterpret_cast<const half4*>(p.bias + c);
+                v0 += (float)bv[0]; v1 += (float)bv[1]; v2 += (float)bv[2]; v3 += (float)bv[3];
+            }
+            if (EPI == EPI_GEGLU) {
+                const f16 h0 = (f16)v0, h1 = (f16)v1, g0 = (f16)v2, g1 = (f16)v3;
+                const f16 q0 = (f16)gelu_erf((float)g0), q1 = (f16)gelu_erf((float)g1);
+                typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+                const half2_ o = half2_{(f16)((float)h0 * (float)q0), (f16)((float)h1 * (float)q1)};
+                const int ol = (cl >> 4) * 8 + 2 * lg;
+                *reinterpret_cast<half2_*>(smem + pr * ROWB + ol * 2) = o;
+            } else {
+                half4 o = half4{(f16)v0, (f16)v1, (f16)v2, (f16)v3};
+                if (p.temb && m < p.M) {
+                    const half4 tv = *reinterpret_cast<const half4*>(p.temb + (size_t)n * p.temb_ld + c);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (f16)((float)o[r] + (float)tv[r]);
+                }
+                *reinterpret_cast<half4*>(smem + pr * ROWB + cl * 2) = o;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = TCO / 8;                               // 16-byte chunks per row
+    const int c0o = (EPI == EPI_GEGLU) ? c0out / 2 : c0out;
+    for (int idx = threadIdx.x; idx < TP * CPR; idx += NTH) {
+        const int row = idx / CPR, ch = idx - row * CPR;
+        const int m = p0 + row;
+        if (m >= p.M) continue;
+        const char* src = smem + row * ROWB + ch * 16;
+        const half4 lo = *reinterpret_cast<const half4*>(src);
+        const half4 hi = *reinterpret_cast<const half4*>(src + 8);
+        half8 o = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (EPI != EPI_GEGLU && p.res) {
+            const half8 rv = *reinterpret_cast<const half8*>(p.res + (size_t)m * p.ldres + c0o + ch * 8);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) o[r] = (f16)((float)o[r] + (float)rv[r]);
+        }
+        *reinterpret_cast<half8*>(p.Y + (size_t)m * p.ldy + c0o + ch * 8) = o;
     }
 }
 
@@ -638,7 +714,15 @@ void igemm_il_kernel(IGemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     step((nk - 1) & 1, false);
-    epilogue<EPI>(p, acc, p0, c0out, wc, wp, l15, lg, OHW);
+#ifdef DM_EXP_NOEPI
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
+    if (p.M < 0) epilogue_lds<EPI, 128 * WC, TP, TC>(p, acc, smem, p0, c0out, wc, wp, l15, lg, OHW);
+#else
+    epilogue_lds<EPI, 128 * WC, TP, TC>(p, acc, smem, p0, c0out, wc, wp, l15, lg, OHW);
+#endif
 }
 
 

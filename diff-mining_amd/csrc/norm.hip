@@ -14,12 +14,12 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int GN_PIX = 64;          // pixels per stats block
+constexpr int GN_PIX_MAX = 256;     // pixels per stats block (fewer when the image is small)
 
 // grid (chunks, N); block = (C/8 column threads) x R row groups, <= 320 threads.
 // The channel concat cat([X, X2]) of the up blocks is read in place (never materialised).
 __global__ void gn_stats_partial(const f16* __restrict__ X, const f16* __restrict__ X2, int HW, int C, int C1,
-                                 int G, int R, double* __restrict__ partial) {
+                                 int G, int R, int GN_PIX, double* __restrict__ partial) {
     extern __shared__ float sh[];   // [R][C][2]
     const int cols = C >> 3;
     const int n = blockIdx.y;
@@ -176,7 +176,8 @@ __global__ void layernorm_kernel(const f16* __restrict__ X, int rows, int C, con
 
 }  // namespace
 
-int gn_stats_chunks(int HW) { return (HW + GN_PIX - 1) / GN_PIX; }
+static int gn_pix(int HW) { int p = GN_PIX_MAX; while (p > 32 && HW / p < 16) p >>= 1; return p; }
+int gn_stats_chunks(int HW) { const int p = gn_pix(HW); return (HW + p - 1) / p; }
 
 static void gn_geometry(int C, int* R, int* threads) {
     const int cols = C / 8;
@@ -191,7 +192,7 @@ hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, in
     if (threads > 1024) return hipErrorInvalidValue;
     const int chunks = gn_stats_chunks(HW);
     const size_t lds = (size_t)R * C * 2 * sizeof(float);
-    hipLaunchKernelGGL(gn_stats_partial, dim3(chunks, N), dim3(threads), lds, s, X, X2 ? X2 : X, HW, C, C1, G, R, partial);
+    hipLaunchKernelGGL(gn_stats_partial, dim3(chunks, N), dim3(threads), lds, s, X, X2 ? X2 : X, HW, C, C1, G, R, gn_pix(HW), partial);
     const int tot = N * G;
     hipLaunchKernelGGL(gn_stats_final, dim3((tot + 63) / 64), dim3(64), 0, s, partial, tot, chunks, G, C,
                        (double)HW * (double)(C / G), eps, gamma, beta, ab);
@@ -202,7 +203,7 @@ hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, in
                            f16* Y, hipStream_t s) {
     int R, threads; gn_geometry(C, &R, &threads);
     // enough blocks to fill the chip, few enough that the per-thread affine load amortises
-    int ppb = 64;
+    int ppb = 256;
     while (ppb > 8 && (long long)N * ((HW + ppb - 1) / ppb) < 2048) ppb >>= 1;
     hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + ppb - 1) / ppb, N), dim3(threads), 0, s, X, X2 ? X2 : X, HW, C, C1, R,
                        ppb, ab, silu, Y);

@@ -22,6 +22,8 @@ IGEMM_SHAPES = [
     ("conv3 1280->1280 @8", 1, 8, 8, 1280, 0, 1280, 0),
     ("conv3 2560->1280 @16 (cat)", 1, 16, 16, 1280, 1280, 1280, 0),
     ("geglu 320->2560 @64", 0, 64, 64, 320, 0, 2560, 1),
+    ("plain 320->2560 @64", 0, 64, 64, 320, 0, 2560, 0),
+    ("plain 320->1280 @64", 0, 64, 64, 320, 0, 1280, 0),
     ("ff2 1280->320 @64", 0, 64, 64, 1280, 0, 320, 0),
     ("qkv 320->960 @64", 0, 64, 64, 320, 0, 960, 0),
     ("proj 320->320 @64", 0, 64, 64, 320, 0, 320, 0),
