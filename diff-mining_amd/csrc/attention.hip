@@ -28,6 +28,9 @@ namespace {
 
 constexpr int QB = 128;    // queries per block
 constexpr int KT = 64;     // keys per tile
+#ifndef DM_ATTN40_OCC
+#define DM_ATTN40_OCC 2
+#endif
 constexpr float RESCALE_THR = 8.0f;   // log2 units (attention v2 lazy rescale)
 constexpr int NT = 256;
 
@@ -254,7 +257,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 template <int D, int QF, int KTL, bool GLDS>
-__global__ __launch_bounds__(NT, (D > 80 ? 1 : 2))
+__global__ __launch_bounds__(NT, (D > 80 ? 1 : (D == 40 ? DM_ATTN40_OCC : 2)))
 void attn2_kernel(AttnParams p) {
     constexpr int DP = ((D + 31) / 32) * 32, DV = ((D + 15) / 16) * 16;
     constexpr int KS = DP / 32, EF = DV / 16, NCH = D / 8;

@@ -893,6 +893,214 @@ void igemm_conv3_kernel(IGemmParams p) {
     epilogue<EPI>(p, acc, p0, c0out, wc, wp, l15, lg, OHW);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// p3: 256 px x 160 ch tile, 8 waves (64 px x 80 ch each), THREE LDS stages, fragments double
+// buffered in registers.  Per k step: ONE barrier, LDS-DMA of tile kt+2 interleaved with the MFMAs,
+// and the ds_reads of the next half-step always issued under the current half-step's MFMAs:
+//     block 1:  ds_read frags(s=1, tile kt)     || 20 MFMA on frags(s=0, tile kt)  || DMA(tile kt+2)
+//     counted vmcnt (tile kt+1 landed, tile kt+2 may be in flight) ; lgkmcnt(0) ; s_barrier
+//     block 2:  ds_read frags(s=0, tile kt+1)   || 20 MFMA on frags(s=1, tile kt)
+// ---------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512, 2)
+void igemm_p3_kernel(IGemmParams p) {
+    constexpr int WP = 4, WC = 2, NW = 8;
+    constexpr int TP = 256, TC = 160;
+    constexpr int WBYTES = TC * 128, XBYTES = TP * 128, STAGE = WBYTES + XBYTES;
+    constexpr int WG = TC / 8, XG = TP / 8;                  // 20, 32
+    constexpr int WI = (WG + NW - 1) / NW, XI = XG / NW;     // 3 (waves 4..7 issue 2), 4
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wid % WC;
+    const int wp = wid / WC;
+    const bool w3 = (wid + 2 * NW < WG);                     // this wave issues a third weight piece
+
+    const int tiles_c = p.Cout / TC;
+    const int tiles_p = (p.M + TP - 1) / TP;
+    const int nblk = gridDim.x;
+    int v;
+    {
+        const int b = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = b & 7, loc = b >> 3;
+        v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    int pt, ct;
+    if ((long long)p.Cout * p.Cin * ((p.mode == IG_DENSE) ? 2 : 18) > (3ll << 20)) { ct = v / tiles_p; pt = v - ct * tiles_p; }
+    else { pt = v / tiles_c; ct = v - pt * tiles_c; }
+    const int p0 = pt * TP;
+    const int c0out = ct * TC;
+
+    const int C1 = p.C1;
+    const int C2 = p.Cin - C1;
+    const int ntaps = (p.mode == IG_DENSE) ? 1 : 9;
+    const int cpt = p.Cin / BK;
+    const int nk = ntaps * cpt;
+    const int Ktot = ntaps * p.Cin;
+    const int OHW = p.OH * p.OW;
+
+    const int lrow = lane >> 3;
+    const int lchunk = ((lane & 7) ^ lrow) * 8;
+
+    const f16* wsrc[WI];
+#pragma unroll
+    for (int k = 0; k < WI; ++k) {
+        const int g = wid + k * NW;
+        wsrc[k] = p.Wp + (size_t)(c0out + (g < WG ? g : 0) * 8 + lrow) * Ktot + lchunk;
+    }
+    int xn[XI], xoh[XI], xow[XI];
+#pragma unroll
+    for (int k = 0; k < XI; ++k) {
+        const int m = p0 + (wid + k * NW) * 8 + lrow;
+        if (m < p.M) {
+            if (p.mode == IG_DENSE) { xn[k] = 0; xoh[k] = 0; xow[k] = m; }
+            else {
+                const int n = m / OHW;
+                const int rem = m - n * OHW;
+                const int oh = rem / p.OW;
+                xn[k] = n; xoh[k] = oh; xow[k] = rem - oh * p.OW;
+            }
+        } else { xn[k] = -1; xoh[k] = 0; xow[k] = 0; }
+    }
+    const float sh = (float)p.H / (float)p.OH;
+    const float sw = (float)p.W / (float)p.OW;
+    const f16* zero = reinterpret_cast<const f16*>(g_zero_page) + lchunk;
+
+    const f16* xsrc[XI];
+    int xinc[XI];
+    long long xpix[XI];
+    auto set_tap = [&](int tap) __attribute__((always_inline)) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+        for (int k = 0; k < XI; ++k) {
+            long long off = -1;
+            if (xn[k] >= 0) {
+                if (p.mode == IG_DENSE) {
+                    off = (long long)xow[k];
+                } else if (p.mode == IG_CONV3 || p.mode == IG_CONV3_S2) {
+                    const int st = (p.mode == IG_CONV3_S2) ? 2 : 1;
+                    const int ih = xoh[k] * st + dy - 1, iw = xow[k] * st + dx - 1;
+                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) off = ((long long)xn[k] * p.H + ih) * p.W + iw;
+                } else {
+                    const int uh = xoh[k] + dy - 1, uw = xow[k] + dx - 1;
+                    if (uh >= 0 && uh < p.OH && uw >= 0 && uw < p.OW) {
+                        int ih = (int)floorf((float)uh * sh); ih = ih < p.H - 1 ? ih : p.H - 1;
+                        int iw = (int)floorf((float)uw * sw); iw = iw < p.W - 1 ? iw : p.W - 1;
+                        off = ((long long)xn[k] * p.H + ih) * p.W + iw;
+                    }
+                }
+            }
+            xpix[k] = off;
+            xsrc[k] = (off >= 0) ? (p.X + off * C1 + lchunk) : zero;
+            xinc[k] = (off >= 0) ? BK : 0;
+        }
+    };
+    int ld_tap = 0, ld_cc = 0;
+    auto prepare = [&]() __attribute__((always_inline)) {
+        if (ld_cc == 0) set_tap(ld_tap);
+        else if (ld_cc * BK == C1) {
+#pragma unroll
+            for (int k = 0; k < XI; ++k) if (xpix[k] >= 0) xsrc[k] = p.X2 + xpix[k] * C2 + lchunk;
+        }
+        if (++ld_cc == cpt) { ld_cc = 0; ++ld_tap; }
+    };
+    // piece idx: 0..1 weight (always), 2..5 activation, 6 = third weight piece (waves 0..3 only)
+    auto load_piece = [&](char* stage, int idx) __attribute__((always_inline)) {
+        if (idx < 2) {
+            __builtin_amdgcn_global_load_lds((gptr_t)wsrc[idx], (lptr_t)(stage + (wid + idx * NW) * 1024), 16, 0, 0);
+            wsrc[idx] += BK;
+        } else if (idx < 2 + XI) {
+            const int k = idx - 2;
+            __builtin_amdgcn_global_load_lds((gptr_t)xsrc[k], (lptr_t)(stage + WBYTES + (wid + k * NW) * 1024), 16, 0, 0);
+            xsrc[k] += xinc[k];
+        } else {
+            if (w3) __builtin_amdgcn_global_load_lds((gptr_t)wsrc[2], (lptr_t)(stage + (wid + 2 * NW) * 1024), 16, 0, 0);
+            wsrc[2] += BK;
+        }
+    };
+    constexpr int NPIECE = 2 + XI + 1;                        // 7 issue slots (the last may be empty)
+
+    floatx4 acc[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+    const int a_row_off = (wc * 80 + l15) * 128;
+    const int b_row_off = WBYTES + (wp * 64 + l15) * 128;
+    const int koff0 = ((lg ^ (l15 & 7)) << 4), koff1 = (((4 + lg) ^ (l15 & 7)) << 4);
+
+    half8 a0[5], b0[4], a1[5], b1[4];
+    auto read_frags = [&](const char* stage, int koff, half8 (&a)[5], half8 (&b)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) a[i] = *reinterpret_cast<const half8*>(stage + a_row_off + i * 2048 + koff);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8*>(stage + b_row_off + j * 2048 + koff);
+    };
+    auto wait_landed = [&](bool newer_in_flight) __attribute__((always_inline)) {
+        // all of this wave's pieces except those of the newest tile have landed
+        if (!newer_in_flight) wait_vmcnt<0>();
+        else if (w3) wait_vmcnt<7>();
+        else wait_vmcnt<6>();
+    };
+
+    // ---- prologue: tiles 0 and 1 in flight, fragments (s=0) of tile 0 in registers -------------
+    prepare();
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) load_piece(smem, i);
+    if (nk > 1) {
+        prepare();
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) load_piece(smem + STAGE, i);
+    }
+    wait_landed(nk > 1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(smem, koff0, a0, b0);
+
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nxt = (cur == 2) ? 0 : cur + 1;
+        const int nn = (nxt == 2) ? 0 : nxt + 1;
+        const char* st = smem + cur * STAGE;
+        char* st2 = smem + nn * STAGE;
+        const bool more2 = (kt + 2 < nk);
+        if (more2) prepare();
+        // ---- block 1 ----
+        read_frags(st, koff1, a1, b1);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+            if (more2) { load_piece(st2, i); if (i + 5 < NPIECE) load_piece(st2, i + 5); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- hand-off ----
+        if (kt + 1 < nk) {
+            wait_landed(more2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            read_frags(smem + nxt * STAGE, koff0, a0, b0);
+        }
+        // ---- block 2 ----
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+        cur = nxt;
+    }
+    epilogue_lds<EPI, 512, TP, TC>(p, acc, smem, p0, c0out, wc, wp, l15, lg, OHW);
+}
+
 }  // namespace
 
 template <int WP, int WC, int STAGES>
@@ -950,6 +1158,23 @@ static hipError_t launch_conv3(const IGemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+static hipError_t launch_p3(const IGemmParams& p, hipStream_t s) {
+    constexpr int TP = 256, TC = 160;
+    constexpr size_t lds = 3 * (size_t)(TP + TC) * 128;
+    const int tiles_p = (p.M + TP - 1) / TP;
+    const int tiles_c = p.Cout / TC;
+    dim3 grid(tiles_p * tiles_c), block(512);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)igemm_p3_kernel<EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_p3_kernel<EPI_GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (p.epi == EPI_GEGLU) hipLaunchKernelGGL((igemm_p3_kernel<EPI_GEGLU>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((igemm_p3_kernel<EPI_PLAIN>), grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
 int igemm_variant() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("DM_IGEMM"); v = e ? atoi(e) : 6; }
@@ -963,7 +1188,8 @@ hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
     if (var == 2) return launch_glds<4, 2, 2>(p, s);
     if (var == 3 && p.Cout % 320 == 0) return launch_glds<2, 4, 2>(p, s);
     if (var == 3) return launch_glds<2, 2, 2>(p, s);
-    if (var >= 8 && p.mode == IG_CONV3 && p.epi == EPI_PLAIN && p.OH == p.H && p.OW == p.W) return launch_conv3(p, s);
+    if (var == 9) return launch_p3(p, s);
+    if (var == 8 && p.mode == IG_CONV3 && p.epi == EPI_PLAIN && p.OH == p.H && p.OW == p.W) return launch_conv3(p, s);
     if ((var == 6 || var == 8) && p.Cout % 320 == 0) return launch_il<4>(p, s);
     if (var == 8) return launch_il<2>(p, s);
     if (var == 6 || var == 7) return launch_il<2>(p, s);
