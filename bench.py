@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--images", type=int, default=N_IMG)
+    ap.add_argument("--workload", choices=["typicality", "dift", "xray"], default="typicality",
+                    help="typicality = BASELINE configs[1]/[2] (the graded line); dift = configs[3]; xray = configs[4]")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -60,6 +62,9 @@ def main():
     sd = synth.synth_state_dict(seed=0, dtype=np.float16)
     eng = UNetEngine(local_rank)
     eng.load_state_dict(sd)
+
+    if args.workload != "typicality":
+        return side_workload(args, eng, dev)
 
     n_img = args.images
     x, eps, t, c = synth.synth_inputs(n_img * world, N_DRAWS, LAT, LAT)
@@ -121,7 +126,7 @@ def main():
                        "parallelism": f"image-sharded x{world}, one all-gather of T(x|c)"},
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv3x3/1x1/linear)",
                          "achieved": round(ig_tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ig_tf / PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(ig_tf / PEAK_TFLOPS, 4), "traffic": hbm_traffic_per_launch(),
                          "launches": prof["igemm_launches"], "kernel_ms_total": round(prof["igemm_ms"], 3),
                          "whole_path_tflops": round(value / world * per_img * FLOP_PER_FORWARD_64 / 1e12, 2),
                          "whole_path_frac": round(value / world * per_img * FLOP_PER_FORWARD_64 / 1e12 / PEAK_TFLOPS, 4),
@@ -133,6 +138,63 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def hbm_traffic_per_launch():
+    """HBM bytes per igemm launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per
+    the gfx950 correction, + WRITE_SIZE); rocprofv3 cannot run inside this process, so the number is
+    the recorded one for this kernel build, or None when no record exists."""
+    path = os.path.join(ROOT, "profiles", "r01_v4_hbm_traffic.json")
+    try:
+        return round(json.load(open(path))["kernels"]["igemm_kernel"]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
+def side_workload(args, eng, dev):
+    """BASELINE configs[3] (DIFT-161 tap, batch 64) and configs[4] (1024 px per-pixel heat-map)."""
+    from diff_mining_amd import synth
+    if args.workload == "dift":
+        n_lat, ens, lat = 8, 8, 64
+        x, eps, _, c = synth.synth_inputs(n_lat, ens, lat, lat)
+        xt = torch.from_numpy(x).float().to(dev).repeat_interleave(ens, 0)
+        et = torch.from_numpy(eps).float().to(dev).repeat(n_lat, 1, 1, 1)
+        a = 0.81210744                                          # acp[161]
+        noisy = ((a ** 0.5) * xt + ((1 - a) ** 0.5) * et).half()
+        eng.set_prompts(torch.from_numpy(c[:1]).to(dev))
+        slots = torch.zeros(n_lat * ens, dtype=torch.int32, device=dev)
+        tt = torch.tensor(161, device=dev)
+
+        def step():
+            return eng.dift(noisy, tt, slots, 1, ens)[1]
+        units, name, flop = n_lat, "DIFT-161 images/s (ensemble 8, tap up_blocks[1], batch 64 @64x64 latent)", 438.79e9 * ens
+    else:
+        lat = 128
+        x, eps, t, c = synth.synth_inputs(1, N_DRAWS, lat, lat)
+        xd, ed, td, cd = (torch.from_numpy(a).to(dev) for a in (x, eps, t, c))
+        eng.set_prompts(cd)
+        eb, tb = ed.repeat(N_COND, 1, 1, 1), td.repeat(N_COND)
+        slots = torch.arange(N_COND, dtype=torch.int32, device=dev).repeat_interleave(N_DRAWS)
+
+        def step():
+            loss = eng.score(xd, eb, tb, slots)
+            grid = loss.view(N_COND, N_DRAWS, 4, lat, lat).transpose(0, 1).contiguous()
+            return eng.reduce_typicality(grid)[0]
+        units, name, flop = 1, "X-ray 1024x1024 per-pixel typicality heat-maps/s (latent 128x128, 10 t x 2 prompts)", 4674.01e9 * 20
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    val = units * args.steps / dt
+    print(json.dumps({"metric": name, "value": round(val, 4), "unit": "images/s", "n_gpus": 1, "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": "f16",
+                      "data": "synthetic", "whole_path_tflops": round(val * flop / 1e12, 2),
+                      "whole_path_frac": round(val * flop / 1e12 / PEAK_TFLOPS, 4),
+                      "out_shape": list(out.shape), "memory": eng.memory()}), flush=True)
 
 
 def cpu_baseline(sd):
