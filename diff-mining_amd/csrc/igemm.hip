@@ -22,6 +22,7 @@
 // 0.93x, 256x160 tiles (2 or 3 LDS stages, counted vmcnt, register-double-buffered fragments,
 // horizontal tap reuse for 3x3) 0.80-0.95x, direct fragment stores 0.85x on the wide short-K linears.
 #include "dm_kernels.h"
+#include <cstdlib>
 
 namespace dm {
 
@@ -311,8 +312,25 @@ static hipError_t launch_t(const IGemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t launch_igemm_big(const IGemmParams& p, hipStream_t s);     // igemm_big.hip (256 x 320 tile)
+
+// Shape -> tile choice (measured on MI355X at the bench batch, tools/bench_ops.py): the 256x320 tile
+// pays on the k >= 640 linears, on the >= 640-channel / concat 3x3 convs and on the wide GEGLU
+// projections (+8..25 %) when the launch still has >= 2 tiles per CU; 128x320 wins elsewhere.
+static bool use_big(const IGemmParams& p) {
+    static int force = -2;
+    if (force == -2) { const char* e = getenv("DM_IGEMM_BIG"); force = e ? atoi(e) : -1; }
+    if (p.Cout % 320 != 0) return false;
+    const long long tiles = (long long)((p.M + 255) / 256) * (p.Cout / 320);
+    if (tiles < 1024) return false;
+    if (force >= 0) return force != 0;
+    if (p.mode == IG_DENSE) return p.Cin >= 640 || p.Cout >= 2560;
+    return p.Cin >= 640;
+}
+
 hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
     if (p.Cout % 160 != 0 || p.Cin % BK != 0 || p.C1 % BK != 0 || p.M <= 0) return hipErrorInvalidValue;
+    if (use_big(p)) return launch_igemm_big(p, s);
     return (p.Cout % 320 == 0) ? launch_t<4>(p, s) : launch_t<2>(p, s);
 }
 
