@@ -660,7 +660,7 @@ int max_chunk(int h, int w) {
 // ================================================================================================
 extern "C" {
 
-const char* dm_version(void) { return "dm_engine 0.1 (gfx950; igemm 128x160x64 mfma_f32_16x16x32_f16)"; }
+const char* dm_version(void) { return "dm_engine 0.1 (gfx950; igemm 128x320 / 256x320 x64 mfma_f32_16x16x32_f16, LDS-DMA)"; }
 
 int dm_scheduler_alphas_cumprod(int n, float beta_start, float beta_end, float* out) {
     if (n < 2 || !out) return 1;

@@ -39,6 +39,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         raise EngineError(
             f"{p} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
             "The typicality engine has no CPU / PyTorch fallback.")
+    # PyTorch-ROCm ships its own libamdhip64; importing torch first makes this library bind to that
+    # same HIP runtime (two runtimes in one process cannot see each other's device context).
+    import torch  # noqa: F401
     lib = C.CDLL(p)
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     lib.dm_version.restype = C.c_char_p

@@ -85,6 +85,23 @@ def test_unet_and_loss_vs_oracle(engine, sd15_weights_torch, h, w, n_draws):
     assert abs(T - T_ref) <= 2e-3 * ref_loss.mean().item()
 
 
+def test_baseline_shape_vs_oracle(engine, sd15_weights_torch):
+    """BASELINE configs[1] geometry (512 px -> 64x64 latent), 1 draw x 2 prompts, against the oracle.
+    Exercises the 256x320 igemm tiles and the 4096-token attention that the small cases do not."""
+    x, eps, t, c = _inputs(64, 64, 1)
+    nb, tb, cc, slots = _tile(eps, t, c)
+    engine.set_prompts(c)
+    loss = engine.score(x, nb, tb, slots).cpu()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = R.compute_loss(sd15_weights_torch, x, nb, tb, cc, autocast=True)
+    rl = U.rel_l2(loss, ref)
+    T = R.typicality_scalar(loss.view(2, 1, 4, 64, 64).transpose(0, 1)).item()
+    T_ref = R.typicality_scalar(ref.view(2, 1, 4, 64, 64).transpose(0, 1)).item()
+    print(f"[64x64] loss rel-L2 {rl:.2e}; T(x|c) engine {T:.5f} oracle {T_ref:.5f}; mean loss {ref.mean():.4f}")
+    assert rl < 6e-3, rl
+    assert abs(T - T_ref) <= 2e-3 * ref.mean().item()
+
+
 def test_golden_fixture(engine):
     """Committed golden vectors (tests/golden, produced by tests/make_golden.py from the oracle)."""
     path = os.path.join(GOLDEN, "score_8x8.npz")
