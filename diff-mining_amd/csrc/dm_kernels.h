@@ -73,4 +73,9 @@ hipError_t launch_ensemble_mean(const f16* X, int groups, int ens, int HW, int C
 hipError_t launch_typicality(const void* loss, int is_f16, int n_draws, int n_cond, int HW,
                              float* map, float* scalar, hipStream_t s);
 
+// image-space reduction of the latent typicality map: bilinear (align_corners=False) to (H, W), then
+// AvgPool2d((kx, ky), stride 1); tmp [H][W-ky+1], out [H-kx+1][W-ky+1] fp32
+hipError_t launch_typicality_image(const float* map, int h, int w, int H, int W, int kx, int ky, float* tmp,
+                                   float* out, hipStream_t s);
+
 }  // namespace dm

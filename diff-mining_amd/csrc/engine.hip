@@ -959,6 +959,19 @@ int dm_reduce_typicality(dm_engine* e, const void* loss_dev, int loss_is_f16, in
     return 0;
 }
 
+int dm_typicality_image(dm_engine* e, const void* loss_dev, int loss_is_f16, int n_draws, int n_cond, int h, int w,
+                        int img_h, int img_w, int kx, int ky, void* work_dev, void* out_dev, void* stream) {
+    if (!e) return 1;
+    if (!loss_dev || !work_dev || !out_dev) DM_FAIL(e, "dm_typicality_image: null argument");
+    if (kx < 1 || ky < 1 || kx > img_h || ky > img_w) DM_FAIL(e, "dm_typicality_image: bad window %dx%d for %dx%d", kx, ky, img_h, img_w);
+    DM_HIP(e, hipSetDevice(e->device));
+    float* map = (float*)work_dev;
+    float* tmp = map + (size_t)h * w;
+    DM_HIP(e, launch_typicality(loss_dev, loss_is_f16, n_draws, n_cond, h * w, map, nullptr, (hipStream_t)stream));
+    DM_HIP(e, launch_typicality_image(map, h, w, img_h, img_w, kx, ky, tmp, (float*)out_dev, (hipStream_t)stream));
+    return 0;
+}
+
 int dm_prof_enable(dm_engine* e, int on) {
     if (!e) return 1;
     e->prof = on != 0;

@@ -195,6 +195,46 @@ __global__ void typicality_map_kernel(const T* __restrict__ L, int n_draws, int 
     map[p] = acc / (float)n_draws;
 }
 
+// Consumers' image-space reduction (cluster.py:125-137 `load_typicality`, xray/compute.py:210-218):
+//   U = bilinear(D, (H, W), align_corners=False)  of the latent map D = mean_N(mean_C L_null - mean_C L_c)
+//   out = AvgPool2d((kx, ky), stride 1)(U)                     (linear, so it commutes with the means)
+// as two separable box-sum passes; pass 1 evaluates the bilinear sample on the fly.
+__device__ __forceinline__ float bilinear_at(const float* __restrict__ D, int h, int w, float sy, float sx, int y, int x) {
+    float fy = sy * ((float)y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+    float fx = sx * ((float)x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = y0 < h - 1 ? y0 : h - 1; x0 = x0 < w - 1 ? x0 : w - 1;
+    const int y1 = y0 + 1 < h ? y0 + 1 : h - 1, x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float top = D[y0 * w + x0] * (1.f - lx) + D[y0 * w + x1] * lx;
+    const float bot = D[y1 * w + x0] * (1.f - lx) + D[y1 * w + x1] * lx;
+    return top * (1.f - ly) + bot * ly;
+}
+
+// tmp[y][x] = sum_{dx < ky} U[y][x + dx],  y in [0,H), x in [0, W - ky + 1)
+__global__ void upsample_rowsum_kernel(const float* __restrict__ D, int h, int w, int H, int W, int ky,
+                                       float* __restrict__ tmp) {
+    const int OWd = W - ky + 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * OWd) return;
+    const int y = i / OWd, x = i - y * OWd;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    float acc = 0.f;
+    for (int dx = 0; dx < ky; ++dx) acc += bilinear_at(D, h, w, sy, sx, y, x + dx);
+    tmp[i] = acc;
+}
+
+// out[y][x] = (1/(kx*ky)) sum_{dy < kx} tmp[y + dy][x]
+__global__ void colsum_kernel(const float* __restrict__ tmp, int H, int OWd, int kx, float inv, float* __restrict__ out) {
+    const int OHd = H - kx + 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= OHd * OWd) return;
+    const int y = i / OWd, x = i - y * OWd;
+    float acc = 0.f;
+    for (int dy = 0; dy < kx; ++dy) acc += tmp[(y + dy) * OWd + x];
+    out[i] = acc * inv;
+}
+
 __global__ void mean_reduce_kernel(const float* __restrict__ map, int n, float* __restrict__ out) {
     __shared__ double sh[256];
     double s = 0.0;
@@ -257,6 +297,16 @@ hipError_t launch_typicality(const void* loss, int is_f16, int n_draws, int n_co
         hipLaunchKernelGGL(typicality_map_kernel<float>, dim3((HW + 255) / 256), dim3(256), 0, s,
                            (const float*)loss, n_draws, n_cond, HW, map);
     if (scalar) hipLaunchKernelGGL(mean_reduce_kernel, dim3(1), dim3(256), 0, s, map, HW, scalar);
+    return hipGetLastError();
+}
+
+hipError_t launch_typicality_image(const float* map, int h, int w, int H, int W, int kx, int ky, float* tmp,
+                                   float* out, hipStream_t s) {
+    const int OWd = W - ky + 1, OHd = H - kx + 1;
+    if (OWd <= 0 || OHd <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(upsample_rowsum_kernel, dim3((H * OWd + 255) / 256), dim3(256), 0, s, map, h, w, H, W, ky, tmp);
+    hipLaunchKernelGGL(colsum_kernel, dim3((OHd * OWd + 255) / 256), dim3(256), 0, s, tmp, H, OWd, kx,
+                       1.0f / ((float)kx * (float)ky), out);
     return hipGetLastError();
 }
 

@@ -20,7 +20,7 @@ SYMBOLS = [
     "dm_version", "dm_scheduler_alphas_cumprod", "dm_timestep_sinusoid", "dm_engine_create",
     "dm_engine_destroy", "dm_last_error", "dm_engine_load_weight", "dm_engine_finalize",
     "dm_engine_set_prompts", "dm_score", "dm_unet_forward", "dm_dift", "dm_dift_shape",
-    "dm_reduce_typicality", "dm_prof_enable", "dm_prof_read", "dm_engine_memory",
+    "dm_reduce_typicality", "dm_typicality_image", "dm_prof_enable", "dm_prof_read", "dm_engine_memory",
     "dm_op_igemm", "dm_op_attention", "dm_op_groupnorm", "dm_op_layernorm",
 ]
 
@@ -60,6 +60,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_dift.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.dm_dift_shape.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.dm_reduce_typicality.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.dm_typicality_image.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.dm_prof_enable.argtypes = [vp, i32]
     lib.dm_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64),
                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
@@ -256,6 +257,23 @@ class UNetEngine:
                                                   C.c_void_p(m.data_ptr()), C.c_void_p(sc.data_ptr()), self._stream()),
                     "dm_reduce_typicality")
         return m, sc
+
+    def typicality_image(self, grid, image_size, kx: int = 1, ky: int = 1):
+        """`Cluster.load_typicality` (cluster.py:125-137) on the GPU: grid [N,n_cond,4,h,w] ->
+        [H-kx+1, W-ky+1] fp32 = mean_N(pool(interp(mean_C L_null)) - pool(interp(mean_C L_c)));
+        image_size = (H, W).  kx = ky = 1 is the X-ray per-pixel map (xray/compute.py:210-218)."""
+        torch = self._torch
+        grid = grid.to(self.device).contiguous()
+        assert grid.dim() == 5 and grid.shape[2] == 4 and grid.dtype in (torch.float16, torch.float32)
+        N, nc, _, h, w = grid.shape
+        H, W = int(image_size[0]), int(image_size[1])
+        work = torch.empty(h * w + H * W, dtype=torch.float32, device=self.device)
+        out = torch.empty(H - kx + 1, W - ky + 1, dtype=torch.float32, device=self.device)
+        self._check(self.lib.dm_typicality_image(self._h, C.c_void_p(grid.data_ptr()),
+                                                 1 if grid.dtype == torch.float16 else 0, N, nc, h, w, H, W, kx, ky,
+                                                 C.c_void_p(work.data_ptr()), C.c_void_p(out.data_ptr()), self._stream()),
+                    "dm_typicality_image")
+        return out
 
     # -- measurement -----------------------------------------------------------------------------
     def prof_enable(self, on: bool = True):

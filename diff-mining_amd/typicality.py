@@ -138,6 +138,16 @@ class TypicalityScorer:
     def typicality_scalar(self, grid):
         return self.engine.reduce_typicality(grid)[1]
 
+    def load_typicality(self, grid, image_size, kx: int, ky: int):
+        """`Cluster.load_typicality` (cluster.py:125-137) from the grid instead of the .npy path:
+        bilinear resize to image_size = (H, W), kx x ky stride-1 average pooling per condition,
+        -(pool(c) - pool(null)), mean over N -> [H-kx+1, W-ky+1] fp32 on the GPU."""
+        return self.engine.typicality_image(grid, image_size, kx, ky)
+
+    def pixel_heatmap(self, grid, image_size):
+        """`Typicallity.compute` dm_pixel (xray/compute.py:210-218): per-pixel E_N[L_null - L_c] at image size."""
+        return self.engine.typicality_image(grid, image_size, 1, 1)
+
 
 def shard_indices(n_items: int, rank: int, world: int) -> Sequence[int]:
     """Image-major sharding `subs[i::sub_split]` of compute.py:339."""

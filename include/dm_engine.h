@@ -102,6 +102,15 @@ int dm_dift_shape(int h, int w, int up_ft_index, int* c_out, int* h_out, int* w_
 int dm_reduce_typicality(dm_engine* e, const void* loss_dev, int loss_is_f16, int n_draws, int n_cond,
                          int h, int w, void* map_out_dev, void* scalar_out_dev, void* stream);
 
+/* Image-space form of the same reduction, as `Cluster.load_typicality` (cluster.py:125-137) and
+ * `Typicallity.compute` (xray/compute.py:210-218) produce it: the latent map is resized with
+ * bilinear interpolation (align_corners=False) to the image size (img_h, img_w) and averaged over
+ * every kx x ky window (AvgPool2d((kx, ky), stride 1); kx = ky = 1 gives the per-pixel X-ray map).
+ * out_dev [img_h-kx+1, img_w-ky+1] fp32; work_dev: scratch of (h*w + img_h*img_w) fp32. */
+int dm_typicality_image(dm_engine* e, const void* loss_dev, int loss_is_f16, int n_draws, int n_cond,
+                        int h, int w, int img_h, int img_w, int kx, int ky, void* work_dev, void* out_dev,
+                        void* stream);
+
 /* Profiling support for bench.py: when enabled, every launch of the dominant (implicit-GEMM)
  * kernel is bracketed by hipEvents on the launch stream.  dm_prof_read synchronises and returns
  * the accumulated kernel milliseconds, launch count and algorithmic FLOPs since the last reset. */

@@ -327,6 +327,21 @@ def typicality_map(grid: torch.Tensor) -> torch.Tensor:
     return (dm[:, -1] - dm[:, 0]).mean(0)
 
 
+def load_typicality(grid: torch.Tensor, image_size, kx: int, ky: int) -> torch.Tensor:
+    """`Cluster.load_typicality` (cluster.py:125-137) + `pool` (utils.py:74-80), in the reference's
+    own order of operations: mean over C, bilinear resize to (H, W), AvgPool2d((kx, ky), stride 1) per
+    condition, -(pool(c) - pool(null)), mean over N.  grid [N,2,4,h,w] -> [H-kx+1, W-ky+1]."""
+    dm = grid.float().mean(dim=2)
+    dm = F.interpolate(dm, tuple(image_size), mode="bilinear")
+
+    def pool(x):
+        if kx != 1 and ky != 1:
+            return torch.nn.AvgPool2d((kx, ky), stride=(1, 1), padding=0)(x)
+        return x
+    d = pool(dm[:, 0].unsqueeze(1)) - pool(dm[:, 1].unsqueeze(1))
+    return -d.squeeze(1).mean(dim=0)
+
+
 def typicality_scalar(grid: torch.Tensor) -> torch.Tensor:
     """T(x|c) = mean over pixels of `typicality_map` (intent of cluster.py:517-531)."""
     return typicality_map(grid).mean()

@@ -179,6 +179,51 @@ def test_surface_compute_losses_and_reductions(engine, sd15_weights_torch):
         assert back.dtype == np.float16 and back.shape == (3, 2, 4, 8, 8)
 
 
+@pytest.mark.parametrize("h,w,H,W,k", [(8, 8, 64, 64, 5), (32, 40, 256, 320, 50), (64, 64, 512, 512, 64), (16, 16, 128, 128, 1)])
+def test_image_space_typicality_vs_reference_order(engine, h, w, H, W, k):
+    """dm_typicality_image vs the reference's order of operations (cluster.py:125-137) on CPU."""
+    g = torch.Generator().manual_seed(h * 1000 + k)
+    grid = (torch.rand(3, 2, 4, h, w, generator=g) * 2).half()
+    from diff_mining_amd.typicality import TypicalityScorer
+    sc = TypicalityScorer(engine)
+    got = sc.load_typicality(grid, (H, W), k, k).cpu()
+    ref = R.load_typicality(grid, (H, W), k, k)
+    assert got.shape == ref.shape == (H - k + 1, W - k + 1)
+    torch.testing.assert_close(got, ref, atol=2e-5, rtol=1e-4)
+    if k == 1:
+        torch.testing.assert_close(sc.pixel_heatmap(grid, (H, W)).cpu(), ref, atol=2e-5, rtol=1e-4)
+
+
+def test_safetensors_checkpoint_round_trip(engine, sd15_weights_f16, tmp_path):
+    """`unet/diffusion_pytorch_model.safetensors` (what the reference's --export-only writes,
+    finetuning/base.py:245-250) loads into a second engine and scores bit-identically."""
+    from safetensors.numpy import save_file
+    from diff_mining_amd.engine import UNetEngine, EngineError
+    path = str(tmp_path / "diffusion_pytorch_model.safetensors")
+    save_file(sd15_weights_f16, path)
+    e2 = UNetEngine(0)
+    e2.load_safetensors(path)
+    x, eps, t, c = _inputs(8, 8, 1)
+    nb, tb, cc, slots = _tile(eps, t, c)
+    engine.set_prompts(c)
+    e2.set_prompts(c)
+    assert torch.equal(engine.score(x, nb, tb, slots), e2.score(x, nb, tb, slots))
+    e2.close()
+    # a checkpoint with a missing / misshapen tensor is rejected with a named error
+    bad = dict(sd15_weights_f16)
+    bad.pop("mid_block.resnets.0.conv1.weight")
+    e3 = UNetEngine(0)
+    with pytest.raises(EngineError, match="mid_block.resnets.0.conv1.weight"):
+        e3.load_state_dict(bad)
+    e3.close()
+    bad = dict(sd15_weights_f16)
+    bad["conv_in.weight"] = bad["conv_in.weight"][:, :3]
+    e4 = UNetEngine(0)
+    with pytest.raises(EngineError, match="conv_in.weight"):
+        e4.load_state_dict(bad)
+    e4.close()
+
+
 def test_unet_callable_drop_in(engine, sd15_weights_torch):
     from diff_mining_amd.typicality import UNetCallable
     unet = UNetCallable(engine)
