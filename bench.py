@@ -124,7 +124,7 @@ def main():
                                    f"batch {n_img} images/GPU = {n_img * per_img} U-Net forwards/step/GPU, synthetic weights",
                        "images_per_gpu_per_step": n_img, "unet_forwards_per_image": per_img,
                        "parallelism": f"image-sharded x{world}, one all-gather of T(x|c)"},
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv3x3/1x1/linear)",
+            "roofline": {"bound": "mfma", "kernel": "igemm_kernel + igemm_big_kernel (implicit-GEMM conv3x3/1x1/linear, 128x320 and 256x320 tiles)",
                          "achieved": round(ig_tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ig_tf / PEAK_TFLOPS, 4), "traffic": hbm_traffic_per_launch(),
                          "launches": prof["igemm_launches"], "kernel_ms_total": round(prof["igemm_ms"], 3),
@@ -144,9 +144,9 @@ def hbm_traffic_per_launch():
     """HBM bytes per igemm launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per
     the gfx950 correction, + WRITE_SIZE); rocprofv3 cannot run inside this process, so the number is
     the recorded one for this kernel build, or None when no record exists."""
-    path = os.path.join(ROOT, "profiles", "r01_v4_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_final_pmc.json")
     try:
-        return round(json.load(open(path))["kernels"]["igemm_kernel"]["hbm_bytes_per_launch"])
+        return round(json.load(open(path))["kernels"]["igemm_kernel+igemm_big_kernel"]["hbm_bytes_per_launch"])
     except Exception:
         return None
 
