@@ -16,7 +16,11 @@
 //   * head_dim padding (40 -> 64 for the QK^T k extent, 40 -> 48 PV rows) is done by pointing the
 //     out-of-range lanes at a zeroed LDS slot — never in HBM;
 //   * lazy rescale: the running max is only advanced (and O, l rescaled) when some row of the wave
-//     grew by more than 2^8, so the steady state has no O-wide multiply.
+//     grew by more than 2^8, so the steady state has no O-wide multiply;
+//   * the softmax is VALU bound at head_dim 40 (4-cycle VALU, one exp per score), so two of its
+//     terms are moved into the MFMAs' idle padding: the running max rides in two extra k columns of
+//     the padded QK^T operand (the MFMA returns sc*q.k - m), and the denominator accumulates in a
+//     padded, all-ones row of V^T.  Steady state per score: exp2 + max + convert (D = 40: +11 %).
 // Measured alternatives (r01): register staging + transposing ds_write_b16 0.55x, 128-key staged
 // tiles 0.95x, 64 queries/wave (occupancy 1) 0.8x, forcing 4 waves/SIMD (spills) 0.45x.
 #include "dm_kernels.h"
@@ -48,6 +52,16 @@ void attn_kernel(AttnParams p) {
     constexpr int TBYTES = KT * RS;               // one K (or V) tile
     constexpr int ZREL = 2 * TBYTES;               // zeroed 64-byte slot at the end of each stage
     constexpr int STAGE = 2 * TBYTES + 64;
+    // FOLD : the padded part of the QK^T k extent carries two extra columns, K' = [k, 1, 1] and
+    //        Q' = [sc*q, -m_hi, -m_lo], so the MFMA itself delivers sc*(q.k) - m_run (fp32 accumulate;
+    //        m split in two fp16 halves) and the steady-state softmax is exp2 + max + convert only.
+    // LONES: one padded PV row of V^T is all ones, so the softmax denominator accumulates in the PV
+    //        accumulator (row d = D) instead of with VALU adds.
+    constexpr bool FOLD = (DP - D >= 8);            // D = 40, 80
+    constexpr bool LONES = (DV - D >= 4);           // D = 40
+    constexpr int SX = (D / 8) / 4, LGX = (D / 8) % 4;          // fragment (s, lane group) of chunk d = D..D+7
+    constexpr int EX = D / 16, VLX = (D % 16) / 4;              // PV fragment / lane sub-group of row d = D
+    constexpr int KONES = ZREL + 16, VONES = ZREL + 32;        // constant slots inside the 64-byte area
     constexpr int NI = 2 * NCH * (KT / 64);       // glds instructions per KV tile (K then V)
     constexpr int MI = (NI + 3) / 4;               // per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -67,7 +81,13 @@ void attn_kernel(AttnParams p) {
     const f16* Vb = p.V + (size_t)kvb * p.bsv + h * D;
     f16* Ob = p.O + (size_t)b * p.bso + h * D;
 
-    if (tid < 32) *reinterpret_cast<unsigned*>(smem + (tid >> 4) * STAGE + ZREL + (tid & 15) * 4) = 0u;
+    if (tid < 32) {          // per stage: 16 B zeros | 16 B {1,1,0..} (K ones columns) | 8 B {1,0,0,0} (V ones row) | zeros
+        const int w = tid & 15;
+        unsigned v = 0u;
+        if (w == 4) v = 0x3C003C00u;                 // halfs {1, 1}
+        if (w == 8) v = 0x00003C00u;                 // halfs {1, 0}
+        *reinterpret_cast<unsigned*>(smem + (tid >> 4) * STAGE + ZREL + w * 4) = v;
+    }
 
     // ---- Q fragments ----------------------------------------------------------------------------
     half8 qf[QF][KS];
@@ -81,6 +101,15 @@ void attn_kernel(AttnParams p) {
             if (d < D) qf[jq][s] = *reinterpret_cast<const half8*>(Qb + (size_t)q * p.ldq + d);
             else qf[jq][s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
         }
+    }
+    const float sc = p.scale * 1.44269504088896340736f;   // scores live in the log2 domain
+    if (FOLD) {                                              // Q' = fp16(sc * q)
+#pragma unroll
+        for (int jq = 0; jq < QF; ++jq)
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) qf[jq][s][k] = (f16)((float)qf[jq][s][k] * sc);
     }
 
     // ---- glds bookkeeping: instruction j = wid + 4*i covers elements idx = (j % NCH ... ) ----------
@@ -114,17 +143,19 @@ void attn_kernel(AttnParams p) {
     // ---- LDS read offsets (tile-relative; lanes beyond head_dim read the zero slot) ---------------
     int koff[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) koff[s] = (32 * s + 8 * lg < D) ? (l15 * RS + 64 * s + 16 * lg) : ZREL;
+    for (int s = 0; s < KS; ++s)
+        koff[s] = (32 * s + 8 * lg < D) ? (l15 * RS + 64 * s + 16 * lg) : ((FOLD && s == SX && lg == LGX) ? KONES : ZREL);
     int voff[EF];
 #pragma unroll
     for (int e = 0; e < EF; ++e)
-        voff[e] = (16 * e + 4 * (l15 & 3) < D) ? (TBYTES + (4 * lg + (l15 >> 2)) * RS + 32 * e + 8 * (l15 & 3)) : ZREL;
+        voff[e] = (16 * e + 4 * (l15 & 3) < D) ? (TBYTES + (4 * lg + (l15 >> 2)) * RS + 32 * e + 8 * (l15 & 3))
+                                                : ((LONES && e == EX && (l15 & 3) == VLX) ? VONES : ZREL);
     // a lane either reads real rows (offset advances with the fragment) or the zero slot (it does not)
     int kstep[KS], vstep[EF];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) kstep[s] = (koff[s] == ZREL) ? 0 : 16 * RS;
+    for (int s = 0; s < KS; ++s) kstep[s] = (koff[s] >= ZREL) ? 0 : 16 * RS;
 #pragma unroll
-    for (int e = 0; e < EF; ++e) vstep[e] = (voff[e] == ZREL) ? 0 : 16 * RS;
+    for (int e = 0; e < EF; ++e) vstep[e] = (voff[e] >= ZREL) ? 0 : 16 * RS;
 
     floatx4 oacc[EF][QF];
 #pragma unroll
@@ -133,10 +164,9 @@ void attn_kernel(AttnParams p) {
         for (int jq = 0; jq < QF; ++jq) oacc[e][jq] = floatx4{0, 0, 0, 0};
     float m_run[QF], l_run[QF];
 #pragma unroll
-    for (int jq = 0; jq < QF; ++jq) { m_run[jq] = -INFINITY; l_run[jq] = 0.f; }
-    const float sc = p.scale * 1.44269504088896340736f;
+    for (int jq = 0; jq < QF; ++jq) { m_run[jq] = FOLD ? 0.f : -INFINITY; l_run[jq] = 0.f; }
 
-    auto compute = [&](int buf, int k0, bool tail) __attribute__((always_inline)) {
+    auto compute = [&](int buf, int k0, bool tail, bool first) __attribute__((always_inline)) {
         const char* kt = smem + buf * STAGE;
         floatx4 sacc[4][QF];
 #pragma unroll
@@ -172,26 +202,62 @@ void attn_kernel(AttnParams p) {
             mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32));
             // lazy rescale: keep the stale running max while no row of the wave grew by more than
             // 2^RESCALE_THR; P is then bounded by 2^RESCALE_THR (exact in fp32, fp16 keeps 11 bits).
-            const float mxs = mx * sc;
-            if (__builtin_amdgcn_ballot_w64(mxs > m_run[jq] + RESCALE_THR) != 0ull) {
-                const float m_new = __builtin_fmaxf(m_run[jq], mxs);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[jq] - m_new);
-                m_run[jq] = m_new;
-                l_run[jq] *= alpha;
+            if constexpr (FOLD) {
+                // sacc already holds sc*(q.k) - m_run (first tile: m_run = 0)
+                float ps = 0.f;
+                if (first || __builtin_amdgcn_ballot_w64(mx > RESCALE_THR) != 0ull) {
+                    const float delta = first ? mx : __builtin_fmaxf(mx, 0.f);    // the running max only grows
+                    const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+                    m_run[jq] += delta;
+                    if (!LONES) l_run[jq] *= alpha;
 #pragma unroll
-                for (int e = 0; e < EF; ++e) oacc[e][jq] *= alpha;
-            }
-            const float m_use = m_run[jq];
-            float ps = 0.f;
+                    for (int e = 0; e < EF; ++e) oacc[e][jq] *= alpha;
+                    if (lg == LGX) {                                          // refresh the -m columns of Q'
+                        const f16 mh = (f16)m_run[jq];
+                        const f16 ml = (f16)(m_run[jq] - (float)mh);
+                        qf[jq][SX][0] = -mh; qf[jq][SX][1] = -ml;
+                    }
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+                    for (int f = 0; f < 4; ++f)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[f][jq][r], sc, -m_use));
-                    ps += pv;
-                    pb[jq][f >> 1][(f & 1) * 4 + r] = (f16)pv;
+                        for (int r = 0; r < 4; ++r) {
+                            const float pv = __builtin_amdgcn_exp2f(sacc[f][jq][r] - delta);
+                            if (!LONES) ps += pv;
+                            pb[jq][f >> 1][(f & 1) * 4 + r] = (f16)pv;
+                        }
+                } else {                                                      // steady state: exp2 and convert only
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pv = __builtin_amdgcn_exp2f(sacc[f][jq][r]);
+                            if (!LONES) ps += pv;
+                            pb[jq][f >> 1][(f & 1) * 4 + r] = (f16)pv;
+                        }
                 }
-            l_run[jq] += ps;
+                if (!LONES) l_run[jq] += ps;
+            } else {
+                const float mxs = mx * sc;
+                if (__builtin_amdgcn_ballot_w64(mxs > m_run[jq] + RESCALE_THR) != 0ull) {
+                    const float m_new = __builtin_fmaxf(m_run[jq], mxs);
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[jq] - m_new);
+                    m_run[jq] = m_new;
+                    l_run[jq] *= alpha;
+#pragma unroll
+                    for (int e = 0; e < EF; ++e) oacc[e][jq] *= alpha;
+                }
+                const float m_use = m_run[jq];
+                float ps = 0.f;
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[f][jq][r], sc, -m_use));
+                        ps += pv;
+                        pb[jq][f >> 1][(f & 1) * 4 + r] = (f16)pv;
+                    }
+                l_run[jq] += ps;
+            }
         }
         // PV: the transpose reads are issued through inline asm — the builtin form makes hipcc drain
         // vmcnt(0) (the in-flight LDS-DMA of the NEXT tile) before every LDS transpose read, which
@@ -230,7 +296,7 @@ void attn_kernel(AttnParams p) {
 
     const int ntiles = (p.Tk + KT - 1) / KT;
     auto compute_tile = [&](int cur, int k0) __attribute__((always_inline)) {
-        if (k0 + 64 > p.Tk) compute(cur, k0, true); else compute(cur, k0, false);
+        if (k0 + 64 > p.Tk) compute(cur, k0, true, k0 == 0); else compute(cur, k0, false, k0 == 0);
     };
     issue(0, 0);
     for (int t = 0; t < ntiles; ++t) {
@@ -243,9 +309,14 @@ void attn_kernel(AttnParams p) {
 
 #pragma unroll
     for (int jq = 0; jq < QF; ++jq) {
-        float l = l_run[jq];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        float l;
+        if constexpr (LONES) {
+            l = __shfl(oacc[EX][jq][0], (VLX << 4) | l15);      // row d = D of O^T lives in lane group VLX, r = 0
+        } else {
+            l = l_run[jq];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
         const float inv = 1.0f / l;
         const int q = q0 + 16 * jq + l15;
         if (q >= p.Tq) continue;
