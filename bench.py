@@ -75,17 +75,18 @@ def main():
     eng.set_prompts(c)
     # sample order per image: cond-major tiling of compute.py:150-152 (row k*N+i = draw i, cond k)
     per_img = N_DRAWS * N_COND
-    eps_b = eps.repeat(N_COND, 1, 1, 1).repeat(n_img, 1, 1, 1).contiguous()     # same draws for every image
-    t_b = t.repeat(N_COND).repeat(n_img).contiguous()
-    slots = torch.arange(N_COND, dtype=torch.int32, device=dev).repeat_interleave(N_DRAWS).repeat(n_img).contiguous()
-    x_index = torch.arange(n_img, dtype=torch.int32, device=dev).repeat_interleave(per_img).contiguous()
+    # the 80 distinct (image, draw) pairs of the step; each is scored under the N_COND prompts
+    # (D.compute_losses tiles exactly this, compute.py:150-152: same draws for every image, seed 42)
+    eps_u = eps.repeat(n_img, 1, 1, 1).contiguous()
+    t_u = t.repeat(n_img).contiguous()
+    x_index = torch.arange(n_img, dtype=torch.int32, device=dev).repeat_interleave(N_DRAWS).contiguous()
     scores = torch.empty(n_img, dtype=torch.float32, device=dev)
 
     def step():
-        loss = eng.score(x, eps_b, t_b, slots, x_index=x_index)              # [n_img*20,4,64,64] fp32
-        grid = loss.view(n_img, N_COND, N_DRAWS, 4, LAT, LAT)
+        loss = eng.score_conds(x, eps_u, t_u, N_COND, x_index=x_index)       # [2*n_img*10,4,64,64] fp32, cond-major
+        grid = loss.view(N_COND, n_img, N_DRAWS, 4, LAT, LAT)
         for i in range(n_img):
-            g = grid[i].transpose(0, 1).contiguous()                          # [N,2,4,h,w]
+            g = grid[:, i].transpose(0, 1).contiguous()                       # [N,2,4,h,w]
             scores[i] = eng.reduce_typicality(g)[1][0]
         return gather_scores(scores, n_img * world, rank, world)
 

@@ -74,7 +74,7 @@ void attn_kernel(AttnParams p) {
     const int h = blockIdx.y;
     const int b = blockIdx.z;
     const int q0 = blockIdx.x * (64 * QF) + wid * (16 * QF);
-    const int kvb = p.kv_slot ? p.kv_slot[b] : b;
+    const int kvb = p.kv_slot ? p.kv_slot[b] : (p.slot_div > 0 ? b / p.slot_div : b);
 
     const f16* Qb = p.Q + (size_t)b * p.bsq + h * D;
     const f16* Kb = p.K + (size_t)kvb * p.bsk + h * D;

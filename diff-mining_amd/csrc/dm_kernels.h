@@ -35,6 +35,7 @@ struct AttnParams {
     int ldq, ldk, ldv, ldo;          // row strides in elements
     long long bsq, bsk, bsv, bso;    // batch strides in elements
     const int32_t* kv_slot;          // optional: K/V batch index per sample (prompt slot)
+    int slot_div;                    // if > 0 (and kv_slot == nullptr): K/V batch index = sample / slot_div
     int B, heads, Tq, Tk, D;
     float scale;
 };
@@ -63,9 +64,12 @@ hipError_t launch_im2col_in(const f16* x, const int32_t* x_index, const f16* eps
                             hipStream_t s);
 // conv_out 3x3 (C0 -> 4) on the normalised activations, fused eps-MSE (wavefront shuffle reduce).
 // loss [B,4,H,W] fp32 = (float(fp16(conv)) - float(eps))^2 ; if eps == nullptr writes pred fp16 NCHW.
+// sample b reads eps row (b % eps_rows) and writes output row (b / out_group) * out_stride + out_off + b % out_group
+// (identity when eps_rows = out_group = B, out_stride = out_off = 0).
 hipError_t launch_conv_out(const f16* Xn /* NHWC [B,H,W,C0] */, const f16* w /* [4][9*C0] k=(tap,c) */,
                            const f16* bias, const f16* eps, int B, int H, int W, int C0,
-                           float* loss, f16* pred, hipStream_t s);
+                           float* loss, f16* pred, int eps_rows, int out_group, int out_stride, int out_off,
+                           hipStream_t s);
 hipError_t launch_nhwc_to_nchw(const f16* X, int N, int HW, int C, f16* Y, hipStream_t s);
 // mean over groups of `ens` consecutive samples, NHWC fp16 -> NCHW fp32
 hipError_t launch_ensemble_mean(const f16* X, int groups, int ens, int HW, int C, float* Y, hipStream_t s);

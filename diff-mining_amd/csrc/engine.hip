@@ -451,13 +451,15 @@ struct Fwd {
         return 0;
     }
 
+    int slot_div = 0;       // shared-draw mode: prompt slot of sample b is b / slot_div (no slot array)
+
     int attention(const f16* Q, int ldq, long long bsq, const f16* K, const f16* V, int ldkv, long long bskv,
                   const int32_t* slots, int B, int Tq, int Tk, int C, f16* O) {
         AttnParams a;
         a.Q = Q; a.K = K; a.V = V; a.O = O;
         a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.ldo = C;
         a.bsq = bsq; a.bsk = bskv; a.bsv = bskv; a.bso = (long long)Tq * C;
-        a.kv_slot = slots; a.B = B; a.heads = HEADS; a.Tq = Tq; a.Tk = Tk; a.D = C / HEADS;
+        a.kv_slot = slots; a.slot_div = 0; a.B = B; a.heads = HEADS; a.Tq = Tq; a.Tk = Tk; a.D = C / HEADS;
         a.scale = 1.0f / sqrtf((float)a.D);
         DM_TRY(prof_begin(1, 4.0 * B * HEADS * (double)Tq * Tk * a.D));
         DM_HIP(e, launch_attention(a, s));
@@ -465,13 +467,14 @@ struct Fwd {
         return 0;
     }
 
-    int transformer(const TfmW& t, const Tensor& x, const int32_t* slots, Tensor* out) {
+    // Transformer2D, first half: GroupNorm, proj_in, LayerNorm, self-attention, to_out + residual.
+    // Nothing here depends on the prompt.
+    int transformer_pre(const TfmW& t, const Tensor& x, Tensor* t1) {
         const int C = t.c, T = x.H * x.W, B = x.N;
-        Tensor n, t0, ln, qkv, a, t1, q, t2, ff, t3;
+        Tensor n, t0, ln, qkv, a;
         DM_TRY(groupnorm(t.gn, x, nullptr, ATTN_GN_EPS, false, &n));
         DM_TRY(dense(t.proj_in, n, nullptr, nullptr, EPI_PLAIN, &t0));
         free(n);
-        // self attention
         DM_TRY(layernorm(t.ln1, t0, &ln));
         DM_TRY(dense(t.qkv, ln, nullptr, nullptr, EPI_PLAIN, &qkv));
         free(ln);
@@ -479,21 +482,35 @@ struct Fwd {
         if (!dry) DM_TRY(attention(qkv.p, 3 * C, (long long)T * 3 * C, qkv.p + C, qkv.p + 2 * C, 3 * C, (long long)T * 3 * C,
                                    nullptr, B, T, T, C, a.p));
         free(qkv);
-        DM_TRY(dense(t.o1, a, nullptr, &t0, EPI_PLAIN, &t1));
+        DM_TRY(dense(t.o1, a, nullptr, &t0, EPI_PLAIN, t1));
         free(a); free(t0);
-        // cross attention against the per-prompt K/V cache
+        return 0;
+    }
+    // second half: cross-attention against the per-prompt K/V cache, GEGLU feed-forward, proj_out + x.
+    // Consumes (frees) t1.
+    int transformer_post(const TfmW& t, const Tensor& x, Tensor& t1, const int32_t* slots, Tensor* out) {
+        const int C = t.c, T = x.H * x.W, B = x.N;
+        Tensor ln, a, q, t2, ff, t3;
         DM_TRY(layernorm(t.ln2, t1, &ln));
         DM_TRY(dense(t.q2, ln, nullptr, nullptr, EPI_PLAIN, &q));
         free(ln);
         DM_TRY(alloc(&a, B, x.H, x.W, C));
         if (!dry) {
             const f16* kv = e->kv_cache[t.layer];
-            DM_TRY(attention(q.p, C, (long long)T * C, kv, kv + C, 2 * C, (long long)CTX_LEN * 2 * C, slots, B, T, CTX_LEN, C, a.p));
+            AttnParams ap;
+            ap.Q = q.p; ap.K = kv; ap.V = kv + C; ap.O = a.p;
+            ap.ldq = C; ap.ldk = 2 * C; ap.ldv = 2 * C; ap.ldo = C;
+            ap.bsq = (long long)T * C; ap.bsk = (long long)CTX_LEN * 2 * C; ap.bsv = ap.bsk; ap.bso = (long long)T * C;
+            ap.kv_slot = slot_div > 0 ? nullptr : slots; ap.slot_div = slot_div;
+            ap.B = B; ap.heads = HEADS; ap.Tq = T; ap.Tk = CTX_LEN; ap.D = C / HEADS;
+            ap.scale = 1.0f / sqrtf((float)ap.D);
+            DM_TRY(prof_begin(1, 4.0 * B * HEADS * (double)T * CTX_LEN * ap.D));
+            DM_HIP(e, launch_attention(ap, s));
+            DM_TRY(prof_end());
         }
         free(q);
         DM_TRY(dense(t.o2, a, nullptr, &t1, EPI_PLAIN, &t2));
         free(a); free(t1);
-        // GEGLU feed-forward
         DM_TRY(layernorm(t.ln3, t2, &ln));
         DM_TRY(dense(t.ff1, ln, nullptr, nullptr, EPI_GEGLU, &ff));
         free(ln);
@@ -503,11 +520,28 @@ struct Fwd {
         free(t3);
         return 0;
     }
+    int transformer(const TfmW& t, const Tensor& x, const int32_t* slots, Tensor* out) {
+        Tensor t1;
+        DM_TRY(transformer_pre(t, x, &t1));
+        return transformer_post(t, x, t1, slots, out);
+    }
+    // n_cond stacked copies of a [U, ...] tensor: out[k*U + i] = in[i]
+    int replicate(const Tensor& in, int n_cond, Tensor* out) {
+        DM_TRY(alloc(out, in.N * n_cond, in.H, in.W, in.C));
+        if (!dry) {
+            const size_t bytes = (size_t)in.rows() * in.C * sizeof(f16);
+            for (int k = 0; k < n_cond; ++k)
+                DM_HIP(e, hipMemcpyAsync((char*)out->p + (size_t)k * bytes, in.p, bytes, hipMemcpyDeviceToDevice, s));
+        }
+        return 0;
+    }
 };
 
 struct FwdArgs {
     const f16* x; const int32_t* x_index; const f16* eps; const int64_t* t; const int32_t* slots;
     int B, H, W;
+    int n_cond = 1;           // > 1: shared-draw mode, B = n_cond * U; t / eps / x_index have U rows
+    int out_stride = 0, out_off = 0;   // loss row of sample (k, i) = k * out_stride + out_off + i
     bool add_noise;
     int up_ft_index;          // -1: full forward
     float* loss; f16* pred;   // full forward outputs (either may be null)
@@ -517,40 +551,67 @@ struct FwdArgs {
 int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
     Fwd F{e, s, dry};
     const int B = A.B;
+    const int NC = A.n_cond > 1 ? A.n_cond : 1;
+    const int U = B / NC;                 // distinct (x, t, eps) draws; every draw is scored under NC prompts
+    F.slot_div = (NC > 1) ? U : 0;
     // ---- time embedding: sinusoid row -> MLP -> SiLU -> all 22 time_emb_proj in one GEMM --------
-    Tensor te0, e1, e1s, emb, embs, tproj;
-    DM_TRY(F.alloc(&te0, 1, 1, B, BOC[0]));
-    if (!dry) DM_HIP(e, launch_time_gather(e->sin_table, A.t, B, BOC[0], te0.p, s));
+    Tensor te0, e1, e1s, emb, embs, tprojU, tproj;
+    DM_TRY(F.alloc(&te0, 1, 1, U, BOC[0]));
+    if (!dry) DM_HIP(e, launch_time_gather(e->sin_table, A.t, U, BOC[0], te0.p, s));
     DM_TRY(F.dense(e->time1, te0, nullptr, nullptr, EPI_PLAIN, &e1));
     F.free(te0);
-    DM_TRY(F.alloc(&e1s, 1, 1, B, TEMB));
-    if (!dry) DM_HIP(e, launch_silu(e1.p, e1s.p, (long long)B * TEMB, s));
+    DM_TRY(F.alloc(&e1s, 1, 1, U, TEMB));
+    if (!dry) DM_HIP(e, launch_silu(e1.p, e1s.p, (long long)U * TEMB, s));
     F.free(e1);
     DM_TRY(F.dense(e->time2, e1s, nullptr, nullptr, EPI_PLAIN, &emb));
     F.free(e1s);
-    DM_TRY(F.alloc(&embs, 1, 1, B, TEMB));
-    if (!dry) DM_HIP(e, launch_silu(emb.p, embs.p, (long long)B * TEMB, s));
+    DM_TRY(F.alloc(&embs, 1, 1, U, TEMB));
+    if (!dry) DM_HIP(e, launch_silu(emb.p, embs.p, (long long)U * TEMB, s));
     F.free(emb);
-    DM_TRY(F.dense(e->tproj_all, embs, nullptr, nullptr, EPI_PLAIN, &tproj));
+    DM_TRY(F.dense(e->tproj_all, embs, nullptr, nullptr, EPI_PLAIN, &tprojU));
     F.free(embs);
+    if (NC > 1) DM_TRY(F.replicate(tprojU, NC, &tproj)); else tproj = tprojU;
 
     // ---- conv_in (+ fused add_noise) ------------------------------------------------------------
     Tensor h;
     {
         Tensor col;
-        DM_TRY(F.alloc(&col, B, A.H, A.W, 64));
+        DM_TRY(F.alloc(&col, U, A.H, A.W, 64));
         if (!dry) DM_HIP(e, launch_im2col_in(A.x, A.x_index, A.eps, A.t, A.add_noise ? e->sa_tab : nullptr,
-                                             A.add_noise ? e->sb_tab : nullptr, B, A.H, A.W, col.p, s));
+                                             A.add_noise ? e->sb_tab : nullptr, U, A.H, A.W, col.p, s));
         DM_TRY(F.dense(e->conv_in, col, nullptr, nullptr, EPI_PLAIN, &h));
         F.free(col);
     }
     std::vector<Tensor> skips;
-    skips.push_back(h);
+    Tensor cur;
+    int j_start = 0;
+    if (NC > 1) {
+        // Shared prefix: conv_in, down_blocks[0].resnets[0] and the prompt-independent half of its
+        // transformer (up to the self-attention residual) run ONCE per draw; their outputs are then
+        // stacked NC times and the per-prompt half continues on the full batch.  Bit-identical to
+        // running every (draw, prompt) pair separately (the kernels are batch-position invariant).
+        const DownBlockW& d = e->down[0];
+        Tensor rU, t1U, hB, rB, t1B, a;
+        DM_TRY(F.resnet(d.res[0], h, nullptr, tprojU.p, &rU));
+        DM_TRY(F.transformer_pre(d.tf[0], rU, &t1U));
+        DM_TRY(F.replicate(h, NC, &hB));
+        DM_TRY(F.replicate(rU, NC, &rB));
+        DM_TRY(F.replicate(t1U, NC, &t1B));
+        F.free(h); F.free(rU); F.free(t1U); F.free(tprojU);
+        DM_TRY(F.transformer_post(d.tf[0], rB, t1B, A.slots, &a));
+        F.free(rB);
+        skips.push_back(hB);
+        skips.push_back(a);
+        cur = a;
+        j_start = 1;
+    } else {
+        skips.push_back(h);
+        cur = h;                    // `cur` aliases the newest skip (never freed here)
+    }
     // ---- down -----------------------------------------------------------------------------------
-    Tensor cur = h;                 // `cur` aliases the newest skip (never freed here)
     for (int i = 0; i < NB; ++i) {
         const DownBlockW& d = e->down[i];
-        for (int j = 0; j < LAYERS; ++j) {
+        for (int j = (i == 0 ? j_start : 0); j < LAYERS; ++j) {
             Tensor r;
             DM_TRY(F.resnet(d.res[j], cur, nullptr, tproj.p, &r));
             if (d.attn) {
@@ -614,7 +675,8 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
         Tensor nrm;
         DM_TRY(F.groupnorm(e->norm_out, cur, nullptr, GN_EPS, true, &nrm));
         if (!dry) DM_HIP(e, launch_conv_out(nrm.p, e->conv_out.w, e->conv_out.b, A.loss ? A.eps : nullptr, B, A.H, A.W, BOC[0],
-                                            A.loss, A.pred, s));
+                                            A.loss, A.pred, U, (NC > 1) ? U : B, (NC > 1) ? A.out_stride : 0,
+                                            (NC > 1) ? A.out_off : 0, s));
         F.free(nrm);
     }
     F.free(cur);
@@ -913,6 +975,36 @@ int dm_score(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, const 
     return run_chunked(e, A, n_x, stream);
 }
 
+int dm_score_conds(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, const void* eps_dev, const int64_t* t_dev,
+                   int n_cond, int n_draws, int n_x, int h, int w, void* loss_out_dev, void* stream) {
+    if (!e) return 1;
+    if (!x_dev || !eps_dev || !t_dev || !loss_out_dev) DM_FAIL(e, "dm_score_conds: null argument");
+    if (n_cond < 1 || n_draws < 1) DM_FAIL(e, "dm_score_conds: bad n_cond / n_draws");
+    if (n_cond > e->n_prompts) DM_FAIL(e, "dm_score_conds: n_cond %d exceeds the %d registered prompts", n_cond, e->n_prompts);
+    if (!x_index_dev && n_x != n_draws) DM_FAIL(e, "dm_score_conds: x_index is NULL but n_x (%d) != n_draws (%d)", n_x, n_draws);
+    if (!e->finalized) DM_FAIL(e, "engine not finalized");
+    DM_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t hw = (size_t)h * w;
+    int uc = max_chunk(h, w) / n_cond;
+    if (uc < 1) uc = 1;
+    for (int u0 = 0; u0 < n_draws; u0 += uc) {
+        const int nu = (n_draws - u0 < uc) ? (n_draws - u0) : uc;
+        FwdArgs A{};
+        A.x = (const f16*)x_dev; A.x_index = x_index_dev ? x_index_dev + u0 : nullptr;
+        if (!x_index_dev) A.x = (const f16*)x_dev + (size_t)u0 * 4 * hw;
+        A.eps = (const f16*)eps_dev + (size_t)u0 * 4 * hw; A.t = t_dev + u0; A.slots = nullptr;
+        A.B = nu * n_cond; A.H = h; A.W = w; A.n_cond = n_cond; A.out_stride = n_draws; A.out_off = u0;
+        A.add_noise = true; A.up_ft_index = -1; A.loss = (float*)loss_out_dev;
+        if (n_cond == 1) {          // degenerate: plain scoring of nu samples against prompt slot 0 .. handled by slot_div = 0
+            DM_FAIL(e, "dm_score_conds: use dm_score for n_cond == 1");
+        }
+        DM_TRY(ensure_arena(e, A, s));
+        DM_TRY(run_forward(e, A, s, false));
+    }
+    return 0;
+}
+
 int dm_unet_forward(dm_engine* e, const void* sample_dev, const int64_t* t_dev, const int32_t* slot_dev, int batch,
                     int h, int w, void* out_dev, void* stream) {
     if (!e) return 1;
@@ -1027,7 +1119,7 @@ int dm_op_attention(void* stream, const void* Q, const void* K, const void* V, v
     AttnParams a;
     a.Q = (const f16*)Q; a.K = (const f16*)K; a.V = (const f16*)V; a.O = (f16*)O;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.bsq = bsq; a.bsk = bsk; a.bsv = bsv; a.bso = bso;
-    a.kv_slot = kv_slot; a.B = B; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.D = D; a.scale = scale;
+    a.kv_slot = kv_slot; a.slot_div = 0; a.B = B; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.D = D; a.scale = scale;
     return launch_attention(a, (hipStream_t)stream) == hipSuccess ? 0 : 1;
 }
 

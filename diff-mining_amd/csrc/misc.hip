@@ -90,7 +90,7 @@ __global__ void im2col_in_kernel(const f16* __restrict__ x, const int32_t* __res
 __global__ __launch_bounds__(256)
 void conv_out_kernel(const f16* __restrict__ Xn, const f16* __restrict__ w, const f16* __restrict__ bias,
                      const f16* __restrict__ eps, int B, int H, int W, int C0, float* __restrict__ loss,
-                     f16* __restrict__ pred) {
+                     f16* __restrict__ pred, int eps_rows, int out_group, int out_stride, int out_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f16* ws = reinterpret_cast<f16*>(smem);
     const int K = 9 * C0;
@@ -134,9 +134,10 @@ void conv_out_kernel(const f16* __restrict__ Xn, const f16* __restrict__ w, cons
     if (valid && sub < 4) {
         const float a = sub == 0 ? a0 : (sub == 1 ? a1 : (sub == 2 ? a2 : a3));
         const f16 pr = (f16)(a + (float)bias[sub]);
-        const size_t oidx = ((size_t)b * 4 + sub) * HW + rem;
+        const int orow = (b / out_group) * out_stride + out_off + b % out_group;
+        const size_t oidx = ((size_t)orow * 4 + sub) * HW + rem;
         if (eps) {
-            const float d = (float)pr - (float)eps[oidx];
+            const float d = (float)pr - (float)eps[((size_t)(b % eps_rows) * 4 + sub) * HW + rem];
             loss[oidx] = d * d;
         }
         if (pred) pred[oidx] = pr;
@@ -269,11 +270,12 @@ hipError_t launch_im2col_in(const f16* x, const int32_t* x_index, const f16* eps
 }
 
 hipError_t launch_conv_out(const f16* Xn, const f16* w, const f16* bias, const f16* eps, int B, int H, int W,
-                           int C0, float* loss, f16* pred, hipStream_t s) {
+                           int C0, float* loss, f16* pred, int eps_rows, int out_group, int out_stride, int out_off,
+                           hipStream_t s) {
     const long long npix = (long long)B * H * W;
     const size_t lds = (size_t)4 * 9 * C0 * sizeof(f16);
     hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)((npix + 31) / 32)), dim3(256), lds, s, Xn, w, bias, eps,
-                       B, H, W, C0, loss, pred);
+                       B, H, W, C0, loss, pred, eps_rows, out_group, out_stride, out_off);
     return hipGetLastError();
 }
 

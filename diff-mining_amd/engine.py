@@ -19,7 +19,7 @@ _lib = None
 SYMBOLS = [
     "dm_version", "dm_scheduler_alphas_cumprod", "dm_timestep_sinusoid", "dm_engine_create",
     "dm_engine_destroy", "dm_last_error", "dm_engine_load_weight", "dm_engine_finalize",
-    "dm_engine_set_prompts", "dm_score", "dm_unet_forward", "dm_dift", "dm_dift_shape",
+    "dm_engine_set_prompts", "dm_score", "dm_score_conds", "dm_unet_forward", "dm_dift", "dm_dift_shape",
     "dm_reduce_typicality", "dm_typicality_image", "dm_prof_enable", "dm_prof_read", "dm_engine_memory",
     "dm_op_igemm", "dm_op_attention", "dm_op_groupnorm", "dm_op_layernorm",
 ]
@@ -56,6 +56,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_engine_finalize.argtypes = [vp]
     lib.dm_engine_set_prompts.argtypes = [vp, vp, i32, vp]
     lib.dm_score.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.dm_score_conds.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.dm_unet_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.dm_dift.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.dm_dift_shape.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
@@ -203,6 +204,31 @@ class UNetEngine:
                                       C.c_void_p(xi.data_ptr()) if xi is not None else None,
                                       C.c_void_p(eps.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(s.data_ptr()),
                                       B, x.shape[0], h, w, C.c_void_p(out.data_ptr()), self._stream()), "dm_score")
+        return out
+
+    def score_conds(self, x, eps, t, n_cond: int, x_index=None):
+        """D.compute_losses' inner call pattern: each of the U draws (x, eps, t) under prompts 0..n_cond-1.
+        Returns loss [n_cond*U,4,h,w] fp32, cond-major (row k*U+i).  Bit-identical to `score` on the tiled
+        batch; the prompt-independent head of the U-Net runs once per draw."""
+        torch = self._torch
+        x = x.to(self.device, torch.float16).contiguous()
+        eps = eps.to(self.device, torch.float16).contiguous()
+        U, _, h, w = eps.shape
+        t = t.to(self.device, torch.int64).contiguous()
+        assert t.shape == (U,) and 2 <= n_cond <= self.n_prompts
+        xi = None
+        if x_index is not None:
+            xi = torch.as_tensor(x_index, device=self.device).to(torch.int32).contiguous()
+            assert xi.shape == (U,)
+        elif x.shape[0] != U:
+            assert x.shape[0] == 1
+            xi = torch.zeros(U, dtype=torch.int32, device=self.device)
+        out = torch.empty(n_cond * U, 4, h, w, dtype=torch.float32, device=self.device)
+        self._check(self.lib.dm_score_conds(self._h, C.c_void_p(x.data_ptr()),
+                                            C.c_void_p(xi.data_ptr()) if xi is not None else None,
+                                            C.c_void_p(eps.data_ptr()), C.c_void_p(t.data_ptr()), n_cond, U,
+                                            x.shape[0], h, w, C.c_void_p(out.data_ptr()), self._stream()),
+                    "dm_score_conds")
         return out
 
     def unet(self, sample, t, slots):

@@ -113,10 +113,11 @@ class TypicalityScorer:
         eng.set_prompts(country_embeds)
         self.unet._ctx_key = None
         # sample row k*N + i = draw i under condition k  -> view as [n_cond, N] then transpose
-        n_batch = torch.cat([noises.to(self.device)] * n_cond, 0)
-        t_batch = torch.cat([timesteps.to(self.device)] * n_cond, 0)
-        slots = torch.arange(n_cond, dtype=torch.int32, device=self.device).repeat_interleave(N)
-        loss = eng.score(x, n_batch, t_batch, slots)                       # [n_cond*N,4,h,w] fp32
+        if n_cond >= 2:
+            loss = eng.score_conds(x, noises, timesteps, n_cond)            # [n_cond*N,4,h,w] fp32, cond-major
+        else:
+            slots = torch.zeros(N, dtype=torch.int32, device=self.device)
+            loss = eng.score(x, noises.to(self.device), timesteps.to(self.device), slots)
         grid = loss.view(n_cond, N, *loss.shape[1:]).transpose(0, 1).to(torch.float16)   # compute.py:155,160
         return grid.cpu() if to_host else grid.contiguous()
 

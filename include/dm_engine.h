@@ -80,6 +80,18 @@ int dm_score(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, const 
              const int64_t* t_dev, const int32_t* slot_dev, int batch, int n_x, int h, int w,
              void* loss_out_dev, void* stream);
 
+/* The same, for the way D.compute_losses actually calls it (compute.py:145-155): every one of
+ * n_draws (x, eps, t) draws is scored under the n_cond prompts registered in slots 0..n_cond-1.
+ * The part of the U-Net that cannot see the prompt (conv_in, down_blocks.0.resnets.0 and its
+ * transformer up to the self-attention residual) is evaluated once per draw instead of once per
+ * (draw, prompt) pair; results are bit-identical to dm_score on the tiled batch.
+ *   x_index_dev [n_draws] or NULL; eps_dev [n_draws,4,h,w]; t_dev [n_draws]
+ *   loss_out_dev [n_cond * n_draws, 4, h, w] fp32, cond-major: row k*n_draws + i = draw i, prompt k
+ *   (exactly the layout `torch.split(loss, [B]*n_cond)` expects at compute.py:155). */
+int dm_score_conds(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, const void* eps_dev,
+                   const int64_t* t_dev, int n_cond, int n_draws, int n_x, int h, int w,
+                   void* loss_out_dev, void* stream);
+
 /* `unet(sample, t, encoder_hidden_states).sample` (compute.py:100) without the fused
  * add_noise / loss: sample_dev [batch,4,h,w] fp16 -> out_dev [batch,4,h,w] fp16 (NCHW). */
 int dm_unet_forward(dm_engine* e, const void* sample_dev, const int64_t* t_dev, const int32_t* slot_dev,

@@ -250,6 +250,27 @@ def test_determinism_and_batch_invariance(engine):
     assert torch.equal(p, a[perm.to(a.device)])
 
 
+@pytest.mark.parametrize("h,w,U,n_img", [(8, 8, 3, 1), (16, 16, 6, 2), (12, 10, 2, 1)])
+def test_shared_draw_scoring_is_bit_identical(engine, h, w, U, n_img):
+    """dm_score_conds (prompt-independent head of the U-Net evaluated once per draw) == dm_score on
+    the cond-major tiled batch, bit for bit."""
+    x, eps, t, c = _inputs(h, w, U, n_img)
+    engine.set_prompts(c)
+    xi = (torch.arange(U) % n_img).int()
+    nb, tb, cc, slots = _tile(eps, t, c)
+    ref = engine.score(x, nb, tb, slots, x_index=torch.cat([xi, xi]))
+    got = engine.score_conds(x, eps, t, 2, x_index=xi)
+    assert got.shape == ref.shape
+    assert torch.equal(got, ref)
+    # three prompts
+    c3 = torch.cat([c, (c[:1] * 0.5)])
+    engine.set_prompts(c3)
+    nb3, tb3 = torch.cat([eps] * 3), torch.cat([t] * 3)
+    slots3 = torch.arange(3, dtype=torch.int32).repeat_interleave(U)
+    ref3 = engine.score(x, nb3, tb3, slots3, x_index=torch.cat([xi] * 3))
+    assert torch.equal(engine.score_conds(x, eps, t, 3, x_index=xi), ref3)
+
+
 def test_full_size_properties(engine):
     """BASELINE config 2 shape (64x64 latent, 10 t x 2 prompts): size-independent properties."""
     x, eps, t, c = _inputs(64, 64, 10)
@@ -263,6 +284,7 @@ def test_full_size_properties(engine):
     loss2 = engine.score(x, nb, tb, slots)
     assert not torch.equal(loss2[:10], loss2[10:])        # conditioning matters
     assert torch.equal(loss2[:10], loss[:10])             # slot 0 unchanged by what slot 1 holds
+    assert torch.equal(engine.score_conds(x, eps, t, 2), loss2)     # shared-draw path at the full shape
     m = loss2.mean().item()
     assert 0.1 < m < 10.0, m
     json.dump({"mean_loss_64x64": m}, open(os.path.join(os.environ.get("GRAFT_OUT", "/tmp"), "full_size.json"), "w"))
