@@ -103,9 +103,23 @@ def bench_attn():
         print(f"{name:24s} {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TF/s")
 
 
+def bench_norm():
+    d = U.dev()
+    for C, HW in ((320, 4096), (640, 1024), (1280, 256)):
+        rows = B * HW
+        x = torch.randn(rows, C, device=d).half()
+        g = torch.ones(C, device=d); b = torch.zeros(C, device=d)
+        y = torch.empty_like(x)
+        lib = U.E.load_library(); st = U.stream()
+        ms = timeit(lambda: lib.dm_op_layernorm(st, U.ptr(x), rows, C, U.ptr(g), U.ptr(b), 1e-5, U.ptr(y)))
+        print(f"layernorm C={C} rows={rows}: {ms:.3f} ms  {2 * rows * C * 2 / ms / 1e9:.2f} TB/s")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("igemm", "all"):
         bench_igemm()
     if what in ("attn", "all"):
         bench_attn()
+    if what in ("norm", "all"):
+        bench_norm()

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Regenerate the judged artifacts of a round on the GPU box:  bash tools/profile_round.sh <tag>
+# (run through gpurun; outputs land in gpurun_out/<tag>/, copy the summaries into profiles/).
+set -u
+TAG=${1:-r01_final}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline \
+    > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+           "SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+    rocprofv3 --pmc $set --kernel-trace -f csv -d $OUT/pmc_$i -o pmc -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline \
+        > $OUT/pmc_$i.json 2> $OUT/pmc_$i.err
+    i=$((i+1))
+done
+python tools/pmc_to_json.py $OUT 2 > $OUT/pmc.json
+find $OUT/stats -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
+# raw traces are large; keep only the summaries
+rm -rf $OUT/pmc_[0-9] $OUT/stats
+ls -la $OUT
+cat $OUT/bench.json
