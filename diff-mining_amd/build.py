@@ -15,8 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdm_engine.so")
-SOURCES = ["igemm.hip", "igemm_big.hip", "attention.hip", "norm.hip", "misc.hip", "engine.hip"]
-HEADERS = [os.path.join(CSRC, "dm_kernels.h"), os.path.join(os.path.dirname(HERE), "include", "dm_engine.h")]
+SOURCES = ["igemm.hip", "igemm_big.hip", "igemm64.hip", "attention.hip", "norm.hip", "misc.hip", "vae.hip", "engine.hip"]
+HEADERS = [os.path.join(CSRC, "dm_kernels.h"), os.path.join(CSRC, "igemm_tile.h"), os.path.join(os.path.dirname(HERE), "include", "dm_engine.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
          "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
@@ -52,7 +52,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
-    with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):

@@ -10,7 +10,7 @@ namespace dm {
 typedef _Float16 f16;
 
 // ---- K1/K2/K3: implicit-GEMM on MFMA (conv3x3 s1/s2/upsampled, 1x1 conv, linear) -------------
-enum IGemmMode { IG_DENSE = 0, IG_CONV3 = 1, IG_CONV3_S2 = 2, IG_CONV3_UP = 3 };
+enum IGemmMode { IG_DENSE = 0, IG_CONV3 = 1, IG_CONV3_S2 = 2, IG_CONV3_UP = 3, IG_CONV3_S2P0 = 4 };
 enum IGemmEpi { EPI_PLAIN = 0, EPI_GEGLU = 1 };
 
 struct IGemmParams {
@@ -81,5 +81,16 @@ hipError_t launch_typicality(const void* loss, int is_f16, int n_draws, int n_co
 // AvgPool2d((kx, ky), stride 1); tmp [H][W-ky+1], out [H-kx+1][W-ky+1] fp32
 hipError_t launch_typicality_image(const float* map, int h, int w, int H, int W, int kx, int ky, float* tmp,
                                    float* out, hipStream_t s);
+
+
+// ---- VAE encoder (vae.hip) ---------------------------------------------------------------------
+// RGB image NCHW fp16 -> im2col rows of encoder.conv_in: out [B*H*W][64], k = c*9 + ky*3 + kx (k < 27), zero after
+hipError_t launch_im2col_rgb(const f16* x, int B, int H, int W, f16* out, hipStream_t s);
+// single-head attention, head_dim 512: Q/K/V [B][T][ld], O [B][T][ldo]
+hipError_t launch_attention512(const f16* Q, const f16* K, const f16* V, f16* O, int B, int T, int ld, int ldo,
+                               float scale, hipStream_t s);
+// quant_conv (1x1, 8->8) on the first 8 channels of Hm [B*HW][ldh] + posterior sample * scaling (NCHW outputs)
+hipError_t launch_posterior(const f16* Hm, int ldh, const f16* qw, const f16* qb, const f16* noise, int B, int HW,
+                            float scaling, f16* latent16, float* latent32, float* moments, hipStream_t s);
 
 }  // namespace dm

@@ -59,6 +59,19 @@ struct TfmW {
 struct UpBlockW { ResW res[3]; TfmW tf[3]; bool attn = false; ConvW up; bool has_up = false; };
 struct DownBlockW { ResW res[2]; TfmW tf[2]; bool attn = false; ConvW down; bool has_down = false; };
 
+// SDv1.5 VAE encoder (block_out_channels 128/256/512/512, two resnets per block, no time embedding)
+constexpr int VNB = 4;
+const int VBOC[VNB] = {128, 256, 512, 512};
+constexpr float VAE_EPS = 1e-6f;
+struct VaeW {
+    ConvW conv_in;                 // [128][64] over im2col rows
+    ResW down[VNB][2]; ConvW ds[VNB - 1];
+    ResW mid[2];
+    NormW attn_gn; ConvW qkv, o;   // single-head attention, to_q/to_k/to_v stacked [1536][512]
+    NormW norm_out; ConvW conv_out;  // conv_out rows padded 8 -> 128
+    const f16* qw = nullptr; const f16* qb = nullptr;    // quant_conv [8][8], [8]
+};
+
 struct Arena {
     struct Blk { size_t off, sz; bool free; };
     std::vector<Blk> blks;
@@ -129,6 +142,11 @@ struct dm_engine {
     f16* sa_tab = nullptr;           // [1000] fp16 sqrt(acp16)
     f16* sb_tab = nullptr;           // [1000] fp16 sqrt(1-acp16)
 
+    // optional VAE encoder (dm_engine_load_vae_weight / dm_engine_finalize_vae)
+    std::map<std::string, HostTensor> host_vae;
+    VaeW vae; bool vae_ready = false;
+    char* vslab = nullptr; size_t vslab_bytes = 0;
+
     // prompt K/V cache
     int n_prompts = 0;
     std::vector<f16*> kv_cache;      // per transformer layer: [P*77][2C]
@@ -194,6 +212,7 @@ void host_sinusoid(int t, int dim, float* out) {
 struct Packer {
     dm_engine* e;
     std::vector<char> blob;
+    std::map<std::string, HostTensor>* src = nullptr;      // default: the U-Net state dict
     size_t put(const void* src, size_t bytes) {
         size_t off = (blob.size() + 255) & ~(size_t)255;
         blob.resize(off + bytes);
@@ -201,8 +220,9 @@ struct Packer {
         return off;
     }
     HostTensor* get(const std::string& name, std::initializer_list<int64_t> shape) {
-        auto it = e->host.find(name);
-        if (it == e->host.end()) { e->err = "missing tensor: " + name; return nullptr; }
+        std::map<std::string, HostTensor>& m = src ? *src : e->host;
+        auto it = m.find(name);
+        if (it == m.end()) { e->err = "missing tensor: " + name; return nullptr; }
         HostTensor& t = it->second;
         std::vector<int64_t> want(shape);
         if (t.shape != want) {
@@ -312,6 +332,17 @@ int pack_resnet(Packer& P, const std::string& name, int cin, int cout, ResW* r, 
     return 0;
 }
 
+int pack_vae_resnet(Packer& P, const std::string& name, int cin, int cout, ResW* r) {
+    r->cin = cin; r->cout = cout; r->temb_off = 0;
+    DM_TRY(pack_norm(P, name + ".norm1", cin, &r->n1));
+    DM_TRY(pack_conv3(P, name + ".conv1", cout, cin, &r->c1));
+    DM_TRY(pack_norm(P, name + ".norm2", cout, &r->n2));
+    DM_TRY(pack_conv3(P, name + ".conv2", cout, cout, &r->c2));
+    r->has_sc = (cin != cout);
+    if (r->has_sc) DM_TRY(pack_dense(P, name + ".conv_shortcut", cout, cin, true, true, &r->sc));
+    return 0;
+}
+
 int pack_tfm(Packer& P, const std::string& name, int c, TfmW* t, dm_engine* e) {
     t->c = c; t->layer = e->n_tf++;
     e->tfs.push_back(t);
@@ -353,6 +384,7 @@ struct Fwd {
     dm_engine* e;
     hipStream_t s;
     bool dry;
+    float res_eps = GN_EPS;   // GroupNorm eps of the ResNet blocks (U-Net 1e-5, VAE 1e-6)
 
     int alloc(Tensor* t, int N, int H, int W, int C) {
         t->N = N; t->H = H; t->W = W; t->C = C;
@@ -437,10 +469,10 @@ struct Fwd {
 
     int resnet(const ResW& r, const Tensor& x, const Tensor* x2, const f16* tproj, Tensor* out) {
         Tensor n1, h1, n2, sc;
-        DM_TRY(groupnorm(r.n1, x, x2, GN_EPS, true, &n1));
+        DM_TRY(groupnorm(r.n1, x, x2, res_eps, true, &n1));
         DM_TRY(igemm(r.c1, IG_CONV3, n1, nullptr, x.H, x.W, tproj ? tproj + r.temb_off : nullptr, e->tproj_total, nullptr, EPI_PLAIN, &h1));
         free(n1);
-        DM_TRY(groupnorm(r.n2, h1, nullptr, GN_EPS, true, &n2));
+        DM_TRY(groupnorm(r.n2, h1, nullptr, res_eps, true, &n2));
         free(h1);
         const Tensor* resid = &x;
         if (r.has_sc) { DM_TRY(dense(r.sc, x, x2, nullptr, EPI_PLAIN, &sc)); resid = &sc; }
@@ -685,6 +717,91 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
     return 0;
 }
 
+// ---- VAE encoder: image -> moments -> latent (compute.py:91-93) ---------------------------------
+struct VaeArgs {
+    const f16* image; const f16* noise; int B, H, W; float scaling;
+    f16* latent16; float* latent32; float* moments;
+};
+
+int run_vae(dm_engine* e, const VaeArgs& A, hipStream_t s, bool dry) {
+    Fwd F{e, s, dry};
+    F.res_eps = VAE_EPS;
+    const VaeW& v = e->vae;
+    Tensor cur;
+    {
+        Tensor col;
+        DM_TRY(F.alloc(&col, A.B, A.H, A.W, 64));
+        if (!dry) DM_HIP(e, launch_im2col_rgb(A.image, A.B, A.H, A.W, col.p, s));
+        DM_TRY(F.dense(v.conv_in, col, nullptr, nullptr, EPI_PLAIN, &cur));
+        F.free(col);
+    }
+    for (int i = 0; i < VNB; ++i) {
+        for (int j = 0; j < 2; ++j) {
+            Tensor r;
+            DM_TRY(F.resnet(v.down[i][j], cur, nullptr, nullptr, &r));
+            F.free(cur);
+            cur = r;
+        }
+        if (i != VNB - 1) {
+            Tensor dn;      // Downsample2D(padding=0): F.pad(x, (0,1,0,1)) + conv3x3 stride 2
+            DM_TRY(F.igemm(v.ds[i], IG_CONV3_S2P0, cur, nullptr, cur.H / 2, cur.W / 2, nullptr, 0, nullptr, EPI_PLAIN, &dn));
+            F.free(cur);
+            cur = dn;
+        }
+    }
+    {
+        Tensor m0, n, qkv, a, m1, m2;
+        DM_TRY(F.resnet(v.mid[0], cur, nullptr, nullptr, &m0));
+        F.free(cur);
+        const int C = VBOC[VNB - 1], T = m0.H * m0.W;
+        DM_TRY(F.groupnorm(v.attn_gn, m0, nullptr, VAE_EPS, false, &n));
+        DM_TRY(F.dense(v.qkv, n, nullptr, nullptr, EPI_PLAIN, &qkv));
+        F.free(n);
+        DM_TRY(F.alloc(&a, m0.N, m0.H, m0.W, C));
+        if (!dry) {
+            DM_TRY(F.prof_begin(1, 4.0 * m0.N * (double)T * T * C));
+            DM_HIP(e, launch_attention512(qkv.p, qkv.p + C, qkv.p + 2 * C, a.p, m0.N, T, 3 * C, C, 1.0f / sqrtf((float)C), s));
+            DM_TRY(F.prof_end());
+        }
+        F.free(qkv);
+        DM_TRY(F.dense(v.o, a, nullptr, &m0, EPI_PLAIN, &m1));
+        F.free(a); F.free(m0);
+        DM_TRY(F.resnet(v.mid[1], m1, nullptr, nullptr, &m2));
+        F.free(m1);
+        cur = m2;
+    }
+    Tensor nrm, co;
+    DM_TRY(F.groupnorm(v.norm_out, cur, nullptr, VAE_EPS, true, &nrm));
+    F.free(cur);
+    DM_TRY(F.igemm(v.conv_out, IG_CONV3, nrm, nullptr, nrm.H, nrm.W, nullptr, 0, nullptr, EPI_PLAIN, &co));
+    F.free(nrm);
+    if (!dry) DM_HIP(e, launch_posterior(co.p, co.C, v.qw, v.qb, A.noise, A.B, co.H * co.W, A.scaling, A.latent16, A.latent32,
+                                         A.moments, s));
+    F.free(co);
+    return 0;
+}
+
+template <class RunFn>
+int ensure_arena_for(dm_engine* e, hipStream_t s, RunFn run_dry) {
+    e->arena.reset((size_t)1 << 60, true);
+    char* keep = e->arena_base;
+    e->arena_base = nullptr;
+    int rc = run_dry();
+    e->arena_base = keep;
+    if (rc) return rc;
+    const size_t need = e->arena.peak;
+    if (need > e->arena_cap) {
+        DM_HIP(e, hipStreamSynchronize(s));
+        if (e->arena_base) DM_HIP(e, hipFree(e->arena_base));
+        e->arena_base = nullptr; e->arena_cap = 0;
+        const size_t cap = need + (need >> 4);
+        DM_HIP(e, hipMalloc((void**)&e->arena_base, cap));
+        e->arena_cap = cap;
+    }
+    e->arena.reset(e->arena_cap, false);
+    return 0;
+}
+
 int ensure_arena(dm_engine* e, const FwdArgs& A, hipStream_t s) {
     // dry run with an unbounded virtual arena to get the exact peak, then (re)allocate if needed
     e->arena.reset((size_t)1 << 60, true);
@@ -757,6 +874,7 @@ void dm_engine_destroy(dm_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     if (e->wslab) (void)hipFree(e->wslab);
+    if (e->vslab) (void)hipFree(e->vslab);
     if (e->arena_base) (void)hipFree(e->arena_base);
     if (e->sin_table) (void)hipFree(e->sin_table);
     if (e->sa_tab) (void)hipFree(e->sa_tab);
@@ -907,6 +1025,144 @@ int dm_engine_finalize(dm_engine* e) {
     e->kv_cache.assign(e->n_tf, nullptr);
     e->finalized = true;
     return 0;
+}
+
+int dm_engine_load_vae_weight(dm_engine* e, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim) {
+    if (!e || !name || !host_ptr || !shape) return 1;
+    if (e->vae_ready) DM_FAIL(e, "load_vae_weight after finalize_vae");
+    std::string nm(name);
+    if (nm.rfind("vae.", 0) == 0) nm = nm.substr(4);
+    if (nm.rfind("decoder.", 0) == 0 || nm.rfind("post_quant_conv.", 0) == 0) return 0;     // not on the path
+    // pre-0.15 diffusers names of the mid-block attention
+    static const char* legacy[4][2] = {{".query.", ".to_q."}, {".key.", ".to_k."}, {".value.", ".to_v."}, {".proj_attn.", ".to_out.0."}};
+    for (auto& l : legacy) { const size_t at = nm.find(l[0]); if (at != std::string::npos) nm.replace(at, strlen(l[0]), l[1]); }
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    // legacy checkpoints store the attention projections as 1x1 convs [C, C, 1, 1]
+    if (nm.find(".attentions.0.to_") != std::string::npos && ndim == 4 && shape[2] == 1 && shape[3] == 1) t.shape.resize(2);
+    const size_t n = t.numel();
+    t.data.resize(n);
+    if (dtype == DM_F16) memcpy(t.data.data(), host_ptr, n * 2);
+    else if (dtype == DM_F32) { const float* f = (const float*)host_ptr; for (size_t i = 0; i < n; ++i) t.data[i] = (f16)f[i]; }
+    else DM_FAIL(e, "unsupported dtype %d for %s", dtype, name);
+    e->host_vae[nm] = std::move(t);
+    return 0;
+}
+
+int dm_engine_finalize_vae(dm_engine* e) {
+    if (!e) return 1;
+    if (e->vae_ready) return 0;
+    DM_HIP(e, hipSetDevice(e->device));
+    Packer P{e, {}, &e->host_vae};
+    VaeW& v = e->vae;
+    {
+        HostTensor* w = P.get("encoder.conv_in.weight", {VBOC[0], 3, 3, 3});
+        if (!w) return 1;
+        std::vector<f16> pk((size_t)VBOC[0] * 64, (f16)0.f);
+        for (int co = 0; co < VBOC[0]; ++co)
+            for (int k = 0; k < 27; ++k) pk[(size_t)co * 64 + k] = w->data[(size_t)co * 27 + k];
+        v.conv_in.w = as_ptr(P.put(pk.data(), pk.size() * 2));
+        v.conv_in.cin = 64; v.conv_in.cout = VBOC[0]; v.conv_in.k = 1;
+        DM_TRY(pack_bias(P, "encoder.conv_in", VBOC[0], &v.conv_in.b));
+    }
+    int cin = VBOC[0];
+    for (int i = 0; i < VNB; ++i) {
+        const int cout = VBOC[i];
+        const std::string bn = "encoder.down_blocks." + std::to_string(i);
+        for (int j = 0; j < 2; ++j)
+            DM_TRY(pack_vae_resnet(P, bn + ".resnets." + std::to_string(j), j == 0 ? cin : cout, cout, &v.down[i][j]));
+        if (i != VNB - 1) DM_TRY(pack_conv3(P, bn + ".downsamplers.0.conv", cout, cout, &v.ds[i]));
+        cin = cout;
+    }
+    const int C = VBOC[VNB - 1];
+    DM_TRY(pack_vae_resnet(P, "encoder.mid_block.resnets.0", C, C, &v.mid[0]));
+    {
+        const std::string a = "encoder.mid_block.attentions.0";
+        DM_TRY(pack_norm(P, a + ".group_norm", C, &v.attn_gn));
+        DM_TRY(pack_stack(P, {a + ".to_q", a + ".to_k", a + ".to_v"}, C, C, &v.qkv));
+        std::vector<f16> qb;
+        for (const char* leaf : {".to_q", ".to_k", ".to_v"}) {
+            HostTensor* b = P.get(a + leaf + ".bias", {C});
+            if (!b) return 1;
+            qb.insert(qb.end(), b->data.begin(), b->data.end());
+        }
+        v.qkv.b = as_ptr(P.put(qb.data(), qb.size() * 2));
+        DM_TRY(pack_dense(P, a + ".to_out.0", C, C, false, true, &v.o));
+    }
+    DM_TRY(pack_vae_resnet(P, "encoder.mid_block.resnets.1", C, C, &v.mid[1]));
+    DM_TRY(pack_norm(P, "encoder.conv_norm_out", C, &v.norm_out));
+    {
+        // conv_out 512 -> 8, rows zero-padded to one 128-channel igemm tile: [128][tap*C + c]
+        HostTensor* w = P.get("encoder.conv_out.weight", {8, C, 3, 3});
+        HostTensor* b = P.get("encoder.conv_out.bias", {8});
+        if (!w || !b) return 1;
+        std::vector<f16> pk((size_t)128 * 9 * C, (f16)0.f), pb(128, (f16)0.f);
+        for (int co = 0; co < 8; ++co) {
+            for (int ci = 0; ci < C; ++ci)
+                for (int tap = 0; tap < 9; ++tap)
+                    pk[((size_t)co * 9 + tap) * C + ci] = w->data[((size_t)co * C + ci) * 9 + tap];
+            pb[co] = b->data[co];
+        }
+        v.conv_out.w = as_ptr(P.put(pk.data(), pk.size() * 2));
+        v.conv_out.b = as_ptr(P.put(pb.data(), pb.size() * 2));
+        v.conv_out.cin = C; v.conv_out.cout = 128; v.conv_out.k = 3;
+        HostTensor* qw = P.get("quant_conv.weight", {8, 8, 1, 1});
+        HostTensor* qb = P.get("quant_conv.bias", {8});
+        if (!qw || !qb) return 1;
+        v.qw = as_ptr(P.put(qw->data.data(), 64 * 2));
+        v.qb = as_ptr(P.put(qb->data.data(), 8 * 2));
+    }
+    size_t unused = 0; std::string first_unused;
+    for (auto& kv : e->host_vae) if (!kv.second.used) { if (!unused) first_unused = kv.first; ++unused; }
+    if (unused) DM_FAIL(e, "%zu unexpected tensors in the VAE state dict (first: %s)", unused, first_unused.c_str());
+    if (e->host_vae.size() != 108) DM_FAIL(e, "expected 108 VAE encoder tensors, got %zu", e->host_vae.size());
+
+    e->vslab_bytes = P.blob.size();
+    DM_HIP(e, hipMalloc((void**)&e->vslab, e->vslab_bytes));
+    DM_HIP(e, hipMemcpy(e->vslab, P.blob.data(), e->vslab_bytes, hipMemcpyHostToDevice));
+    char* base = e->vslab;
+    rebase_conv(v.conv_in, base); rebase_conv(v.qkv, base); rebase_conv(v.o, base); rebase_conv(v.conv_out, base);
+    rebase_norm(v.attn_gn, base); rebase_norm(v.norm_out, base);
+    rebase(v.qw, base); rebase(v.qb, base);
+    for (int i = 0; i < VNB; ++i) {
+        for (int j = 0; j < 2; ++j) rebase_res(v.down[i][j], base);
+        if (i != VNB - 1) rebase_conv(v.ds[i], base);
+    }
+    rebase_res(v.mid[0], base); rebase_res(v.mid[1], base);
+    e->host_vae.clear();
+    e->vae_ready = true;
+    return 0;
+}
+
+int dm_vae_encode(dm_engine* e, const void* image_dev, const void* noise_dev, int batch, int H, int W, float scaling_factor,
+                  void* latent_f16_dev, void* latent_f32_dev, void* moments_f32_dev, void* stream) {
+    if (!e) return 1;
+    if (!e->vae_ready) DM_FAIL(e, "dm_vae_encode: VAE weights not loaded (dm_engine_finalize_vae)");
+    if (!image_dev || (!latent_f16_dev && !latent_f32_dev && !moments_f32_dev)) DM_FAIL(e, "dm_vae_encode: null argument");
+    if (batch <= 0 || H < 8 || W < 8 || (H % 8) || (W % 8)) DM_FAIL(e, "dm_vae_encode: H and W must be positive multiples of 8");
+    DM_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t ipx = (size_t)H * W, lpx = (size_t)(H / 8) * (W / 8);
+    long long chunk = (8LL * 512 * 512) / (long long)ipx;         // workspace ~ 2.7 GB per 8 images of 512^2
+    if (chunk < 1) chunk = 1;
+    for (int b0 = 0; b0 < batch; b0 += (int)chunk) {
+        VaeArgs A{};
+        A.B = (batch - b0 < chunk) ? (batch - b0) : (int)chunk;
+        A.H = H; A.W = W; A.scaling = scaling_factor;
+        A.image = (const f16*)image_dev + (size_t)b0 * 3 * ipx;
+        A.noise = noise_dev ? (const f16*)noise_dev + (size_t)b0 * 4 * lpx : nullptr;
+        A.latent16 = latent_f16_dev ? (f16*)latent_f16_dev + (size_t)b0 * 4 * lpx : nullptr;
+        A.latent32 = latent_f32_dev ? (float*)latent_f32_dev + (size_t)b0 * 4 * lpx : nullptr;
+        A.moments = moments_f32_dev ? (float*)moments_f32_dev + (size_t)b0 * 8 * lpx : nullptr;
+        DM_TRY(ensure_arena_for(e, s, [&]() { return run_vae(e, A, s, true); }));
+        DM_TRY(run_vae(e, A, s, false));
+    }
+    return 0;
+}
+
+int dm_op_attention512(void* stream, const void* Q, const void* K, const void* V, void* O, int B, int T, int ld, int ldo,
+                       float scale) {
+    return launch_attention512((const f16*)Q, (const f16*)K, (const f16*)V, (f16*)O, B, T, ld, ldo, scale, (hipStream_t)stream) == hipSuccess ? 0 : 1;
 }
 
 int dm_engine_set_prompts(dm_engine* e, const void* ctx_dev, int n_prompts, void* stream) {

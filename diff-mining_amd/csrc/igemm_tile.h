@@ -1,0 +1,300 @@
+// igemm_tile.h — the 128-pixel implicit-GEMM tile kernel, shared by igemm.hip (U-Net: waves of
+// 64 px x 80 ch, NI = 5) and igemm64.hip (VAE encoder: waves of 64 px x 64 ch, NI = 4, channel counts
+// 128/256/512).  Each instantiation lives in its own translation unit on purpose: co-compiling large
+// kernels perturbs the register allocation of both (measured).
+#pragma once
+#include "dm_kernels.h"
+#include <cstdlib>
+
+namespace dm {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 64;           // k per step (one tap, 64 input channels)
+
+// erf-GELU  x * Phi(x),  Phi via Abramowitz-Stegun 7.1.26 (|erf error| < 1.5e-7, far below the fp16
+// rounding of the result): 1 rcp + 1 exp2 + 7 FMAs instead of libm erff (~40 instructions), which
+// dominated the GEGLU epilogue (40 calls per lane per tile).  The negative tail is formed as
+// 0.5*poly*e directly (no 1 - 1 cancellation).
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float ax = __builtin_fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+    float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    poly = __builtin_fmaf(t, poly, 1.421413741f);
+    poly = __builtin_fmaf(t, poly, -0.284496736f);
+    poly = __builtin_fmaf(t, poly, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
+    const float half_tail = 0.5f * poly * e;                 // = 0.5 * (1 - erf(|x|/sqrt2))
+    const float phi = (x < 0.f) ? half_tail : 1.0f - half_tail;
+    return x * phi;
+}
+
+// Epilogue staged through LDS: fragments (bias / time-embedding / GEGLU applied, rounded to fp16) are
+// written to an LDS tile [TP px][TCO ch] (row stride padded by 8 B: conflict-free ds_write_b64 /
+// b32), then copied out as whole rows with 16-byte stores (+ the residual read the same way).
+// The direct fragment stores write 8-byte (GEGLU: 4-byte) pieces of 16 different 128-byte lines per
+// instruction; on the wide, short-K linears that partial-line traffic bound the whole kernel.
+template <int EPI, int NTH, int TP, int TC, int NI>
+__device__ __forceinline__ void epilogue_lds(const IGemmParams& p, floatx4 (&acc)[NI][4], char* smem, int p0,
+                                             int c0out, int wc, int wp, int l15, int lg, int OHW) {
+    constexpr int TCO = (EPI == EPI_GEGLU) ? TC / 2 : TC;     // output channels of the tile
+    constexpr int ROWB = TCO * 2 + 8;
+    __syncthreads();                                           // every wave is done with the operand tiles
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pr = wp * 64 + 16 * j + l15;
+        const int m = p0 + pr;
+        const int n = (p.temb != nullptr && m < p.M) ? (m / OHW) : 0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int cl = wc * (16 * NI) + 16 * i + 4 * lg;              // tile-local channel
+            const int c = c0out + cl;
+            float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+            if (p.bias) {
+                const half4 bv = *reinterpret_cast<const half4*>(p.bias + c);
+                v0 += (float)bv[0]; v1 += (float)bv[1]; v2 += (float)bv[2]; v3 += (float)bv[3];
+            }
+            if (EPI == EPI_GEGLU) {
+                const f16 h0 = (f16)v0, h1 = (f16)v1, g0 = (f16)v2, g1 = (f16)v3;
+                const f16 q0 = (f16)gelu_erf((float)g0), q1 = (f16)gelu_erf((float)g1);
+                typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+                const half2_ o = half2_{(f16)((float)h0 * (float)q0), (f16)((float)h1 * (float)q1)};
+                const int ol = (cl >> 4) * 8 + 2 * lg;
+                *reinterpret_cast<half2_*>(smem + pr * ROWB + ol * 2) = o;
+            } else {
+                half4 o = half4{(f16)v0, (f16)v1, (f16)v2, (f16)v3};
+                if (p.temb && m < p.M) {
+                    const half4 tv = *reinterpret_cast<const half4*>(p.temb + (size_t)n * p.temb_ld + c);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (f16)((float)o[r] + (float)tv[r]);
+                }
+                *reinterpret_cast<half4*>(smem + pr * ROWB + cl * 2) = o;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = TCO / 8;                               // 16-byte chunks per row
+    const int c0o = (EPI == EPI_GEGLU) ? c0out / 2 : c0out;
+    for (int idx = threadIdx.x; idx < TP * CPR; idx += NTH) {
+        const int row = idx / CPR, ch = idx - row * CPR;
+        const int m = p0 + row;
+        if (m >= p.M) continue;
+        const char* src = smem + row * ROWB + ch * 16;
+        const half4 lo = *reinterpret_cast<const half4*>(src);
+        const half4 hi = *reinterpret_cast<const half4*>(src + 8);
+        half8 o = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (EPI != EPI_GEGLU && p.res) {
+            const half8 rv = *reinterpret_cast<const half8*>(p.res + (size_t)m * p.ldres + c0o + ch * 8);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) o[r] = (f16)((float)o[r] + (float)rv[r]);
+        }
+        *reinterpret_cast<half8*>(p.Y + (size_t)m * p.ldy + c0o + ch * 8) = o;
+    }
+}
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int WC, int EPI, int NI>
+__global__ __launch_bounds__(128 * WC, 2)
+void igemm_kernel(IGemmParams p) {
+    constexpr int WP = 2;
+    constexpr int NW = WP * WC;
+    constexpr int TP = 64 * WP, TC = 16 * NI * WC;
+    constexpr int WBYTES = TC * 128, XBYTES = TP * 128, STAGE = WBYTES + XBYTES;
+    constexpr int WG = TC / 8, XG = TP / 8;
+    constexpr int WI = WG / NW, XI = XG / NW;               // exact: 5 + 4 (WC=2), 5 + 2 (WC=4)
+    static_assert(WG % NW == 0 && XG % NW == 0, "uniform LDS-DMA count per wave required");
+    constexpr int NL = WI + XI;
+    static_assert(NL <= 2 * NI, "one LDS-DMA piece per MFMA group");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wid % WC;
+    const int wp = wid / WC;
+
+    const int tiles_c = p.Cout / TC;
+    const int nblk = gridDim.x;
+    int v;
+    {
+        const int b = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = b & 7, loc = b >> 3;
+        v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int pt = v / tiles_c;
+    const int ct = v - pt * tiles_c;
+    const int p0 = pt * TP;
+    const int c0out = ct * TC;
+
+    const int C1 = p.C1;
+    const int C2 = p.Cin - C1;
+    const int ntaps = (p.mode == IG_DENSE) ? 1 : 9;
+    const int cpt = p.Cin / BK;
+    const int nk = ntaps * cpt;
+    const int Ktot = ntaps * p.Cin;
+    const int OHW = p.OH * p.OW;
+
+    const int lrow = lane >> 3;
+    const int lchunk = ((lane & 7) ^ lrow) * 8;
+
+    const f16* wsrc[WI];
+#pragma unroll
+    for (int k = 0; k < WI; ++k)
+        wsrc[k] = p.Wp + (size_t)(c0out + (wid + k * NW) * 8 + lrow) * Ktot + lchunk;
+    int xn[XI], xoh[XI], xow[XI];
+#pragma unroll
+    for (int k = 0; k < XI; ++k) {
+        const int m = p0 + (wid + k * NW) * 8 + lrow;
+        if (m < p.M) {
+            const int n = m / OHW;
+            const int rem = m - n * OHW;
+            const int oh = rem / p.OW;
+            xn[k] = n; xoh[k] = oh; xow[k] = rem - oh * p.OW;
+        } else { xn[k] = -1; xoh[k] = 0; xow[k] = 0; }
+    }
+    const float sh = (float)p.H / (float)p.OH;
+    const float sw = (float)p.W / (float)p.OW;
+    const f16* zero = reinterpret_cast<const f16*>(g_zero_page) + lchunk;
+
+    // per-lane source pointer of each activation row for the tile about to be loaded; advanced by
+    // BK per tile inside a tap (0 for zero-page rows), recomputed when the tap or the source changes
+    const f16* xsrc[XI];
+    int xinc[XI];
+    long long xpix[XI];
+    auto set_tap = [&](int tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+        for (int k = 0; k < XI; ++k) {
+            long long off = -1;
+            if (xn[k] >= 0) {
+                if (p.mode == IG_DENSE) {
+                    off = (long long)(p0 + (wid + k * NW) * 8 + lrow);
+                } else if (p.mode == IG_CONV3 || p.mode == IG_CONV3_S2 || (NI == 4 && p.mode == IG_CONV3_S2P0)) {
+                    const bool p0s2 = (NI == 4 && p.mode == IG_CONV3_S2P0);     // pad (0,1,0,1), stride 2 (VAE)
+                    const int st = (p.mode == IG_CONV3_S2 || p0s2) ? 2 : 1;
+                    const int pd = p0s2 ? 0 : 1;
+                    const int ih = xoh[k] * st + dy - pd, iw = xow[k] * st + dx - pd;
+                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) off = ((long long)xn[k] * p.H + ih) * p.W + iw;
+                } else {
+                    const int uh = xoh[k] + dy - 1, uw = xow[k] + dx - 1;
+                    if (uh >= 0 && uh < p.OH && uw >= 0 && uw < p.OW) {
+                        int ih = (int)floorf((float)uh * sh); ih = ih < p.H - 1 ? ih : p.H - 1;
+                        int iw = (int)floorf((float)uw * sw); iw = iw < p.W - 1 ? iw : p.W - 1;
+                        off = ((long long)xn[k] * p.H + ih) * p.W + iw;
+                    }
+                }
+            }
+            xpix[k] = off;
+            xsrc[k] = (off >= 0) ? (p.X + off * C1 + lchunk) : zero;
+            xinc[k] = (off >= 0) ? BK : 0;
+        }
+    };
+    int ld_tap = 0, ld_cc = 0;
+    auto prepare = [&]() {                                   // pointers for the next tile to load
+        if (ld_cc == 0) set_tap(ld_tap);
+        else if (ld_cc * BK == C1) {
+#pragma unroll
+            for (int k = 0; k < XI; ++k) if (xpix[k] >= 0) xsrc[k] = p.X2 + xpix[k] * C2 + lchunk;
+        }
+        if (++ld_cc == cpt) { ld_cc = 0; ++ld_tap; }
+    };
+    auto load_piece = [&](int buf, int idx) {                // idx in [0, NL): W pieces first, then X
+        char* wt = smem + buf * STAGE;
+        if (idx < WI) {
+            __builtin_amdgcn_global_load_lds((gptr_t)wsrc[idx], (lptr_t)(wt + (wid + idx * NW) * 1024), 16, 0, 0);
+            wsrc[idx] += BK;
+        } else {
+            const int k = idx - WI;
+            __builtin_amdgcn_global_load_lds((gptr_t)xsrc[k], (lptr_t)(wt + WBYTES + (wid + k * NW) * 1024), 16, 0, 0);
+            xsrc[k] += xinc[k];
+        }
+    };
+
+    floatx4 acc[NI][4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+    const int a_row_off = (wc * (16 * NI) + l15) * 128;
+    const int b_row_off = (wp * 64 + l15) * 128;
+    const int koff0 = ((lg ^ (l15 & 7)) << 4), koff1 = (((4 + lg) ^ (l15 & 7)) << 4);
+
+    prepare();
+#pragma unroll
+    for (int i = 0; i < NL; ++i) load_piece(0, i);
+
+    auto step = [&](int cur, bool more) {
+        const char* wt = smem + cur * STAGE;
+        const char* xt = wt + WBYTES;
+        half8 a0[NI], b0[4], a1[NI], b1[4];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) a0[i] = *reinterpret_cast<const half8*>(wt + a_row_off + i * 2048 + koff0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const half8*>(xt + b_row_off + j * 2048 + koff0);
+        if (more) prepare();
+        // 2*NI groups of 4 MFMAs; one LDS-DMA piece after each of the first NL groups
+#pragma unroll
+        for (int g = 0; g < 2 * NI; ++g) {
+            const int i = g % NI;
+            if (g == 2) {
+#pragma unroll
+                for (int ii = 0; ii < NI; ++ii) a1[ii] = *reinterpret_cast<const half8*>(wt + a_row_off + ii * 2048 + koff1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const half8*>(xt + b_row_off + j * 2048 + koff1);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = (g < NI) ? __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[i], b0[j], acc[i][j], 0, 0, 0)
+                                    : __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+            if (more && g < NL) load_piece(cur ^ 1, g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        step(kt & 1, true);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    step((nk - 1) & 1, false);
+    epilogue_lds<EPI, 128 * WC, TP, TC, NI>(p, acc, smem, p0, c0out, wc, wp, l15, lg, OHW);
+}
+
+}  // namespace
+
+template <int WC, int NI>
+static hipError_t launch_t(const IGemmParams& p, hipStream_t s) {
+    constexpr int TP = 128, TC = 16 * NI * WC;
+    constexpr size_t lds = 2 * (size_t)(TP + TC) * 128;
+    const int tiles_p = (p.M + TP - 1) / TP;
+    const int tiles_c = p.Cout / TC;
+    dim3 grid(tiles_p * tiles_c), block(128 * WC);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_PLAIN, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_GEGLU, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (p.epi == EPI_GEGLU)
+        hipLaunchKernelGGL((igemm_kernel<WC, EPI_GEGLU, NI>), grid, block, lds, s, p);
+    else
+        hipLaunchKernelGGL((igemm_kernel<WC, EPI_PLAIN, NI>), grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace dm

@@ -22,6 +22,7 @@ SYMBOLS = [
     "dm_engine_set_prompts", "dm_score", "dm_score_conds", "dm_unet_forward", "dm_dift", "dm_dift_shape",
     "dm_reduce_typicality", "dm_typicality_image", "dm_prof_enable", "dm_prof_read", "dm_engine_memory",
     "dm_op_igemm", "dm_op_attention", "dm_op_groupnorm", "dm_op_layernorm",
+    "dm_engine_load_vae_weight", "dm_engine_finalize_vae", "dm_vae_encode", "dm_op_attention512",
 ]
 
 
@@ -70,6 +71,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_op_attention.argtypes = [vp] * 5 + [i32] * 4 + [i64] * 4 + [vp] + [i32] * 5 + [C.c_float]
     lib.dm_op_groupnorm.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, C.c_float, vp, vp, i32, vp]
     lib.dm_op_layernorm.argtypes = [vp, vp, i32, i32, vp, vp, C.c_float, vp]
+    lib.dm_engine_load_vae_weight.argtypes = [vp, C.c_char_p, vp, i32, C.POINTER(i64), i32]
+    lib.dm_engine_finalize_vae.argtypes = [vp]
+    lib.dm_vae_encode.argtypes = [vp, vp, vp, i32, i32, i32, C.c_float, vp, vp, vp, vp]
+    lib.dm_op_attention512.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float]
     if path is None:
         _lib = lib
     return lib
@@ -138,8 +143,7 @@ class UNetEngine:
             pass
 
     # -- weights ---------------------------------------------------------------------------------
-    def load_state_dict(self, sd: Dict[str, "np.ndarray"]):
-        """sd: diffusers-named U-Net state dict (numpy or torch tensors, fp16/fp32/bf16)."""
+    def _load(self, fn, sd, what):
         torch = self._torch
         for name, t in sd.items():
             if hasattr(t, "detach"):
@@ -154,10 +158,50 @@ class UNetEngine:
                 a = a.astype(np.float32)
                 dt = 1
             shape = (C.c_int64 * a.ndim)(*a.shape)
-            self._check(self.lib.dm_engine_load_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), dt,
-                                                       shape, a.ndim), f"load_weight({name})")
+            self._check(fn(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), dt, shape, a.ndim), f"{what}({name})")
+
+    def load_state_dict(self, sd: Dict[str, "np.ndarray"]):
+        """sd: diffusers-named U-Net state dict (numpy or torch tensors, fp16/fp32/bf16)."""
+        self._load(self.lib.dm_engine_load_weight, sd, "load_weight")
         self._check(self.lib.dm_engine_finalize(self._h), "finalize")
         self._finalized = True
+
+    def load_vae_state_dict(self, sd: Dict[str, "np.ndarray"]):
+        """sd: `AutoencoderKL.state_dict()` (`pipe.vae`, compute.py:73); only `encoder.*` and
+        `quant_conv.*` are used, the decoder half is ignored.  Optional: scoring needs only the U-Net."""
+        self._load(self.lib.dm_engine_load_vae_weight, sd, "load_vae_weight")
+        self._check(self.lib.dm_engine_finalize_vae(self._h), "finalize_vae")
+        self._vae_ready = True
+
+    def load_vae_safetensors(self, path: str):
+        """`vae/diffusion_pytorch_model.safetensors` of a diffusers pipeline directory."""
+        from safetensors.numpy import load_file
+        self.load_vae_state_dict(load_file(path))
+
+    def vae_encode(self, image, noise=None, scaling_factor: float = 0.18215, out_dtype=None, return_moments=False):
+        """`vae.encode(image).latent_dist.sample() * scaling_factor` (compute.py:91-93) with the N(0,1) draw
+        injected (`noise` [B,4,H/8,W/8]; None -> posterior mode).  image [B,3,H,W] in [-1,1].
+        Returns latents [B,4,H/8,W/8] (`out_dtype` fp16 default, or fp32) [, moments fp32 [B,8,H/8,W/8]]."""
+        torch = self._torch
+        out_dtype = out_dtype or torch.float16
+        image = image.to(self.device, torch.float16).contiguous()
+        B, c, H, W = image.shape
+        assert c == 3 and H % 8 == 0 and W % 8 == 0, image.shape
+        h, w = H // 8, W // 8
+        if noise is not None:
+            noise = noise.to(self.device, torch.float16).contiguous()
+            assert noise.shape == (B, 4, h, w), noise.shape
+        lat = torch.empty(B, 4, h, w, dtype=out_dtype, device=self.device)
+        mom = torch.empty(B, 8, h, w, dtype=torch.float32, device=self.device) if return_moments else None
+        p16 = C.c_void_p(lat.data_ptr()) if out_dtype == torch.float16 else None
+        p32 = C.c_void_p(lat.data_ptr()) if out_dtype == torch.float32 else None
+        assert p16 or p32, "out_dtype must be torch.float16 or torch.float32"
+        self._check(self.lib.dm_vae_encode(self._h, C.c_void_p(image.data_ptr()),
+                                           C.c_void_p(noise.data_ptr()) if noise is not None else None, B, H, W,
+                                           float(scaling_factor), p16, p32,
+                                           C.c_void_p(mom.data_ptr()) if mom is not None else None, self._stream()),
+                    "dm_vae_encode")
+        return (lat, mom) if return_moments else lat
 
     def load_safetensors(self, path: str):
         """`unet/diffusion_pytorch_model.safetensors` of a diffusers pipeline directory (the format

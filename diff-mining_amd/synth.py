@@ -90,7 +90,8 @@ def hash_normal(name: str, n: int, seed: int = 0) -> np.ndarray:
 def _scale_for(name: str, shape) -> tuple:
     """(kind, scale, offset) for a tensor: value = offset + scale * z."""
     leaf = name.rsplit(".", 1)[1]
-    is_norm = (".norm" in name or name.startswith("conv_norm_out")) and len(shape) == 1
+    mod = name.rsplit(".", 2)[-2]                              # norm1, group_norm, conv_norm_out, ...
+    is_norm = "norm" in mod and len(shape) == 1
     if is_norm:
         return (1.0, 0.1) if leaf == "weight" else (0.0, 0.05)   # gamma ~ 1 +- .1, beta ~ +-.05
     if leaf == "bias":
@@ -116,6 +117,25 @@ def synth_state_dict(cfg: UNetConfig = SD15, seed: int = 0, dtype=np.float32) ->
         t = synth_tensor(name, shape, seed)
         out[name] = t if dtype == np.float32 else t.astype(dtype)
     return out
+
+
+def synth_vae_state_dict(cfg=None, seed: int = 0, dtype=np.float32) -> dict:
+    """Synthetic `encoder.*` / `quant_conv.*` tensors of the SDv1.5 VAE (see vae_spec.py)."""
+    from .vae_spec import SD15_VAE, vae_encoder_tensor_spec
+    out = {}
+    for name, shape in vae_encoder_tensor_spec(cfg or SD15_VAE):
+        t = synth_tensor("vae." + name, shape, seed)
+        out[name] = t if dtype == np.float32 else t.astype(dtype)
+    return out
+
+
+def synth_image(n: int, H: int, W: int, seed: int = 5) -> np.ndarray:
+    """Smooth synthetic RGB images in [-1, 1] (`to_tensor(img) * 2 - 1`, compute.py:126-132), fp16-representable."""
+    z = hash_normal("input.image", n * 3 * H * W, seed).reshape(n, 3, H, W)
+    yy, xx = np.meshgrid(np.linspace(-1, 1, H), np.linspace(-1, 1, W), indexing="ij")
+    base = np.stack([np.sin(3 * xx + k) * np.cos(2 * yy - k) for k in range(3)])[None]
+    img = np.clip(0.6 * base + 0.25 * z, -1.0, 1.0)
+    return img.astype(np.float32).astype(np.float16)
 
 
 def synth_inputs(n_img: int, n_draws: int, h: int, w: int, n_prompts: int = 2,

@@ -130,6 +130,28 @@ int dm_prof_enable(dm_engine* e, int on);
 int dm_prof_read(dm_engine* e, double* igemm_ms, double* igemm_flops, int64_t* igemm_launches,
                  double* attn_ms, double* attn_flops, int64_t* attn_launches);
 
+/* ---- VAE encoder -------------------------------------------------------------
+ * Replaces `self.vae.encode(x).latent_dist.sample() * self.vae.config.scaling_factor`
+ * (diffmining/typicality/compute.py:91-93, called at :137; dift.py:187) so the engine can start from
+ * pixels.  Optional: an engine without VAE weights still scores latents.
+ *
+ * dm_engine_load_vae_weight: one tensor of `AutoencoderKL.state_dict()` by its diffusers name
+ *   (`encoder.*`, `quant_conv.*`; an optional `vae.` prefix is stripped; `decoder.*` and
+ *   `post_quant_conv.*` are accepted and ignored; the pre-0.15 attention names query/key/value/proj_attn
+ *   and their [C,C,1,1] shapes are mapped to to_q/to_k/to_v/to_out.0).  Host memory, DM_F16 or DM_F32.
+ * dm_engine_finalize_vae: checks the 108 encoder tensors (34,163,664 parameters), packs, uploads.
+ * dm_vae_encode: image [batch,3,H,W] fp16 NCHW in [-1,1] (H, W multiples of 8), noise [batch,4,H/8,W/8]
+ *   fp16 = the injected N(0,1) draw of `latent_dist.sample()` (NULL -> posterior mode, mean only).
+ *   Outputs (each optional, at least one): latent fp16 / fp32 [batch,4,H/8,W/8] =
+ *   (mean + exp(0.5 clamp(logvar,-30,20)) * noise) * scaling_factor, and the fp32 moments
+ *   [batch,8,H/8,W/8] (mean | logvar) of `quant_conv(encoder(image))`.                               */
+int dm_engine_load_vae_weight(dm_engine* e, const char* name, const void* host_ptr, int dtype,
+                              const int64_t* shape, int ndim);
+int dm_engine_finalize_vae(dm_engine* e);
+int dm_vae_encode(dm_engine* e, const void* image_dev, const void* noise_dev, int batch, int H, int W,
+                  float scaling_factor, void* latent_f16_dev, void* latent_f32_dev, void* moments_f32_dev,
+                  void* stream);
+
 /* Bytes of device memory currently held by the engine (weights + workspace arena). */
 int dm_engine_memory(dm_engine* e, size_t* weights_bytes, size_t* arena_bytes);
 
@@ -139,7 +161,9 @@ int dm_engine_memory(dm_engine* e, size_t* weights_bytes, size_t* arena_bytes);
  * pointers; activations are NHWC fp16; weights are in the engine's packed layout:
  *   igemm : Y[m][co] = sum_k X~[m][k] Wp[co][k], k = (tap, cin); Wp [Cout][taps*Cin] fp16.
  *           mode 0 dense (1x1 conv / Linear), 1 conv3x3 s1 p1, 2 conv3x3 s2 p1,
- *           3 conv3x3 on the nearest-upsampled (OH x OW) image.  X2 = optional second source
+ *           3 conv3x3 on the nearest-upsampled (OH x OW) image, 4 conv3x3 s2 on F.pad(x,(0,1,0,1))
+ *           (VAE Downsample2D(padding=0)).  Cout must be a multiple of 160 (80-channel waves) or of
+ *           128 (64-channel waves; VAE).  X2 = optional second source
  *           (channel concat cat([X, X2]), as the up blocks do).  epi 1 = GEGLU on quad-interleaved rows.
  *   attention : softmax(Q K^T * scale) V per head, head_dim D in {40, 80, 160}; strides in elements.
  *   groupnorm : (optionally concat) GroupNorm(G) (+SiLU), fp32 statistics; gamma/beta fp32.
@@ -150,6 +174,9 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
 int dm_op_attention(void* stream, const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv,
                     int ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso, const int32_t* kv_slot,
                     int B, int heads, int Tq, int Tk, int D, float scale);
+/* single-head attention with head_dim 512 (VAE mid block): Q/K/V [B][T][ld], O [B][T][ldo] */
+int dm_op_attention512(void* stream, const void* Q, const void* K, const void* V, void* O, int B, int T, int ld,
+                       int ldo, float scale);
 int dm_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, int C, int C1, int G, float eps,
                     const float* gamma, const float* beta, int silu, void* Y);
 int dm_op_layernorm(void* stream, const void* X, int rows, int C, const float* gamma, const float* beta, float eps,

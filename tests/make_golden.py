@@ -1,6 +1,6 @@
 """Generates the committed golden vectors under tests/golden/ from the CPU oracle.
 
-    python tests/make_golden.py
+    python tests/make_golden.py            (add --vae-only to regenerate just the VAE fixture)
 
 Inputs come from the integer-hash generator (diff-mining_amd/synth.py), weights are NOT stored
 (regenerated deterministically, seed 0); outputs are the oracle's.  The reference itself cannot
@@ -20,8 +20,25 @@ from oracle import unet_ref as R  # noqa: E402
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
+def vae():
+    """VAE encoder at 64x64 (latent 8x8): image, injected draw -> moments, latents (autocast oracle)."""
+    from oracle import vae_ref
+    os.makedirs(OUT, exist_ok=True)
+    sd = {k: torch.from_numpy(v).float() for k, v in synth.synth_vae_state_dict(seed=0, dtype=np.float16).items()}
+    img = synth.synth_image(2, 64, 64)
+    noise = synth.hash_normal("input.vae_noise", 2 * 4 * 8 * 8, 42).reshape(2, 4, 8, 8).astype(np.float32).astype(np.float16)
+    lat, mom = vae_ref.vae_encode(sd, torch.from_numpy(img).float(), torch.from_numpy(noise).float(), autocast=True)
+    np.savez_compressed(os.path.join(OUT, "vae_64x64.npz"), image=img, noise=noise, moments=mom.numpy(), latents=lat.numpy())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--vae-only" in sys.argv:
+        vae()
+        for f in sorted(os.listdir(OUT)):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+        return
+    vae()
     sd = {k: torch.from_numpy(v).float() for k, v in synth.synth_state_dict(seed=0, dtype=np.float16).items()}
     # scoring, latent 8x8, 2 draws x 2 prompts
     x, eps, t, c = synth.synth_inputs(1, 2, 8, 8)

@@ -5,6 +5,7 @@ build-owned structural pins: parameter/tensor counts of the public SDv1.5 U-Net,
 sinusoid known answers, shape walks, and algebraic properties of the scoring surface.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -170,3 +171,69 @@ def test_synth_weights_are_deterministic_and_fp16():
         np.uint64(synth.fnv1a64("conv_in.weight")) ^ synth._splitmix64(
             np.array([0], dtype=np.uint64) + synth._GOLDEN)[0], 0, 4))
     assert synth.fnv1a64("a") == 0xAF63DC4C8601EC8C
+
+
+# ---- VAE encoder oracle (oracle/vae_ref.py) -----------------------------------
+def _vae_sd():
+    from diff_mining_amd import synth
+    return {k: torch.from_numpy(v) for k, v in synth.synth_vae_state_dict(seed=0).items()}
+
+
+def test_vae_spec_counts_and_names():
+    """Known answers of the public SDv1.5 VAE: the encoder has 34,163,592 parameters, quant_conv 72."""
+    from diff_mining_amd.vae_spec import canonical_vae_name, vae_encoder_param_count, vae_encoder_tensor_spec
+    spec = vae_encoder_tensor_spec()
+    assert len(spec) == 108 and len({n for n, _ in spec}) == 108
+    assert vae_encoder_param_count() == 34_163_592 + 72
+    names = {n for n, _ in spec}
+    assert "encoder.mid_block.attentions.0.to_out.0.weight" in names
+    assert "encoder.down_blocks.1.resnets.0.conv_shortcut.weight" in names
+    assert "encoder.down_blocks.3.downsamplers.0.conv.weight" not in names
+    assert canonical_vae_name("vae.encoder.mid_block.attentions.0.proj_attn.bias") == "encoder.mid_block.attentions.0.to_out.0.bias"
+    assert canonical_vae_name("decoder.conv_in.weight") is None
+
+
+def test_vae_oracle_uses_every_tensor_and_shapes():
+    from diff_mining_amd import synth
+    from oracle import vae_ref
+    sd = _vae_sd()
+    used = set()
+    img = torch.from_numpy(synth.synth_image(2, 64, 96)).float()
+    m = vae_ref.vae_moments(sd, img, autocast=False, used_keys=used)
+    assert used == set(sd.keys())
+    assert m.shape == (2, 8, 8, 12) and torch.isfinite(m).all()
+    m16 = vae_ref.vae_moments(sd, img, autocast=True)
+    rel = ((m16 - m).norm() / m.norm()).item()
+    assert rel < 5e-3, rel
+
+
+def test_vae_oracle_algebra():
+    """Zero conv_out weight => moments = quant_conv(bias) everywhere; mode = mean * scaling; the draw enters
+    as mean + exp(0.5 logvar) * noise; logvar is clamped to [-30, 20]; batch-permutation equivariance."""
+    from diff_mining_amd import synth
+    from oracle import vae_ref
+    sd = _vae_sd()
+    img = torch.from_numpy(synth.synth_image(2, 32, 32)).float()
+    m = vae_ref.vae_moments(sd, img, autocast=False)
+    mp = vae_ref.vae_moments(sd, img.flip(0), autocast=False)
+    assert torch.allclose(mp.flip(0), m, atol=1e-5)
+    z = dict(sd)
+    z["encoder.conv_out.weight"] = torch.zeros_like(sd["encoder.conv_out.weight"])
+    mz = vae_ref.vae_moments(z, img, autocast=False)
+    want = sd["quant_conv.weight"].view(8, 8) @ sd["encoder.conv_out.bias"] + sd["quant_conv.bias"]
+    assert torch.allclose(mz, want.view(1, 8, 1, 1).expand_as(mz), atol=1e-6)
+    noise = torch.randn(2, 4, 4, 4, generator=torch.Generator().manual_seed(0))
+    lat = vae_ref.posterior_sample(m, noise)
+    assert torch.allclose(lat, (m[:, :4] + torch.exp(0.5 * m[:, 4:]) * noise) * 0.18215, atol=1e-6)
+    assert torch.equal(vae_ref.posterior_sample(m, None), m[:, :4] * 0.18215)
+    big = m.clone()
+    big[:, 4:] = 100.0
+    assert torch.allclose(vae_ref.posterior_sample(big, noise), (m[:, :4] + np.exp(10.0) * noise) * 0.18215, rtol=1e-5)
+
+
+def test_vae_golden_reproduces():
+    from oracle import vae_ref
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vae_64x64.npz"))
+    sd = _vae_sd()
+    lat, mom = vae_ref.vae_encode(sd, torch.from_numpy(g["image"]).float(), torch.from_numpy(g["noise"]).float(), autocast=True)
+    assert np.array_equal(mom.numpy(), g["moments"]) and np.array_equal(lat.numpy(), g["latents"])
