@@ -40,8 +40,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--images", type=int, default=N_IMG)
-    ap.add_argument("--workload", choices=["typicality", "dift", "xray"], default="typicality",
-                    help="typicality = BASELINE configs[1]/[2] (the graded line); dift = configs[3]; xray = configs[4]")
+    ap.add_argument("--workload", choices=["typicality", "dift", "xray", "vae", "pixels"], default="typicality",
+                    help="typicality = BASELINE configs[1]/[2] (the graded line); dift = configs[3]; xray = configs[4]; "
+                         "vae = SURVEY 8f rank 2 (VAE encode of 8 images @512px); pixels = vae + typicality from images")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -169,6 +170,27 @@ def side_workload(args, eng, dev):
         def step():
             return eng.dift(noisy, tt, slots, 1, ens)[1]
         units, name, flop = n_lat, "DIFT-161 images/s (ensemble 8, tap up_blocks[1], batch 64 @64x64 latent)", 438.79e9 * ens
+    elif args.workload in ("vae", "pixels"):
+        n_img, lat = N_IMG, LAT
+        eng.load_vae_state_dict(synth.synth_vae_state_dict(seed=0, dtype=np.float16))
+        img = torch.from_numpy(synth.synth_image(n_img, lat * 8, lat * 8)).to(dev)
+        _, eps, t, c = synth.synth_inputs(n_img, N_DRAWS, lat, lat)
+        vnoise = torch.from_numpy(synth.synth_inputs(n_img, 1, lat, lat)[0]).to(dev)
+        eu, tu = torch.from_numpy(eps).to(dev).repeat(n_img, 1, 1, 1), torch.from_numpy(t).to(dev).repeat(n_img)
+        xi = torch.arange(n_img, dtype=torch.int32, device=dev).repeat_interleave(N_DRAWS)
+        eng.set_prompts(torch.from_numpy(c).to(dev))
+        vae_flop = 1116.66e9                                     # encoder @512x512, 2 FLOP/MAC incl. attention
+        if args.workload == "vae":
+            def step():
+                return eng.vae_encode(img, vnoise)
+            units, name, flop = n_img, "VAE-encoded images/s (SDv1.5 AutoencoderKL encoder + posterior sample, 512x512, batch 8)", vae_flop
+        else:
+            def step():
+                x = eng.vae_encode(img, vnoise)
+                loss = eng.score_conds(x, eu, tu, N_COND, xi)
+                return loss.view(N_COND, n_img, N_DRAWS, -1).mean(dim=(2, 3))
+            units, name, flop = n_img, ("typicality-scored images/s from pixels (VAE encode + 10 t x 2 prompts, 512px, "
+                                        "batch 8)"), vae_flop + 20 * 803.27e9
     else:
         lat = 128
         x, eps, t, c = synth.synth_inputs(1, N_DRAWS, lat, lat)

@@ -62,25 +62,29 @@ __global__ void gn_stats_partial(const f16* __restrict__ X, const f16* __restric
     }
 }
 
-// one thread per (n, g): mean/rstd in fp64, then the per-channel affine of that group:
+// one wavefront per (n, g): the per-chunk partial sums are combined in fp64 in a fixed order (lane-strided
+// sums, then an xor-shuffle tree: deterministic), then the per-channel affine of that group is emitted:
 //   y = x * a + b,  a = rstd * gamma[c],  b = beta[c] - mean * a      (ab[n][c] = {a, b})
 __global__ void gn_stats_final(const double* __restrict__ partial, int total, int chunks, int G, int C, double count,
                                float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
                                float* __restrict__ ab) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // n*G + g
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // n*G + g
     if (i >= total) return;
     const int n = i / G, g = i - n * G;
     double ds = 0.0, dq = 0.0;
-    for (int c = 0; c < chunks; ++c) {
+    for (int c = lane; c < chunks; c += 64) {
         const double* in = partial + (((size_t)n * chunks + c) * G + g) * 2;
         ds += in[0]; dq += in[1];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
     const double mean = ds / count;
     double var = dq / count - mean * mean;
     var = var > 0.0 ? var : 0.0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
     const int cpg = C / G;
-    for (int k = 0; k < cpg; ++k) {
+    for (int k = lane; k < cpg; k += 64) {
         const int c = g * cpg + k;
         const double a = rstd * (double)gamma[c];
         ab[((size_t)n * C + c) * 2 + 0] = (float)a;
@@ -194,7 +198,7 @@ hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, in
     const size_t lds = (size_t)R * C * 2 * sizeof(float);
     hipLaunchKernelGGL(gn_stats_partial, dim3(chunks, N), dim3(threads), lds, s, X, X2 ? X2 : X, HW, C, C1, G, R, gn_pix(HW), partial);
     const int tot = N * G;
-    hipLaunchKernelGGL(gn_stats_final, dim3((tot + 63) / 64), dim3(64), 0, s, partial, tot, chunks, G, C,
+    hipLaunchKernelGGL(gn_stats_final, dim3((tot + 3) / 4), dim3(256), 0, s, partial, tot, chunks, G, C,
                        (double)HW * (double)(C / G), eps, gamma, beta, ab);
     return hipGetLastError();
 }

@@ -2,6 +2,8 @@
 
     reference                                         here
     ------------------------------------------------  -----------------------------------------
+    SD.encode_vae            compute.py:91-93         TypicalityScorer.encode_vae (optional: needs VAE weights)
+    D.load_image             compute.py:126-132       TypicalityScorer.load_image
     SD.compute_loss          compute.py:95-102        TypicalityScorer.compute_loss
     D.noising                compute.py:115-124       TypicalityScorer.noising / draw
     D.compute_losses         compute.py:134-160       TypicalityScorer.compute_losses
@@ -11,7 +13,8 @@
 
 Same names, argument meaning and output layout ([N, n_cond, 4, h, w] float16, cond 0 = c,
 1 = null); differences are stated where they exist:
-  * the engine starts from the latent `x` (the VAE encode of compute.py:137 is outside the path);
+  * `compute_losses` takes the latent `x`; `compute_losses_from_image` runs the VAE encode of
+    compute.py:137 on the engine too (the posterior draw is injected: the reference's is unseeded);
   * all N draws of an image are scored in as few U-Net batches as the engine's workspace allows
     instead of B-sized chunks with a D2H copy each (compute.py:145-156) — `B` is accepted and
     ignored for the result (it never changes the math, only the chunking);
@@ -75,6 +78,30 @@ class TypicalityScorer:
         self.num_train_timesteps = num_train_timesteps
         self.generator_device = generator_device
         self.unet = UNetCallable(engine)
+
+    # -- D.load_image / SD.encode_vae (compute.py:126-132, 91-93) --------------------------------
+    @staticmethod
+    def load_image(x) -> torch.Tensor:
+        """PIL image or uint8 HWC array -> [1,3,H,W] float in [-1,1] (`to_tensor(x) * 2 - 1`)."""
+        a = np.asarray(x.convert("RGB") if hasattr(x, "convert") else x)
+        assert a.ndim == 3 and a.shape[2] == 3 and a.dtype == np.uint8, (a.shape, a.dtype)
+        return (torch.from_numpy(a.copy()).permute(2, 0, 1).float() / 255.0 * 2 - 1).unsqueeze(0)
+
+    @torch.no_grad()
+    def encode_vae(self, x, noise=None, generator: Optional[torch.Generator] = None, scaling_factor: float = 0.18215):
+        """`vae.encode(x).latent_dist.sample() * scaling_factor` -> [B,4,H/8,W/8] fp16 latents on the GPU.
+        The posterior draw: `noise` if given, else N(0,1) from `generator` (CPU) — the reference draws it
+        unseeded on the device before `manual_seed(seed)` (compute.py:137-139)."""
+        B, _, H, W = x.shape
+        if noise is None:
+            noise = torch.randn(B, 4, H // 8, W // 8, generator=generator, dtype=torch.float32).to(torch.float16)
+        return self.engine.vae_encode(x, noise, scaling_factor)
+
+    @torch.no_grad()
+    def compute_losses_from_image(self, img, country_embeds, B: int = 10, vae_noise=None, to_host: bool = True):
+        """`D.compute_losses(img, country_embeds)` from pixels: VAE encode, then the N x n_cond scoring grid."""
+        x = self.encode_vae(img if torch.is_tensor(img) else self.load_image(img), vae_noise)
+        return self.compute_losses(x, country_embeds, B, to_host=to_host)
 
     # -- SD.compute_loss (compute.py:95-102) -----------------------------------------------------
     @torch.no_grad()

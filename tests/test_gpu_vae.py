@@ -214,3 +214,33 @@ def test_vae_legacy_attention_names(vae_sd):
         assert torch.equal(e1.vae_encode(img), e2.vae_encode(img))
     finally:
         e1.close(); e2.close()
+
+
+def test_image_to_typicality_grid(vae_engine, vae_sd, sd15_weights_f16):
+    """Pixels -> latents -> [N,2,4,h,w] grid on one engine (compute.py:134-160 incl. :137), against the
+    two oracles chained the same way."""
+    from diff_mining_amd import synth
+    from diff_mining_amd.typicality import TypicalityScorer
+    from oracle import unet_ref as R
+    from oracle import vae_ref
+    eng = vae_engine
+    if not eng._finalized:
+        eng.load_state_dict(sd15_weights_f16)
+    sc = TypicalityScorer(eng, seed=42, N=2, t_min=0.1, t_max=0.7)
+    img = torch.from_numpy(synth.synth_image(1, 64, 64))
+    vnoise = U.f16_randn(1, 4, 8, 8, seed=51)
+    _, _, _, c = synth.synth_inputs(1, 2, 8, 8)
+    c = torch.from_numpy(c)
+    grid = sc.compute_losses_from_image(img, c, vae_noise=vnoise)
+    assert grid.shape == (2, 2, 4, 8, 8) and grid.dtype == torch.float16
+    vsd = {k: torch.from_numpy(v).float() for k, v in vae_sd.items()}
+    usd = {k: torch.from_numpy(v).float() for k, v in sd15_weights_f16.items()}
+    x_ref, _ = vae_ref.vae_encode(vsd, img.float(), vnoise.float(), autocast=True)
+    noises, ts = sc.draw((1, 4, 8, 8))
+    ref = R.compute_losses(usd, x_ref.half(), c.float(), noises, ts, B=2)
+    assert U.rel_l2(grid, ref) < 8e-3
+    # uint8 image path: load_image reproduces to_tensor(x) * 2 - 1
+    u8 = ((img[0].permute(1, 2, 0).float().numpy() + 1) * 127.5).round().clip(0, 255).astype(np.uint8)
+    t = sc.load_image(u8)
+    assert t.shape == (1, 3, 64, 64) and float(t.min()) >= -1 and float(t.max()) <= 1
+    assert torch.allclose(t, torch.from_numpy(u8).permute(2, 0, 1)[None].float() / 255 * 2 - 1)
