@@ -89,8 +89,12 @@ hipError_t launch_im2col_rgb(const f16* x, int B, int H, int W, f16* out, hipStr
 // single-head attention, head_dim 512: Q/K/V [B][T][ld], O [B][T][ldo]
 hipError_t launch_attention512(const f16* Q, const f16* K, const f16* V, f16* O, int B, int T, int ld, int ldo,
                                float scale, hipStream_t s);
-// quant_conv (1x1, 8->8) on the first 8 channels of Hm [B*HW][ldh] + posterior sample * scaling (NCHW outputs)
-hipError_t launch_posterior(const f16* Hm, int ldh, const f16* qw, const f16* qb, const f16* noise, int B, int HW,
-                            float scaling, f16* latent16, float* latent32, float* moments, hipStream_t s);
+// quant_conv (1x1, 8->8) on the first 8 channels of Hm [B*HW][ldh] + `draws` posterior samples per image * scaling
+// (NCHW outputs: latents [B*draws,4,HW], moments [B,8,HW])
+hipError_t launch_posterior(const f16* Hm, int ldh, const f16* qw, const f16* qb, const f16* noise, int B, int draws,
+                            int HW, float scaling, f16* latent16, float* latent32, float* moments, hipStream_t s);
+// DIFT patch descriptors (cluster.py:291-299): out[p][c] = mean of feat[c][r0:r1, c0:c1], L2-normalised over c;
+// feat [C][h][w] fp32, boxes [P][4] = (r0, r1, c0, c1) in feature cells
+hipError_t launch_patch_embed(const float* feat, int C, int h, int w, const int32_t* boxes, int P, float* out, hipStream_t s);
 
 }  // namespace dm

@@ -719,7 +719,7 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
 
 // ---- VAE encoder: image -> moments -> latent (compute.py:91-93) ---------------------------------
 struct VaeArgs {
-    const f16* image; const f16* noise; int B, H, W; float scaling;
+    const f16* image; const f16* noise; int B, draws, H, W; float scaling;
     f16* latent16; float* latent32; float* moments;
 };
 
@@ -775,7 +775,7 @@ int run_vae(dm_engine* e, const VaeArgs& A, hipStream_t s, bool dry) {
     F.free(cur);
     DM_TRY(F.igemm(v.conv_out, IG_CONV3, nrm, nullptr, nrm.H, nrm.W, nullptr, 0, nullptr, EPI_PLAIN, &co));
     F.free(nrm);
-    if (!dry) DM_HIP(e, launch_posterior(co.p, co.C, v.qw, v.qb, A.noise, A.B, co.H * co.W, A.scaling, A.latent16, A.latent32,
+    if (!dry) DM_HIP(e, launch_posterior(co.p, co.C, v.qw, v.qb, A.noise, A.B, A.draws, co.H * co.W, A.scaling, A.latent16, A.latent32,
                                          A.moments, s));
     F.free(co);
     return 0;
@@ -1134,12 +1134,14 @@ int dm_engine_finalize_vae(dm_engine* e) {
     return 0;
 }
 
-int dm_vae_encode(dm_engine* e, const void* image_dev, const void* noise_dev, int batch, int H, int W, float scaling_factor,
-                  void* latent_f16_dev, void* latent_f32_dev, void* moments_f32_dev, void* stream) {
+int dm_vae_encode(dm_engine* e, const void* image_dev, const void* noise_dev, int batch, int draws_per_image, int H, int W,
+                  float scaling_factor, void* latent_f16_dev, void* latent_f32_dev, void* moments_f32_dev, void* stream) {
     if (!e) return 1;
     if (!e->vae_ready) DM_FAIL(e, "dm_vae_encode: VAE weights not loaded (dm_engine_finalize_vae)");
     if (!image_dev || (!latent_f16_dev && !latent_f32_dev && !moments_f32_dev)) DM_FAIL(e, "dm_vae_encode: null argument");
     if (batch <= 0 || H < 8 || W < 8 || (H % 8) || (W % 8)) DM_FAIL(e, "dm_vae_encode: H and W must be positive multiples of 8");
+    if (draws_per_image < 1 || (draws_per_image > 1 && !noise_dev)) DM_FAIL(e, "dm_vae_encode: draws_per_image > 1 needs the noise draws");
+    const int D = draws_per_image;
     DM_HIP(e, hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
     const size_t ipx = (size_t)H * W, lpx = (size_t)(H / 8) * (W / 8);
@@ -1148,15 +1150,24 @@ int dm_vae_encode(dm_engine* e, const void* image_dev, const void* noise_dev, in
     for (int b0 = 0; b0 < batch; b0 += (int)chunk) {
         VaeArgs A{};
         A.B = (batch - b0 < chunk) ? (batch - b0) : (int)chunk;
-        A.H = H; A.W = W; A.scaling = scaling_factor;
+        A.H = H; A.W = W; A.scaling = scaling_factor; A.draws = D;
         A.image = (const f16*)image_dev + (size_t)b0 * 3 * ipx;
-        A.noise = noise_dev ? (const f16*)noise_dev + (size_t)b0 * 4 * lpx : nullptr;
-        A.latent16 = latent_f16_dev ? (f16*)latent_f16_dev + (size_t)b0 * 4 * lpx : nullptr;
-        A.latent32 = latent_f32_dev ? (float*)latent_f32_dev + (size_t)b0 * 4 * lpx : nullptr;
+        A.noise = noise_dev ? (const f16*)noise_dev + (size_t)b0 * D * 4 * lpx : nullptr;
+        A.latent16 = latent_f16_dev ? (f16*)latent_f16_dev + (size_t)b0 * D * 4 * lpx : nullptr;
+        A.latent32 = latent_f32_dev ? (float*)latent_f32_dev + (size_t)b0 * D * 4 * lpx : nullptr;
         A.moments = moments_f32_dev ? (float*)moments_f32_dev + (size_t)b0 * 8 * lpx : nullptr;
         DM_TRY(ensure_arena_for(e, s, [&]() { return run_vae(e, A, s, true); }));
         DM_TRY(run_vae(e, A, s, false));
     }
+    return 0;
+}
+
+int dm_patch_embed(dm_engine* e, const void* feat_f32_dev, int C, int h, int w, const int32_t* boxes_dev, int n_patches,
+                   void* out_f32_dev, void* stream) {
+    if (!e) return 1;
+    if (!feat_f32_dev || !boxes_dev || !out_f32_dev) DM_FAIL(e, "dm_patch_embed: null argument");
+    DM_HIP(e, hipSetDevice(e->device));
+    DM_HIP(e, launch_patch_embed((const float*)feat_f32_dev, C, h, w, boxes_dev, n_patches, (float*)out_f32_dev, (hipStream_t)stream));
     return 0;
 }
 

@@ -251,6 +251,42 @@ __global__ void mean_reduce_kernel(const float* __restrict__ map, int n, float* 
 
 }  // namespace
 
+// DIFT patch descriptor: window mean of every channel of the ensemble-mean feature map, then L2
+// normalisation across channels (cluster.py:291-299: emb[:, r0:r1, c0:c1].mean((1,2)); emb / ||emb||).
+// One block per patch; a wavefront per channel (lanes stride over the window), means staged in LDS.
+// An empty window gives NaN like numpy's mean of an empty slice.
+__global__ __launch_bounds__(256)
+void patch_embed_kernel(const float* __restrict__ feat, int C, int h, int w, const int32_t* __restrict__ boxes,
+                        float* __restrict__ out) {
+    extern __shared__ float mean_s[];            // [C] + 4 partial sums
+    const int pch = blockIdx.x;
+    int r0 = boxes[pch * 4 + 0], r1 = boxes[pch * 4 + 1], c0 = boxes[pch * 4 + 2], c1 = boxes[pch * 4 + 3];
+    r0 = r0 < 0 ? 0 : r0; c0 = c0 < 0 ? 0 : c0; r1 = r1 > h ? h : r1; c1 = c1 > w ? w : c1;   // numpy slice clamping
+    const int wh = r1 > r0 ? r1 - r0 : 0, ww = c1 > c0 ? c1 - c0 : 0;
+    const int npx = wh * ww;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c = wv; c < C; c += 4) {
+        const float* f = feat + (size_t)c * h * w;
+        float s = 0.f;
+        for (int i = lane; i < npx; i += 64) {
+            const int r = i / ww, col = i - r * ww;
+            s += f[(r0 + r) * w + c0 + col];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) mean_s[c] = s / (float)npx;                 // 0/0 = NaN for an empty window
+    }
+    __syncthreads();
+    float q = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) q += mean_s[c] * mean_s[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) mean_s[C + wv] = q;
+    __syncthreads();
+    const float inv = 1.0f / sqrtf(mean_s[C] + mean_s[C + 1] + mean_s[C + 2] + mean_s[C + 3]);
+    for (int c = threadIdx.x; c < C; c += 256) out[(size_t)pch * C + c] = mean_s[c] * inv;
+}
+
 hipError_t launch_time_gather(const f16* table, const int64_t* t, int B, int dim, f16* out, hipStream_t s) {
     hipLaunchKernelGGL(time_gather_kernel, dim3((B * dim + 255) / 256), dim3(256), 0, s, table, t, B, dim, out);
     return hipGetLastError();
@@ -309,6 +345,12 @@ hipError_t launch_typicality_image(const float* map, int h, int w, int H, int W,
     hipLaunchKernelGGL(upsample_rowsum_kernel, dim3((H * OWd + 255) / 256), dim3(256), 0, s, map, h, w, H, W, ky, tmp);
     hipLaunchKernelGGL(colsum_kernel, dim3((OHd * OWd + 255) / 256), dim3(256), 0, s, tmp, H, OWd, kx,
                        1.0f / ((float)kx * (float)ky), out);
+    return hipGetLastError();
+}
+
+hipError_t launch_patch_embed(const float* feat, int C, int h, int w, const int32_t* boxes, int P, float* out, hipStream_t s) {
+    if (C <= 0 || h <= 0 || w <= 0 || P <= 0 || C > 8192) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(patch_embed_kernel, dim3(P), dim3(256), (size_t)(C + 4) * sizeof(float), s, feat, C, h, w, boxes, out);
     return hipGetLastError();
 }
 

@@ -204,15 +204,17 @@ void attn512_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const 
 
 // moments = quant_conv(h) (fp16 out, fp32 accumulate), mean | logvar = chunk(moments, 2, C);
 // latent = (mean + exp(0.5 clamp(logvar, -30, 20)) * noise) * scaling   (fp32; noise == nullptr -> mode)
+// `draws` posterior samples per image: output sample bo = b * draws + d reads the moments of image b.
 __global__ void posterior_kernel(const f16* __restrict__ Hm, int ldh, const f16* __restrict__ qw /* [8][8] */,
-                                 const f16* __restrict__ qb, const f16* __restrict__ noise, int B, int HW,
+                                 const f16* __restrict__ qb, const f16* __restrict__ noise, int B, int draws, int HW,
                                  float scaling, f16* __restrict__ latent16, float* __restrict__ latent32,
                                  float* __restrict__ moments) {
     const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= (long long)B * HW) return;
-    const int b = (int)(pix / HW);
-    const int rem = (int)(pix - (long long)b * HW);
-    const half8 hv = *reinterpret_cast<const half8*>(Hm + pix * ldh);
+    if (pix >= (long long)B * draws * HW) return;
+    const int bo = (int)(pix / HW);
+    const int rem = (int)(pix - (long long)bo * HW);
+    const int b = bo / draws;
+    const half8 hv = *reinterpret_cast<const half8*>(Hm + ((size_t)b * HW + rem) * ldh);
     float m[8];
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
@@ -221,7 +223,7 @@ __global__ void posterior_kernel(const f16* __restrict__ Hm, int ldh, const f16*
         for (int i = 0; i < 8; ++i) acc += (float)qw[o * 8 + i] * (float)hv[i];
         acc += (float)qb[o];
         m[o] = (float)(f16)acc;
-        if (moments) moments[((size_t)b * 8 + o) * HW + rem] = m[o];
+        if (moments && bo == b * draws) moments[((size_t)b * 8 + o) * HW + rem] = m[o];
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -229,10 +231,10 @@ __global__ void posterior_kernel(const f16* __restrict__ Hm, int ldh, const f16*
         if (noise) {
             float lv = m[4 + c];
             lv = lv < -30.f ? -30.f : (lv > 20.f ? 20.f : lv);
-            v += expf(0.5f * lv) * (float)noise[((size_t)b * 4 + c) * HW + rem];
+            v += expf(0.5f * lv) * (float)noise[((size_t)bo * 4 + c) * HW + rem];
         }
         v *= scaling;
-        const size_t o = ((size_t)b * 4 + c) * HW + rem;
+        const size_t o = ((size_t)bo * 4 + c) * HW + rem;
         if (latent16) latent16[o] = (f16)v;
         if (latent32) latent32[o] = v;
     }
@@ -258,11 +260,11 @@ hipError_t launch_attention512(const f16* Q, const f16* K, const f16* V, f16* O,
     return hipGetLastError();
 }
 
-hipError_t launch_posterior(const f16* Hm, int ldh, const f16* qw, const f16* qb, const f16* noise, int B, int HW,
-                            float scaling, f16* latent16, float* latent32, float* moments, hipStream_t s) {
-    const long long total = (long long)B * HW;
+hipError_t launch_posterior(const f16* Hm, int ldh, const f16* qw, const f16* qb, const f16* noise, int B, int draws,
+                            int HW, float scaling, f16* latent16, float* latent32, float* moments, hipStream_t s) {
+    const long long total = (long long)B * draws * HW;
     hipLaunchKernelGGL(posterior_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Hm, ldh, qw, qb, noise,
-                       B, HW, scaling, latent16, latent32, moments);
+                       B, draws, HW, scaling, latent16, latent32, moments);
     return hipGetLastError();
 }
 

@@ -3,13 +3,16 @@ the HIP engine.
 
 `SDFeaturizer.forward(latents, prompt_embeds, t=261, up_ft_index=1, ensemble_size=8)` keeps the
 reference's argument meaning and its output `[1, C, H/16, W/16]` (for up_ft_index=1), with two
-stated differences: the input is the scaled VAE latent (the VAE encode of dift.py:187 is outside
-the path; the reference draws `ensemble_size` posterior samples of the same image there), and the
-prompt arrives as CLIP hidden states `[1,77,768]` rather than as a string (text tower is outside).
+stated differences: `forward` takes the scaled VAE latent(s) (`forward_image` starts from pixels like
+dift.py:214-232 when VAE weights are loaded — one encoder pass, `ensemble_size` posterior samples), and
+the prompt arrives as CLIP hidden states `[1,77,768]` rather than as a string (text tower is outside).
+`patch_embeddings` is the DIFT branch of `Cluster.compute_embeddings` (cluster.py:288-299) with a
+per-image cache of the feature map.
 """
 from __future__ import annotations
 
-from typing import Optional
+from collections import OrderedDict
+from typing import Optional, Sequence, Tuple
 
 import torch
 
@@ -21,11 +24,23 @@ def scheduler_alphas_cumprod(n: int = 1000, beta_start: float = 0.00085, beta_en
     return torch.cumprod(1.0 - betas, dim=0)
 
 
+def feature_boxes(boxes_px: Sequence[Tuple[int, int, int, int]], image_hw: Tuple[int, int],
+                  feat_hw: Tuple[int, int]) -> torch.Tensor:
+    """Pixel boxes (x_start, y_start, x_end, y_end; x = rows, y = columns, cluster.py:258-262) -> feature
+    cells (r0, r1, c0, c1) with the reference's arithmetic `int(x * (h / image.height))` (cluster.py:292-296)."""
+    H = feat_hw[0] / image_hw[0]
+    W = feat_hw[1] / image_hw[1]
+    return torch.tensor([[int(x0 * H), int(x1 * H), int(y0 * W), int(y1 * W)] for (x0, y0, x1, y1) in boxes_px],
+                        dtype=torch.int32).reshape(-1, 4)
+
+
 class SDFeaturizer:
-    def __init__(self, engine: UNetEngine):
+    def __init__(self, engine: UNetEngine, cache_size: int = 64):
         self.engine = engine
         self.device = engine.device
         self.acp = scheduler_alphas_cumprod().to(self.device)
+        self._cache: "OrderedDict[object, torch.Tensor]" = OrderedDict()   # key -> ensemble-mean map on the GPU
+        self.cache_size = cache_size
 
     def add_noise(self, latents, noise, t):
         """DDIMScheduler.add_noise in the latents' dtype (dift.py:190; fp32 in the reference)."""
@@ -52,3 +67,41 @@ class SDFeaturizer:
         return mean
 
     __call__ = forward
+
+    @torch.no_grad()
+    def forward_image(self, img_tensor, prompt_embeds, t: int = 261, up_ft_index: int = 1, ensemble_size: int = 8,
+                      vae_noise=None, noise=None, generator: Optional[torch.Generator] = None):
+        """`SDFeaturizer.forward(img_tensor, ...)` from pixels (dift.py:214-232): the reference encodes the
+        image `ensemble_size` times and takes one posterior sample of each (dift.py:220,187); here the VAE
+        encoder runs once and `ensemble_size` posterior samples are drawn from its moments (same distribution).
+        img_tensor [3,H,W] or [1,3,H,W] in [-1,1] (`dift_pre`, dift.py:19-21).  Needs VAE weights."""
+        img = img_tensor if img_tensor.dim() == 4 else img_tensor[None]
+        _, _, H, W = img.shape
+        if vae_noise is None:
+            vae_noise = torch.randn(ensemble_size, 4, H // 8, W // 8, generator=generator, dtype=torch.float32)
+        lat = self.engine.vae_encode(img, vae_noise.to(torch.float16), out_dtype=torch.float32,
+                                     draws_per_image=ensemble_size)
+        return self.forward(lat, prompt_embeds, t, up_ft_index, ensemble_size, noise=noise, generator=generator)
+
+    # -- Cluster.compute_embeddings' DIFT branch (cluster.py:288-299) ------------------------------
+    @torch.no_grad()
+    def patch_embeddings(self, feat_or_key, boxes_px, image_hw, compute=None):
+        """L2-normalised window-mean descriptors [P, C] (fp32, GPU) of all patches of ONE image in a single
+        launch.  The reference re-runs the full DIFT forward for every patch row of the dataframe
+        (cluster.py:291: up to 5 per image); here the ensemble-mean map is computed once per image and kept
+        in a small LRU cache: `feat_or_key` is either the map itself ([1,C,h,w] / [C,h,w]) or a hashable
+        cache key (e.g. (image path, prompt, t)) with `compute()` -> map called on a miss."""
+        if torch.is_tensor(feat_or_key):
+            feat = feat_or_key
+        else:
+            feat = self._cache.get(feat_or_key)
+            if feat is None:
+                assert compute is not None, "cache miss and no compute() given"
+                feat = compute().to(self.device, torch.float32)
+                self._cache[feat_or_key] = feat
+                while len(self._cache) > self.cache_size:
+                    self._cache.popitem(last=False)
+            else:
+                self._cache.move_to_end(feat_or_key)
+        fh, fw = feat.shape[-2], feat.shape[-1]
+        return self.engine.patch_embed(feat, feature_boxes(boxes_px, image_hw, (fh, fw)))

@@ -22,7 +22,7 @@ SYMBOLS = [
     "dm_engine_set_prompts", "dm_score", "dm_score_conds", "dm_unet_forward", "dm_dift", "dm_dift_shape",
     "dm_reduce_typicality", "dm_typicality_image", "dm_prof_enable", "dm_prof_read", "dm_engine_memory",
     "dm_op_igemm", "dm_op_attention", "dm_op_groupnorm", "dm_op_layernorm",
-    "dm_engine_load_vae_weight", "dm_engine_finalize_vae", "dm_vae_encode", "dm_op_attention512",
+    "dm_engine_load_vae_weight", "dm_engine_finalize_vae", "dm_vae_encode", "dm_op_attention512", "dm_patch_embed",
 ]
 
 
@@ -73,7 +73,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_op_layernorm.argtypes = [vp, vp, i32, i32, vp, vp, C.c_float, vp]
     lib.dm_engine_load_vae_weight.argtypes = [vp, C.c_char_p, vp, i32, C.POINTER(i64), i32]
     lib.dm_engine_finalize_vae.argtypes = [vp]
-    lib.dm_vae_encode.argtypes = [vp, vp, vp, i32, i32, i32, C.c_float, vp, vp, vp, vp]
+    lib.dm_vae_encode.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.c_float, vp, vp, vp, vp]
+    lib.dm_patch_embed.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
     lib.dm_op_attention512.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float]
     if path is None:
         _lib = lib
@@ -178,10 +179,12 @@ class UNetEngine:
         from safetensors.numpy import load_file
         self.load_vae_state_dict(load_file(path))
 
-    def vae_encode(self, image, noise=None, scaling_factor: float = 0.18215, out_dtype=None, return_moments=False):
+    def vae_encode(self, image, noise=None, scaling_factor: float = 0.18215, out_dtype=None, return_moments=False,
+                   draws_per_image: int = 1):
         """`vae.encode(image).latent_dist.sample() * scaling_factor` (compute.py:91-93) with the N(0,1) draw
-        injected (`noise` [B,4,H/8,W/8]; None -> posterior mode).  image [B,3,H,W] in [-1,1].
-        Returns latents [B,4,H/8,W/8] (`out_dtype` fp16 default, or fp32) [, moments fp32 [B,8,H/8,W/8]]."""
+        injected (`noise` [B*D,4,H/8,W/8], D = draws_per_image; None -> posterior mode).  image [B,3,H,W] in
+        [-1,1].  Returns latents [B*D,4,H/8,W/8] (`out_dtype` fp16 default, or fp32; sample b*D+d belongs to
+        image b) [, moments fp32 [B,8,H/8,W/8]].  The encoder runs once per image whatever D is."""
         torch = self._torch
         out_dtype = out_dtype or torch.float16
         image = image.to(self.device, torch.float16).contiguous()
@@ -190,15 +193,15 @@ class UNetEngine:
         h, w = H // 8, W // 8
         if noise is not None:
             noise = noise.to(self.device, torch.float16).contiguous()
-            assert noise.shape == (B, 4, h, w), noise.shape
-        lat = torch.empty(B, 4, h, w, dtype=out_dtype, device=self.device)
+            assert noise.shape == (B * draws_per_image, 4, h, w), noise.shape
+        lat = torch.empty(B * draws_per_image, 4, h, w, dtype=out_dtype, device=self.device)
         mom = torch.empty(B, 8, h, w, dtype=torch.float32, device=self.device) if return_moments else None
         p16 = C.c_void_p(lat.data_ptr()) if out_dtype == torch.float16 else None
         p32 = C.c_void_p(lat.data_ptr()) if out_dtype == torch.float32 else None
         assert p16 or p32, "out_dtype must be torch.float16 or torch.float32"
         self._check(self.lib.dm_vae_encode(self._h, C.c_void_p(image.data_ptr()),
-                                           C.c_void_p(noise.data_ptr()) if noise is not None else None, B, H, W,
-                                           float(scaling_factor), p16, p32,
+                                           C.c_void_p(noise.data_ptr()) if noise is not None else None, B,
+                                           int(draws_per_image), H, W, float(scaling_factor), p16, p32,
                                            C.c_void_p(mom.data_ptr()) if mom is not None else None, self._stream()),
                     "dm_vae_encode")
         return (lat, mom) if return_moments else lat
@@ -343,6 +346,22 @@ class UNetEngine:
                                                  1 if grid.dtype == torch.float16 else 0, N, nc, h, w, H, W, kx, ky,
                                                  C.c_void_p(work.data_ptr()), C.c_void_p(out.data_ptr()), self._stream()),
                     "dm_typicality_image")
+        return out
+
+    def patch_embed(self, feat, boxes):
+        """DIFT patch descriptors (cluster.py:291-299): feat [C,h,w] or [1,C,h,w] fp32 (the ensemble mean of
+        `dift`), boxes [P,4] int = (r0, r1, c0, c1) feature cells -> [P,C] fp32, window mean then L2-normalised."""
+        torch = self._torch
+        feat = feat.to(self.device, torch.float32).contiguous()
+        if feat.dim() == 4:
+            assert feat.shape[0] == 1
+            feat = feat[0]
+        Cc, h, w = feat.shape
+        b = torch.as_tensor(boxes, device=self.device).to(torch.int32).contiguous()
+        assert b.dim() == 2 and b.shape[1] == 4, b.shape
+        out = torch.empty(b.shape[0], Cc, dtype=torch.float32, device=self.device)
+        self._check(self.lib.dm_patch_embed(self._h, C.c_void_p(feat.data_ptr()), Cc, h, w, C.c_void_p(b.data_ptr()),
+                                            b.shape[0], C.c_void_p(out.data_ptr()), self._stream()), "dm_patch_embed")
         return out
 
     # -- measurement -----------------------------------------------------------------------------

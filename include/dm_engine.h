@@ -140,17 +140,28 @@ int dm_prof_read(dm_engine* e, double* igemm_ms, double* igemm_flops, int64_t* i
  *   `post_quant_conv.*` are accepted and ignored; the pre-0.15 attention names query/key/value/proj_attn
  *   and their [C,C,1,1] shapes are mapped to to_q/to_k/to_v/to_out.0).  Host memory, DM_F16 or DM_F32.
  * dm_engine_finalize_vae: checks the 108 encoder tensors (34,163,664 parameters), packs, uploads.
- * dm_vae_encode: image [batch,3,H,W] fp16 NCHW in [-1,1] (H, W multiples of 8), noise [batch,4,H/8,W/8]
- *   fp16 = the injected N(0,1) draw of `latent_dist.sample()` (NULL -> posterior mode, mean only).
- *   Outputs (each optional, at least one): latent fp16 / fp32 [batch,4,H/8,W/8] =
- *   (mean + exp(0.5 clamp(logvar,-30,20)) * noise) * scaling_factor, and the fp32 moments
+ * dm_vae_encode: image [batch,3,H,W] fp16 NCHW in [-1,1] (H, W multiples of 8); `draws_per_image` D
+ *   posterior samples per image from noise [batch*D,4,H/8,W/8] fp16 = the injected N(0,1) draws of
+ *   `latent_dist.sample()` (NULL with D = 1 -> posterior mode, mean only).  D = 8 is the DIFT ensemble
+ *   (dift.py:187,220 encode the same image 8 times; here the encoder runs once per image).
+ *   Outputs (each optional, at least one): latents fp16 / fp32 [batch*D,4,H/8,W/8] (sample b*D+d belongs to
+ *   image b) = (mean + exp(0.5 clamp(logvar,-30,20)) * noise) * scaling_factor, and the fp32 moments
  *   [batch,8,H/8,W/8] (mean | logvar) of `quant_conv(encoder(image))`.                               */
 int dm_engine_load_vae_weight(dm_engine* e, const char* name, const void* host_ptr, int dtype,
                               const int64_t* shape, int ndim);
 int dm_engine_finalize_vae(dm_engine* e);
-int dm_vae_encode(dm_engine* e, const void* image_dev, const void* noise_dev, int batch, int H, int W,
-                  float scaling_factor, void* latent_f16_dev, void* latent_f32_dev, void* moments_f32_dev,
-                  void* stream);
+int dm_vae_encode(dm_engine* e, const void* image_dev, const void* noise_dev, int batch, int draws_per_image,
+                  int H, int W, float scaling_factor, void* latent_f16_dev, void* latent_f32_dev,
+                  void* moments_f32_dev, void* stream);
+
+/* ---- DIFT patch descriptors ---------------------------------------------------
+ * Replaces the per-patch tail of `Cluster.compute_embeddings` (diffmining/typicality/cluster.py:291-299):
+ *   emb = emb[:, int(x0*H):int(x1*H), int(y0*W):int(y1*W)].mean(axis=(1,2)); emb / np.linalg.norm(emb)
+ * for all patches of an image in one launch, from the ensemble-mean feature map dm_dift wrote
+ * (feat [C,h,w] fp32).  boxes [n_patches][4] int32 = (r0, r1, c0, c1) in feature cells (numpy slice
+ * semantics: clamped to the map; an empty window yields NaN).  out [n_patches][C] fp32.                 */
+int dm_patch_embed(dm_engine* e, const void* feat_f32_dev, int C, int h, int w, const int32_t* boxes_dev,
+                   int n_patches, void* out_f32_dev, void* stream);
 
 /* Bytes of device memory currently held by the engine (weights + workspace arena). */
 int dm_engine_memory(dm_engine* e, size_t* weights_bytes, size_t* arena_bytes);

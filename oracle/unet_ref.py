@@ -358,3 +358,20 @@ def dift_features(sd, latents_noisy, t, prompt_embeds, up_ft_index=1, cfg: RefCo
     out = unet_forward(sd, latents_noisy, tt, prompt_embeds, cfg, autocast, up_ft_indices=[up_ft_index])
     ft = out["up_ft"][up_ft_index]
     return ft, ft.mean(0, keepdim=True)
+
+
+# --------------------------------------------------------------------------------------------
+# DIFT patch descriptor — `Cluster.compute_embeddings`, cluster.py:291-299
+# --------------------------------------------------------------------------------------------
+def dift_patch_embedding(feat, box_px, image_hw):
+    """feat [C,h,w] (the ensemble-mean DIFT map, numpy), box_px = (x_start, y_start, x_end, y_end) in
+    image pixels with x = rows, y = columns (cluster.py:258-262), image_hw = (image.height, image.width).
+    `emb[:, int(x0*H):int(x1*H), int(y0*W):int(y1*W)].mean(axis=(1,2)); emb / ||emb||`."""
+    import numpy as np
+    _, h, w = feat.shape
+    H = h / image_hw[0]
+    W = w / image_hw[1]
+    x0, y0, x1, y1 = box_px
+    emb = feat[:, int(x0 * H):int(x1 * H), int(y0 * W):int(y1 * W)]
+    emb = emb.mean(axis=(1, 2))
+    return emb / np.linalg.norm(emb)

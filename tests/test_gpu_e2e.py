@@ -288,3 +288,32 @@ def test_full_size_properties(engine):
     m = loss2.mean().item()
     assert 0.1 < m < 10.0, m
     json.dump({"mean_loss_64x64": m}, open(os.path.join(os.environ.get("GRAFT_OUT", "/tmp"), "full_size.json"), "w"))
+
+
+def test_dift_patch_embeddings(engine):
+    """cluster.py:291-299 on the GPU: all patches of an image in one launch vs the numpy restatement;
+    the per-image cache computes the map once."""
+    from diff_mining_amd.dift import SDFeaturizer, feature_boxes
+    from oracle import unet_ref as R
+    g = torch.Generator().manual_seed(3)
+    feat = torch.randn(1, 1280, 32, 24, generator=g)
+    image_hw = (512, 384)
+    boxes = [(0, 0, 512, 384), (100, 50, 300, 250), (17, 33, 81, 97), (448, 320, 512, 384), (5, 5, 37, 21)]
+    fz = SDFeaturizer(engine)
+    out = fz.patch_embeddings(feat, boxes, image_hw).cpu().numpy()
+    assert out.shape == (5, 1280)
+    for i, b in enumerate(boxes):
+        ref = R.dift_patch_embedding(feat[0].numpy().astype(np.float64), b, image_hw)
+        assert np.abs(out[i] - ref).max() < 2e-6, (i, np.abs(out[i] - ref).max())
+        assert abs(np.linalg.norm(out[i]) - 1) < 1e-5
+    assert feature_boxes([(100, 50, 300, 250)], image_hw, (32, 24)).tolist() == [[6, 18, 3, 15]]
+    calls = []
+
+    def compute():
+        calls.append(1)
+        return feat
+    a = fz.patch_embeddings(("img0", "prompt", 261), boxes[:2], image_hw, compute)
+    b = fz.patch_embeddings(("img0", "prompt", 261), boxes[2:], image_hw, compute)
+    assert len(calls) == 1 and torch.equal(torch.cat([a, b]).cpu(), torch.from_numpy(out))
+    # empty window -> NaN like numpy's mean of an empty slice
+    assert torch.isnan(fz.patch_embeddings(feat, [(10, 10, 10, 40)], image_hw)).all()

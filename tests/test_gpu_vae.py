@@ -177,7 +177,7 @@ def test_vae_rejects_bad_input(vae_engine, vae_sd):
         vae_engine.lib.dm_vae_encode.restype  # noqa: B018  (attribute exists)
         bad = torch.zeros(1, 3, 60, 64, dtype=torch.float16, device=U.dev())
         out = torch.empty(1, 4, 7, 8, dtype=torch.float16, device=U.dev())
-        vae_engine._check(vae_engine.lib.dm_vae_encode(vae_engine._h, U.ptr(bad), None, 1, 60, 64, 0.18215, U.ptr(out), None,
+        vae_engine._check(vae_engine.lib.dm_vae_encode(vae_engine._h, U.ptr(bad), None, 1, 1, 60, 64, 0.18215, U.ptr(out), None,
                                                        None, U.stream()), "dm_vae_encode")
     eng = UNetEngine(0)
     try:
@@ -244,3 +244,44 @@ def test_image_to_typicality_grid(vae_engine, vae_sd, sd15_weights_f16):
     t = sc.load_image(u8)
     assert t.shape == (1, 3, 64, 64) and float(t.min()) >= -1 and float(t.max()) <= 1
     assert torch.allclose(t, torch.from_numpy(u8).permute(2, 0, 1)[None].float() / 255 * 2 - 1)
+
+
+def test_vae_draws_per_image(vae_engine):
+    """D posterior samples per image from one encoder pass == D separate encodes of the repeated image
+    (dift.py:220,187 encodes the same image `ensemble_size` times)."""
+    from diff_mining_amd import synth
+    img = torch.from_numpy(synth.synth_image(2, 64, 64))
+    noise = U.f16_randn(6, 4, 8, 8, seed=61)
+    a, m = vae_engine.vae_encode(img, noise, draws_per_image=3, return_moments=True)
+    b, m2 = vae_engine.vae_encode(img.repeat_interleave(3, 0), noise, return_moments=True)
+    assert a.shape == (6, 4, 8, 8) and m.shape == (2, 8, 8, 8)
+    assert torch.equal(a, b) and torch.equal(m, m2[::3])
+
+
+def test_dift_from_pixels(vae_engine, vae_sd, sd15_weights_f16):
+    """SDFeaturizer.forward from an image (dift.py:214-232): one encoder pass, `ensemble` posterior samples,
+    DIFT tap, ensemble mean — against the two oracles chained (fp32 U-Net oracle like the reference's DIFT)."""
+    from diff_mining_amd import synth
+    from diff_mining_amd.dift import SDFeaturizer
+    from oracle import unet_ref as R
+    from oracle import vae_ref
+    eng = vae_engine
+    if not eng._finalized:
+        eng.load_state_dict(sd15_weights_f16)
+    ens = 2
+    img = torch.from_numpy(synth.synth_image(1, 128, 128))
+    vnoise = U.f16_randn(ens, 4, 16, 16, seed=71).float()
+    noise = U.f16_randn(ens, 4, 16, 16, seed=72).float()
+    _, _, _, c = synth.synth_inputs(1, 1, 16, 16)
+    prompt = torch.from_numpy(c[:1])
+    fz = SDFeaturizer(eng)
+    got = fz.forward_image(img[0], prompt, t=161, up_ft_index=1, ensemble_size=ens, vae_noise=vnoise, noise=noise)
+    assert got.shape == (1, 1280, 8, 8)
+    vsd = {k: torch.from_numpy(v).float() for k, v in vae_sd.items()}
+    usd = {k: torch.from_numpy(v).float() for k, v in sd15_weights_f16.items()}
+    mom = vae_ref.vae_moments(vsd, img.float(), autocast=True)
+    lat = vae_ref.posterior_sample(mom.repeat(ens, 1, 1, 1), vnoise)
+    noisy = R.add_noise(lat, noise, torch.tensor(161))
+    ft, _ = R.dift_features(usd, noisy.half().float(), 161, prompt.float().expand(ens, -1, -1), 1)
+    ref = ft.mean(0, keepdim=True)
+    assert U.rel_l2(got, ref) < 6e-3, U.rel_l2(got, ref)
