@@ -24,6 +24,7 @@
 // Measured alternatives (r01): register staging + transposing ds_write_b16 0.55x, 128-key staged
 // tiles 0.95x, 64 queries/wave (occupancy 1) 0.8x, forcing 4 waves/SIMD (spills) 0.45x.
 #include "dm_kernels.h"
+#include <cstdlib>
 
 namespace dm {
 
@@ -348,8 +349,15 @@ hipError_t launch_t(const AttnParams& p, hipStream_t s) {
 
 }  // namespace
 
+hipError_t launch_attention_pipe(const AttnParams& p, hipStream_t s);    // attention_pipe.hip
+bool attention_pipe_supports(const AttnParams& p);
+
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.Tq <= 0 || p.Tk <= 0 || p.B <= 0) return hipErrorInvalidValue;
+    // long head_dim-40 self-attention: software-pipelined variant (DM_ATTN_PIPE=0 disables)
+    static int pipe = -1;
+    if (pipe < 0) { const char* e = getenv("DM_ATTN_PIPE"); pipe = e ? atoi(e) : 1; }
+    if (pipe && attention_pipe_supports(p)) return launch_attention_pipe(p, s);
     switch (p.D) {
         case 40: return launch_t<40, 2>(p, s);
         case 80: return launch_t<80, 2>(p, s);

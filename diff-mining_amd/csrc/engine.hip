@@ -118,7 +118,7 @@ struct Tensor {            // NHWC activation in the arena
     long long rows() const { return (long long)N * H * W; }
 };
 
-struct ProfEv { hipEvent_t a, b; double flops; int kind; };
+struct ProfEv { hipEvent_t a, b; double flops; int kind; int M = 0, N = 0, K = 0, mode = 0; };
 
 }  // namespace
 
@@ -403,9 +403,9 @@ struct Fwd {
     void free(Tensor& t) { if (t.off != (size_t)-1) { e->arena.release(t.off); t.off = (size_t)-1; t.p = nullptr; } }
     void free_raw(size_t off) { e->arena.release(off); }
 
-    int prof_begin(int kind, double flops) {
+    int prof_begin(int kind, double flops, int M = 0, int N = 0, int K = 0, int mode = 0) {
         if (!e->prof || dry) return 0;
-        ProfEv ev; ev.flops = flops; ev.kind = kind;
+        ProfEv ev; ev.flops = flops; ev.kind = kind; ev.M = M; ev.N = N; ev.K = K; ev.mode = mode;
         for (hipEvent_t* h : {&ev.a, &ev.b}) {
             if (!e->ev_pool.empty()) { *h = e->ev_pool.back(); e->ev_pool.pop_back(); }
             else DM_HIP(e, hipEventCreate(h));
@@ -436,7 +436,7 @@ struct Fwd {
         if (mode == IG_DENSE) { p.M = (int)x.rows(); p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M; }
         else { p.M = x.N * OH * OW; p.H = x.H; p.W = x.W; p.OH = OH; p.OW = OW; }
         const double flops = 2.0 * (double)p.M * cv.cout * (double)((mode == IG_DENSE ? 1 : 9) * cin);
-        DM_TRY(prof_begin(0, flops));
+        DM_TRY(prof_begin(0, flops, p.M, cv.cout, (mode == IG_DENSE ? 1 : 9) * cin, mode + 10 * epi));
         DM_HIP(e, launch_igemm(p, s));
         DM_TRY(prof_end());
         return 0;
@@ -493,7 +493,7 @@ struct Fwd {
         a.bsq = bsq; a.bsk = bskv; a.bsv = bskv; a.bso = (long long)Tq * C;
         a.kv_slot = slots; a.slot_div = 0; a.B = B; a.heads = HEADS; a.Tq = Tq; a.Tk = Tk; a.D = C / HEADS;
         a.scale = 1.0f / sqrtf((float)a.D);
-        DM_TRY(prof_begin(1, 4.0 * B * HEADS * (double)Tq * Tk * a.D));
+        DM_TRY(prof_begin(1, 4.0 * B * HEADS * (double)Tq * Tk * a.D, B * Tq, Tk, a.D, 100));
         DM_HIP(e, launch_attention(a, s));
         DM_TRY(prof_end());
         return 0;
@@ -536,7 +536,7 @@ struct Fwd {
             ap.kv_slot = slot_div > 0 ? nullptr : slots; ap.slot_div = slot_div;
             ap.B = B; ap.heads = HEADS; ap.Tq = T; ap.Tk = CTX_LEN; ap.D = C / HEADS;
             ap.scale = 1.0f / sqrtf((float)ap.D);
-            DM_TRY(prof_begin(1, 4.0 * B * HEADS * (double)T * CTX_LEN * ap.D));
+            DM_TRY(prof_begin(1, 4.0 * B * HEADS * (double)T * CTX_LEN * ap.D, B * T, CTX_LEN, ap.D, 101));
             DM_HIP(e, launch_attention(ap, s));
             DM_TRY(prof_end());
         }
@@ -1342,12 +1342,17 @@ int dm_prof_read(dm_engine* e, double* igemm_ms, double* igemm_flops, int64_t* i
     if (!e) return 1;
     DM_HIP(e, hipSetDevice(e->device));
     DM_HIP(e, hipDeviceSynchronize());
+    // DM_PROF_DUMP=<file>: append one line per timed launch (kind M N K mode flops ms) for tools/prof_shapes.py
+    FILE* dump = nullptr;
+    if (const char* dp = getenv("DM_PROF_DUMP")) dump = fopen(dp, "a");
     for (auto& ev : e->prof_ev) {
         float ms = 0.f;
         DM_HIP(e, hipEventElapsedTime(&ms, ev.a, ev.b));
+        if (dump) fprintf(dump, "%d %d %d %d %d %.0f %.6f\n", ev.kind, ev.M, ev.N, ev.K, ev.mode, ev.flops, ms);
         e->prof_ms[ev.kind] += ms; e->prof_flops[ev.kind] += ev.flops; e->prof_n[ev.kind] += 1;
         e->ev_pool.push_back(ev.a); e->ev_pool.push_back(ev.b);
     }
+    if (dump) fclose(dump);
     e->prof_ev.clear();
     if (igemm_ms) *igemm_ms = e->prof_ms[0];
     if (igemm_flops) *igemm_flops = e->prof_flops[0];
