@@ -2,6 +2,10 @@
 // the operand layout, the swizzle and the epilogues).  Kept in its own translation unit: co-compiling
 // it with the 128x320 kernel cost that kernel ~5 % (register allocation / scheduling drift).
 #include "dm_kernels.h"
+#include <cstdio>
+#include <type_traits>
+#include <cstdlib>
+#include <cstring>
 
 namespace dm {
 
@@ -39,65 +43,114 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // With CH > 1 channel sub-tiles per wave the block tile is written in CH passes: pass h stages the
 // sub-tile h of every wave ([TP][TC] with TC = 80 * channel-waves) and maps staged column blocks of
 // OB channels back to global channel  c0 + (col / OB) * OB * CH + h * OB + col % OB.
+#ifdef DM_IGEMM_TIMING
+__device__ long long g_igemm_dbg[16];
+#endif
+
 template <int EPI, int NTH, int TP, int TC, int CH>
 __device__ __forceinline__ void epilogue_lds(const IGemmParams& p, floatx4 (&acc)[5][4], char* smem, int p0,
-                                             int c0out, int wc, int wp, int l15, int lg, int OHW, int h) {
+                                             int c0out, int wc, int wp, int l15, int lg, int OHW, int h, const char* bias_lds
+#ifdef DM_IGEMM_TIMING
+                                             , long long* dbg, long long& tlast
+#define ETICK(i) do { const long long _n = (long long)__builtin_readcyclecounter(); dbg[i] += _n - tlast; tlast = _n; } while (0)
+#else
+#define ETICK(i) do {} while (0)
+#endif
+                                             ) {
     constexpr int TCO = (EPI == EPI_GEGLU) ? TC / 2 : TC;     // output channels of the staged tile
     constexpr int OB = (EPI == EPI_GEGLU) ? 40 : 80;
     constexpr int ROWB = TCO * 2 + 8;
-    __syncthreads();                                           // every wave is done with the operand tiles
+    // memory operations are batched and the optional operands resolved once, outside the fragment loops
+    // (see igemm_tile.h: a per-fragment load-wait-use chain made this epilogue as long as ten k steps)
+    float bz[5][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int pr = wp * 64 + 16 * j + l15;
-        const int m = p0 + pr;
-        const int n = (p.temb != nullptr && m < p.M) ? (m / OHW) : 0;
+    for (int i = 0; i < 5; ++i) {
+        const half4 bv = *reinterpret_cast<const half4*>(bias_lds + (wc * 80 * CH + h * 80 + 16 * i + 4 * lg) * 2);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int cl = wc * 80 + 16 * i + 4 * lg;              // staged-tile channel
-            const int c = c0out + wc * 80 * CH + h * 80 + 16 * i + 4 * lg;   // global (packed) channel
-            float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-            if (p.bias) {
-                const half4 bv = *reinterpret_cast<const half4*>(p.bias + c);
-                v0 += (float)bv[0]; v1 += (float)bv[1]; v2 += (float)bv[2]; v3 += (float)bv[3];
+        for (int r = 0; r < 4; ++r) bz[i][r] = (float)bv[r];
+    }
+    // waits for the LDS reads of the previous pass only: no fence, so the stores of that pass stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    ETICK(4);
+    auto stage = [&](auto has_temb) __attribute__((always_inline)) {
+        constexpr bool TEMB = decltype(has_temb)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pr = wp * 64 + 16 * j + l15;
+            const int m = p0 + pr;
+            half4 tv[5];
+            if (TEMB) {
+                const int n = (m < p.M) ? (m / OHW) : 0;
+                const f16* tp = p.temb + (size_t)n * p.temb_ld + c0out + wc * 80 * CH + h * 80 + 4 * lg;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) tv[i] = *reinterpret_cast<const half4*>(tp + 16 * i);
             }
-            if (EPI == EPI_GEGLU) {
-                const f16 h0 = (f16)v0, h1 = (f16)v1, g0 = (f16)v2, g1 = (f16)v3;
-                const f16 q0 = (f16)gelu_erf((float)g0), q1 = (f16)gelu_erf((float)g1);
-                typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
-                const half2_ o = half2_{(f16)((float)h0 * (float)q0), (f16)((float)h1 * (float)q1)};
-                const int ol = (cl >> 4) * 8 + 2 * lg;
-                *reinterpret_cast<half2_*>(smem + pr * ROWB + ol * 2) = o;
-            } else {
-                half4 o = half4{(f16)v0, (f16)v1, (f16)v2, (f16)v3};
-                if (p.temb && m < p.M) {
-                    const half4 tv = *reinterpret_cast<const half4*>(p.temb + (size_t)n * p.temb_ld + c);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (f16)((float)o[r] + (float)tv[r]);
+            for (int i = 0; i < 5; ++i) {
+                const int cl = wc * 80 + 16 * i + 4 * lg;              // staged-tile channel
+                const float v0 = acc[i][j][0] + bz[i][0], v1 = acc[i][j][1] + bz[i][1];
+                const float v2 = acc[i][j][2] + bz[i][2], v3 = acc[i][j][3] + bz[i][3];
+                if (EPI == EPI_GEGLU) {
+                    const f16 h0 = (f16)v0, h1 = (f16)v1, g0 = (f16)v2, g1 = (f16)v3;
+                    const f16 q0 = (f16)gelu_erf((float)g0), q1 = (f16)gelu_erf((float)g1);
+                    typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+                    const half2_ o = half2_{(f16)((float)h0 * (float)q0), (f16)((float)h1 * (float)q1)};
+                    const int ol = (cl >> 4) * 8 + 2 * lg;
+                    *reinterpret_cast<half2_*>(smem + pr * ROWB + ol * 2) = o;
+                } else {
+                    half4 o = half4{(f16)v0, (f16)v1, (f16)v2, (f16)v3};
+                    if (TEMB) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = (f16)((float)o[r] + (float)tv[i][r]);
+                    }
+                    *reinterpret_cast<half4*>(smem + pr * ROWB + cl * 2) = o;
                 }
-                *reinterpret_cast<half4*>(smem + pr * ROWB + cl * 2) = o;
             }
         }
-    }
-    __syncthreads();
+    };
+    if (EPI != EPI_GEGLU && p.temb) stage(std::true_type{}); else stage(std::false_type{});
+    ETICK(5);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    ETICK(6);
     constexpr int CPR = TCO / 8;                               // 16-byte chunks per row
+    constexpr int NIT = (TP * CPR) / NTH;
+    static_assert((TP * CPR) % NTH == 0, "whole number of chunks per thread");
+    constexpr int UB = (NIT % 5 == 0) ? 5 : ((NIT % 4 == 0) ? 4 : 1);
     const int c0o = (EPI == EPI_GEGLU) ? c0out / 2 : c0out;
-    for (int idx = threadIdx.x; idx < TP * CPR; idx += NTH) {
-        const int row = idx / CPR, ch = idx - row * CPR;
-        const int m = p0 + row;
-        if (m >= p.M) continue;
-        const char* src = smem + row * ROWB + ch * 16;
-        const half4 lo = *reinterpret_cast<const half4*>(src);
-        const half4 hi = *reinterpret_cast<const half4*>(src + 8);
-        half8 o = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const int col = ch * 8;
-        const int gc = c0o + (col / OB) * (OB * CH) + h * OB + col % OB;
-        if (EPI != EPI_GEGLU && p.res) {
-            const half8 rv = *reinterpret_cast<const half8*>(p.res + (size_t)m * p.ldres + gc);
+    auto copy_out = [&](auto has_res) __attribute__((always_inline)) {
+        constexpr bool RES = decltype(has_res)::value;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) o[r] = (f16)((float)o[r] + (float)rv[r]);
+        for (int it0 = 0; it0 < NIT; it0 += UB) {
+            half8 o[UB], rv[UB];
+            int mrow[UB], gcol[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = threadIdx.x + (it0 + u) * NTH;
+                const int row = idx / CPR, ch = idx - row * CPR;
+                mrow[u] = p0 + row;
+                const int col = ch * 8;
+                gcol[u] = c0o + (col / OB) * (OB * CH) + h * OB + col % OB;
+                const char* src = smem + row * ROWB + ch * 16;
+                const half4 lo = *reinterpret_cast<const half4*>(src);
+                const half4 hi = *reinterpret_cast<const half4*>(src + 8);
+                o[u] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (RES) {
+                    const int mr = mrow[u] < p.M ? mrow[u] : p.M - 1;
+                    rv[u] = *reinterpret_cast<const half8*>(p.res + (size_t)mr * p.ldres + gcol[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (RES) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[u][r] = (f16)((float)o[u][r] + (float)rv[u][r]);
+                }
+                if (mrow[u] < p.M) *reinterpret_cast<half8*>(p.Y + (size_t)mrow[u] * p.ldy + gcol[u]) = o[u];
+            }
         }
-        *reinterpret_cast<half8*>(p.Y + (size_t)m * p.ldy + gc) = o;
-    }
+    };
+    if (EPI != EPI_GEGLU && p.res) copy_out(std::true_type{}); else copy_out(std::false_type{});
+    ETICK(7);
 }
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page_big[256];
@@ -124,6 +177,13 @@ void igemm_big_kernel(IGemmParams p) {
     static_assert(WG % NW == 0 && XG % NW == 0, "uniform LDS-DMA count per wave required");
     constexpr int NL = WI + XI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef DM_IGEMM_TIMING
+    long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = (long long)__builtin_readcyclecounter();
+#define ITICK(i) do { const long long _n = (long long)__builtin_readcyclecounter(); dbg[i] += _n - tlast; tlast = _n; } while (0)
+#else
+#define ITICK(i) do {} while (0)
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -262,6 +322,12 @@ void igemm_big_kernel(IGemmParams p) {
     const int b_row_off = (wp * 64 + l15) * 128;
     const int koff0 = ((lg ^ (l15 & 7)) << 4), koff1 = (((4 + lg) ^ (l15 & 7)) << 4);
 
+    // bias of this tile's TC channels -> LDS (read back in the epilogue; visible after the first barrier)
+    if (tid < TC / 4) {
+        half4 bv = half4{0, 0, 0, 0};
+        if (p.bias) bv = *reinterpret_cast<const half4*>(p.bias + c0out + tid * 4);
+        *reinterpret_cast<half4*>(smem + 2 * STAGE + tid * 8) = bv;
+    }
     prepare();
 #pragma unroll
     for (int i = 0; i < NL; ++i) load_piece(0, i);
@@ -302,17 +368,31 @@ void igemm_big_kernel(IGemmParams p) {
         }
     };
 
+    ITICK(0);                                   // setup + first DMA issue
     for (int kt = 0; kt < nk - 1; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        ITICK(1);                               // waits at the top of a k step
         step(kt & 1, true);
+        ITICK(2);                               // k step body
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    ITICK(1);
     step((nk - 1) & 1, false);
+    ITICK(2);
 #pragma unroll
     for (int h = 0; h < CH; ++h)
-        epilogue_lds<EPI, 64 * NW, TP, 80 * WC, CH>(p, acc[h], smem, p0, c0out, wc, wp, l15, lg, OHW, h);
+        epilogue_lds<EPI, 64 * NW, TP, 80 * WC, CH>(p, acc[h], smem, p0, c0out, wc, wp, l15, lg, OHW, h, smem + 2 * STAGE
+#ifdef DM_IGEMM_TIMING
+                                                    , dbg, tlast
+#endif
+                                                    );
+#ifdef DM_IGEMM_TIMING
+    ITICK(3);                                   // epilogue
+    if (blockIdx.x == gridDim.x / 2 + 8 && (threadIdx.x & 63) == 0 && wid < 2)
+        for (int i = 0; i < 8; ++i) g_igemm_dbg[wid * 8 + i] = dbg[i];
+#endif
 }
 
 
@@ -320,7 +400,7 @@ void igemm_big_kernel(IGemmParams p) {
 
 hipError_t launch_igemm_big(const IGemmParams& p, hipStream_t s) {
     constexpr int TP = 256, TC = 320;
-    constexpr size_t lds = 2 * (size_t)(TP + TC) * 128;
+    constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 1024;     // + bias of the tile's channels
     dim3 grid(((p.M + TP - 1) / TP) * (p.Cout / TC)), block(512);
     static bool attr_set = false;
     if (!attr_set) {
@@ -332,5 +412,11 @@ hipError_t launch_igemm_big(const IGemmParams& p, hipStream_t s) {
     else hipLaunchKernelGGL((igemm_big_kernel<4, 2, 2, EPI_PLAIN>), grid, block, lds, s, p);
     return hipGetLastError();
 }
+
+#ifdef DM_IGEMM_TIMING
+extern "C" int dm_debug_igemm_timing(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_igemm_dbg), sizeof(long long) * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 
 }  // namespace dm

@@ -5,6 +5,7 @@
 #pragma once
 #include "dm_kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace dm {
 
@@ -39,62 +40,98 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // b32), then copied out as whole rows with 16-byte stores (+ the residual read the same way).
 // The direct fragment stores write 8-byte (GEGLU: 4-byte) pieces of 16 different 128-byte lines per
 // instruction; on the wide, short-K linears that partial-line traffic bound the whole kernel.
+// Memory operations are batched and the optional operands are resolved once (uniform branches outside
+// the fragment loops): under load a global access costs several thousand cycles, and vmcnt is
+// in-order, so a per-fragment "load, wait, use" chain (or a load queued behind the previous stores)
+// made this epilogue as long as ten k steps.  The bias of the tile's channels is staged in LDS before
+// the main loop (`bias_lds`, zeros when there is no bias).
 template <int EPI, int NTH, int TP, int TC, int NI>
-__device__ __forceinline__ void epilogue_lds(const IGemmParams& p, floatx4 (&acc)[NI][4], char* smem, int p0,
-                                             int c0out, int wc, int wp, int l15, int lg, int OHW) {
+__device__ __forceinline__ void epilogue_lds(const IGemmParams& p, floatx4 (&acc)[NI][4], char* smem, const char* bias_lds,
+                                             int p0, int c0out, int wc, int wp, int l15, int lg, int OHW) {
     constexpr int TCO = (EPI == EPI_GEGLU) ? TC / 2 : TC;     // output channels of the tile
     constexpr int ROWB = TCO * 2 + 8;
+    float bz[NI][4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const half4 bv = *reinterpret_cast<const half4*>(bias_lds + (wc * (16 * NI) + 16 * i + 4 * lg) * 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bz[i][r] = (float)bv[r];
+    }
     __syncthreads();                                           // every wave is done with the operand tiles
+    auto stage = [&](auto has_temb) __attribute__((always_inline)) {
+        constexpr bool TEMB = decltype(has_temb)::value;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int pr = wp * 64 + 16 * j + l15;
-        const int m = p0 + pr;
-        const int n = (p.temb != nullptr && m < p.M) ? (m / OHW) : 0;
+        for (int j = 0; j < 4; ++j) {
+            const int pr = wp * 64 + 16 * j + l15;
+            const int m = p0 + pr;
+            half4 tv[NI];
+            if (TEMB) {
+                const int n = (m < p.M) ? (m / OHW) : 0;
+                const f16* tp = p.temb + (size_t)n * p.temb_ld + c0out + wc * (16 * NI) + 4 * lg;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int cl = wc * (16 * NI) + 16 * i + 4 * lg;              // tile-local channel
-            const int c = c0out + cl;
-            float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-            if (p.bias) {
-                const half4 bv = *reinterpret_cast<const half4*>(p.bias + c);
-                v0 += (float)bv[0]; v1 += (float)bv[1]; v2 += (float)bv[2]; v3 += (float)bv[3];
+                for (int i = 0; i < NI; ++i) tv[i] = *reinterpret_cast<const half4*>(tp + 16 * i);     // batched
             }
-            if (EPI == EPI_GEGLU) {
-                const f16 h0 = (f16)v0, h1 = (f16)v1, g0 = (f16)v2, g1 = (f16)v3;
-                const f16 q0 = (f16)gelu_erf((float)g0), q1 = (f16)gelu_erf((float)g1);
-                typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
-                const half2_ o = half2_{(f16)((float)h0 * (float)q0), (f16)((float)h1 * (float)q1)};
-                const int ol = (cl >> 4) * 8 + 2 * lg;
-                *reinterpret_cast<half2_*>(smem + pr * ROWB + ol * 2) = o;
-            } else {
-                half4 o = half4{(f16)v0, (f16)v1, (f16)v2, (f16)v3};
-                if (p.temb && m < p.M) {
-                    const half4 tv = *reinterpret_cast<const half4*>(p.temb + (size_t)n * p.temb_ld + c);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (f16)((float)o[r] + (float)tv[r]);
+            for (int i = 0; i < NI; ++i) {
+                const int cl = wc * (16 * NI) + 16 * i + 4 * lg;              // tile-local channel
+                const float v0 = acc[i][j][0] + bz[i][0], v1 = acc[i][j][1] + bz[i][1];
+                const float v2 = acc[i][j][2] + bz[i][2], v3 = acc[i][j][3] + bz[i][3];
+                if (EPI == EPI_GEGLU) {
+                    const f16 h0 = (f16)v0, h1 = (f16)v1, g0 = (f16)v2, g1 = (f16)v3;
+                    const f16 q0 = (f16)gelu_erf((float)g0), q1 = (f16)gelu_erf((float)g1);
+                    typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+                    const half2_ o = half2_{(f16)((float)h0 * (float)q0), (f16)((float)h1 * (float)q1)};
+                    const int ol = (cl >> 4) * 8 + 2 * lg;
+                    *reinterpret_cast<half2_*>(smem + pr * ROWB + ol * 2) = o;
+                } else {
+                    half4 o = half4{(f16)v0, (f16)v1, (f16)v2, (f16)v3};
+                    if (TEMB) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = (f16)((float)o[r] + (float)tv[i][r]);
+                    }
+                    *reinterpret_cast<half4*>(smem + pr * ROWB + cl * 2) = o;
                 }
-                *reinterpret_cast<half4*>(smem + pr * ROWB + cl * 2) = o;
             }
         }
-    }
+    };
+    if (EPI != EPI_GEGLU && p.temb) stage(std::true_type{}); else stage(std::false_type{});
     __syncthreads();
     constexpr int CPR = TCO / 8;                               // 16-byte chunks per row
+    constexpr int NIT = (TP * CPR) / NTH;                      // chunks per thread (exact)
+    static_assert((TP * CPR) % NTH == 0, "whole number of chunks per thread");
+    constexpr int UB = (NIT % 5 == 0) ? 5 : ((NIT % 4 == 0) ? 4 : 1);
     const int c0o = (EPI == EPI_GEGLU) ? c0out / 2 : c0out;
-    for (int idx = threadIdx.x; idx < TP * CPR; idx += NTH) {
-        const int row = idx / CPR, ch = idx - row * CPR;
-        const int m = p0 + row;
-        if (m >= p.M) continue;
-        const char* src = smem + row * ROWB + ch * 16;
-        const half4 lo = *reinterpret_cast<const half4*>(src);
-        const half4 hi = *reinterpret_cast<const half4*>(src + 8);
-        half8 o = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        if (EPI != EPI_GEGLU && p.res) {
-            const half8 rv = *reinterpret_cast<const half8*>(p.res + (size_t)m * p.ldres + c0o + ch * 8);
+    auto copy_out = [&](auto has_res) __attribute__((always_inline)) {
+        constexpr bool RES = decltype(has_res)::value;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) o[r] = (f16)((float)o[r] + (float)rv[r]);
+        for (int it0 = 0; it0 < NIT; it0 += UB) {
+            half8 o[UB], rv[UB];
+            int mrow[UB], chn[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = threadIdx.x + (it0 + u) * NTH;
+                const int row = idx / CPR, ch = idx - row * CPR;
+                mrow[u] = p0 + row; chn[u] = ch;
+                const char* src = smem + row * ROWB + ch * 16;
+                const half4 lo = *reinterpret_cast<const half4*>(src);
+                const half4 hi = *reinterpret_cast<const half4*>(src + 8);
+                o[u] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (RES) {
+                    const int mr = mrow[u] < p.M ? mrow[u] : p.M - 1;
+                    rv[u] = *reinterpret_cast<const half8*>(p.res + (size_t)mr * p.ldres + c0o + ch * 8);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (RES) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[u][r] = (f16)((float)o[u][r] + (float)rv[u][r]);
+                }
+                if (mrow[u] < p.M) *reinterpret_cast<half8*>(p.Y + (size_t)mrow[u] * p.ldy + c0o + chn[u] * 8) = o[u];
+            }
         }
-        *reinterpret_cast<half8*>(p.Y + (size_t)m * p.ldy + c0o + ch * 8) = o;
-    }
+    };
+    if (EPI != EPI_GEGLU && p.res) copy_out(std::true_type{}); else copy_out(std::false_type{});
 }
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
@@ -232,6 +269,13 @@ void igemm_kernel(IGemmParams p) {
     const int b_row_off = (wp * 64 + l15) * 128;
     const int koff0 = ((lg ^ (l15 & 7)) << 4), koff1 = (((4 + lg) ^ (l15 & 7)) << 4);
 
+    // bias of this tile's channels -> LDS behind the operand stages (zeros without a bias); read back in
+    // the epilogue, visible after the first barrier of the k loop
+    if (tid < TC / 4) {
+        half4 bv = half4{0, 0, 0, 0};
+        if (p.bias) bv = *reinterpret_cast<const half4*>(p.bias + c0out + tid * 4);
+        *reinterpret_cast<half4*>(smem + 2 * STAGE + tid * 8) = bv;
+    }
     prepare();
 #pragma unroll
     for (int i = 0; i < NL; ++i) load_piece(0, i);
@@ -272,7 +316,7 @@ void igemm_kernel(IGemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     step((nk - 1) & 1, false);
-    epilogue_lds<EPI, 128 * WC, TP, TC, NI>(p, acc, smem, p0, c0out, wc, wp, l15, lg, OHW);
+    epilogue_lds<EPI, 128 * WC, TP, TC, NI>(p, acc, smem, smem + 2 * STAGE, p0, c0out, wc, wp, l15, lg, OHW);
 }
 
 }  // namespace
@@ -280,7 +324,7 @@ void igemm_kernel(IGemmParams p) {
 template <int WC, int NI>
 static hipError_t launch_t(const IGemmParams& p, hipStream_t s) {
     constexpr int TP = 128, TC = 16 * NI * WC;
-    constexpr size_t lds = 2 * (size_t)(TP + TC) * 128;
+    constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 1024;      // operand stages + the tile's bias
     const int tiles_p = (p.M + TP - 1) / TP;
     const int tiles_c = p.Cout / TC;
     dim3 grid(tiles_p * tiles_c), block(128 * WC);
