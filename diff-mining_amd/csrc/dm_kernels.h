@@ -97,4 +97,12 @@ hipError_t launch_posterior(const f16* Hm, int ldh, const f16* qw, const f16* qb
 // feat [C][h][w] fp32, boxes [P][4] = (r0, r1, c0, c1) in feature cells
 hipError_t launch_patch_embed(const float* feat, int C, int h, int w, const int32_t* boxes, int P, float* out, hipStream_t s);
 
+// ---- CLIP text tower (clip.hip) ------------------------------------------------------------------
+hipError_t launch_clip_embed(const int32_t* ids, const f16* tok, const f16* pos, int rows, int T, int C, int vocab, f16* out,
+                             hipStream_t s);
+// causal attention over qkv [n*T][3*heads*64] (q pre-scaled) -> out [n*T][heads*64]; T <= 80
+hipError_t launch_clip_attention(const f16* qkv, int n, int T, int heads, f16* out, hipStream_t s);
+hipError_t launch_quick_gelu(f16* x, long long n, hipStream_t s);
+hipError_t launch_f16_to_f32(const f16* x, float* y, long long n, hipStream_t s);
+
 }  // namespace dm

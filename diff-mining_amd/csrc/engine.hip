@@ -72,6 +72,15 @@ struct VaeW {
     const f16* qw = nullptr; const f16* qb = nullptr;    // quant_conv [8][8], [8]
 };
 
+// CLIP ViT-L/14 text tower (12 pre-LN layers, hidden 768, 12 heads of 64, MLP 3072 quick_gelu)
+constexpr int CL_LAYERS = 12, CL_H = 768, CL_F = 3072, CL_HEADS = 12, CL_T = 77, CL_VOCAB = 49408;
+struct ClipLayerW { NormW ln1, ln2; ConvW qkv, o, fc1, fc2; };
+struct ClipW {
+    const f16* tok = nullptr; const f16* pos = nullptr;
+    ClipLayerW layer[CL_LAYERS];
+    NormW final_ln;
+};
+
 struct Arena {
     struct Blk { size_t off, sz; bool free; };
     std::vector<Blk> blks;
@@ -141,6 +150,11 @@ struct dm_engine {
     f16* sin_table = nullptr;        // [1000][320] fp16
     f16* sa_tab = nullptr;           // [1000] fp16 sqrt(acp16)
     f16* sb_tab = nullptr;           // [1000] fp16 sqrt(1-acp16)
+
+    // optional CLIP text tower (dm_engine_load_clip_weight / dm_engine_finalize_clip)
+    std::map<std::string, HostTensor> host_clip;
+    ClipW clip; bool clip_ready = false;
+    char* cslab = nullptr; size_t cslab_bytes = 0;
 
     // optional VAE encoder (dm_engine_load_vae_weight / dm_engine_finalize_vae)
     std::map<std::string, HostTensor> host_vae;
@@ -781,6 +795,44 @@ int run_vae(dm_engine* e, const VaeArgs& A, hipStream_t s, bool dry) {
     return 0;
 }
 
+// ---- CLIP text tower: token ids -> last_hidden_state (compute.py:39-51) -------------------------
+int run_clip(dm_engine* e, const int32_t* ids, int n, f16* out16, float* out32, hipStream_t s, bool dry) {
+    Fwd F{e, s, dry};
+    const ClipW& c = e->clip;
+    const int M = n * CL_T;
+    Tensor x;
+    DM_TRY(F.alloc(&x, 1, 1, M, CL_H));
+    if (!dry) DM_HIP(e, launch_clip_embed(ids, c.tok, c.pos, M, CL_T, CL_H, CL_VOCAB, x.p, s));
+    for (int l = 0; l < CL_LAYERS; ++l) {
+        const ClipLayerW& L = c.layer[l];
+        Tensor h, qkv, a, x1, f, x2;
+        DM_TRY(F.layernorm(L.ln1, x, &h));
+        DM_TRY(F.dense(L.qkv, h, nullptr, nullptr, EPI_PLAIN, &qkv));
+        F.free(h);
+        DM_TRY(F.alloc(&a, 1, 1, M, CL_H));
+        if (!dry) DM_HIP(e, launch_clip_attention(qkv.p, n, CL_T, CL_HEADS, a.p, s));
+        F.free(qkv);
+        DM_TRY(F.dense(L.o, a, nullptr, &x, EPI_PLAIN, &x1));
+        F.free(a); F.free(x);
+        DM_TRY(F.layernorm(L.ln2, x1, &h));
+        DM_TRY(F.dense(L.fc1, h, nullptr, nullptr, EPI_PLAIN, &f));
+        F.free(h);
+        if (!dry) DM_HIP(e, launch_quick_gelu(f.p, (long long)M * CL_F, s));
+        DM_TRY(F.dense(L.fc2, f, nullptr, &x1, EPI_PLAIN, &x2));
+        F.free(f); F.free(x1);
+        x = x2;
+    }
+    Tensor y;
+    DM_TRY(F.layernorm(c.final_ln, x, &y));
+    F.free(x);
+    if (!dry) {
+        if (out16) DM_HIP(e, hipMemcpyAsync(out16, y.p, (size_t)M * CL_H * sizeof(f16), hipMemcpyDeviceToDevice, s));
+        if (out32) DM_HIP(e, launch_f16_to_f32(y.p, out32, (long long)M * CL_H, s));
+    }
+    F.free(y);
+    return 0;
+}
+
 template <class RunFn>
 int ensure_arena_for(dm_engine* e, hipStream_t s, RunFn run_dry) {
     e->arena.reset((size_t)1 << 60, true);
@@ -875,6 +927,7 @@ void dm_engine_destroy(dm_engine* e) {
     (void)hipDeviceSynchronize();
     if (e->wslab) (void)hipFree(e->wslab);
     if (e->vslab) (void)hipFree(e->vslab);
+    if (e->cslab) (void)hipFree(e->cslab);
     if (e->arena_base) (void)hipFree(e->arena_base);
     if (e->sin_table) (void)hipFree(e->sin_table);
     if (e->sa_tab) (void)hipFree(e->sa_tab);
@@ -1158,6 +1211,100 @@ int dm_vae_encode(dm_engine* e, const void* image_dev, const void* noise_dev, in
         A.moments = moments_f32_dev ? (float*)moments_f32_dev + (size_t)b0 * 8 * lpx : nullptr;
         DM_TRY(ensure_arena_for(e, s, [&]() { return run_vae(e, A, s, true); }));
         DM_TRY(run_vae(e, A, s, false));
+    }
+    return 0;
+}
+
+int dm_engine_load_clip_weight(dm_engine* e, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim) {
+    if (!e || !name || !host_ptr || !shape) return 1;
+    if (e->clip_ready) DM_FAIL(e, "load_clip_weight after finalize_clip");
+    std::string nm(name);
+    for (const char* pre : {"text_encoder.", "text_model."}) if (nm.rfind(pre, 0) == 0) nm = nm.substr(strlen(pre));
+    if (nm.rfind("text_model.", 0) == 0) nm = nm.substr(11);
+    if (nm.size() >= 12 && nm.compare(nm.size() - 12, 12, "position_ids") == 0) return 0;          // index buffer
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    const size_t n = t.numel();
+    t.data.resize(n);
+    if (dtype == DM_F16) memcpy(t.data.data(), host_ptr, n * 2);
+    else if (dtype == DM_F32) { const float* f = (const float*)host_ptr; for (size_t i = 0; i < n; ++i) t.data[i] = (f16)f[i]; }
+    else DM_FAIL(e, "unsupported dtype %d for %s", dtype, name);
+    e->host_clip[nm] = std::move(t);
+    return 0;
+}
+
+int dm_engine_finalize_clip(dm_engine* e) {
+    if (!e) return 1;
+    if (e->clip_ready) return 0;
+    DM_HIP(e, hipSetDevice(e->device));
+    Packer P{e, {}, &e->host_clip};
+    ClipW& c = e->clip;
+    {
+        HostTensor* tok = P.get("embeddings.token_embedding.weight", {CL_VOCAB, CL_H});
+        HostTensor* pos = P.get("embeddings.position_embedding.weight", {CL_T, CL_H});
+        if (!tok || !pos) return 1;
+        c.tok = as_ptr(P.put(tok->data.data(), tok->data.size() * 2));
+        c.pos = as_ptr(P.put(pos->data.data(), pos->data.size() * 2));
+    }
+    for (int l = 0; l < CL_LAYERS; ++l) {
+        ClipLayerW& L = c.layer[l];
+        const std::string b = "encoder.layers." + std::to_string(l);
+        DM_TRY(pack_norm(P, b + ".layer_norm1", CL_H, &L.ln1));
+        // q/k/v stacked; the attention scale d^-0.5 = 1/8 (exact in fp16) is folded into q_proj
+        DM_TRY(pack_stack(P, {b + ".self_attn.q_proj", b + ".self_attn.k_proj", b + ".self_attn.v_proj"}, CL_H, CL_H, &L.qkv));
+        {
+            std::vector<f16> qb;
+            for (const char* leaf : {".self_attn.q_proj", ".self_attn.k_proj", ".self_attn.v_proj"}) {
+                HostTensor* bt = P.get(b + leaf + ".bias", {CL_H});
+                if (!bt) return 1;
+                qb.insert(qb.end(), bt->data.begin(), bt->data.end());
+            }
+            for (int i = 0; i < CL_H; ++i) qb[i] = (f16)((float)qb[i] * 0.125f);
+            f16* w = reinterpret_cast<f16*>(P.blob.data() + (reinterpret_cast<size_t>(L.qkv.w) - 1));
+            for (size_t i = 0; i < (size_t)CL_H * CL_H; ++i) w[i] = (f16)((float)w[i] * 0.125f);
+            L.qkv.b = as_ptr(P.put(qb.data(), qb.size() * 2));
+        }
+        DM_TRY(pack_dense(P, b + ".self_attn.out_proj", CL_H, CL_H, false, true, &L.o));
+        DM_TRY(pack_norm(P, b + ".layer_norm2", CL_H, &L.ln2));
+        DM_TRY(pack_dense(P, b + ".mlp.fc1", CL_F, CL_H, false, true, &L.fc1));
+        DM_TRY(pack_dense(P, b + ".mlp.fc2", CL_H, CL_F, false, true, &L.fc2));
+    }
+    DM_TRY(pack_norm(P, "final_layer_norm", CL_H, &c.final_ln));
+    size_t unused = 0; std::string first_unused;
+    for (auto& kv : e->host_clip) if (!kv.second.used) { if (!unused) first_unused = kv.first; ++unused; }
+    if (unused) DM_FAIL(e, "%zu unexpected tensors in the CLIP text state dict (first: %s)", unused, first_unused.c_str());
+    if (e->host_clip.size() != 196) DM_FAIL(e, "expected 196 CLIP text tensors, got %zu", e->host_clip.size());
+    e->cslab_bytes = P.blob.size();
+    DM_HIP(e, hipMalloc((void**)&e->cslab, e->cslab_bytes));
+    DM_HIP(e, hipMemcpy(e->cslab, P.blob.data(), e->cslab_bytes, hipMemcpyHostToDevice));
+    char* base = e->cslab;
+    rebase(c.tok, base); rebase(c.pos, base); rebase_norm(c.final_ln, base);
+    for (int l = 0; l < CL_LAYERS; ++l) {
+        ClipLayerW& L = c.layer[l];
+        rebase_norm(L.ln1, base); rebase_norm(L.ln2, base);
+        rebase_conv(L.qkv, base); rebase_conv(L.o, base); rebase_conv(L.fc1, base); rebase_conv(L.fc2, base);
+    }
+    e->host_clip.clear();
+    e->clip_ready = true;
+    return 0;
+}
+
+int dm_clip_encode(dm_engine* e, const int32_t* input_ids_dev, int n_prompts, int seq_len, void* out_f16_dev, void* out_f32_dev,
+                   void* stream) {
+    if (!e) return 1;
+    if (!e->clip_ready) DM_FAIL(e, "dm_clip_encode: CLIP text weights not loaded (dm_engine_finalize_clip)");
+    if (!input_ids_dev || (!out_f16_dev && !out_f32_dev) || n_prompts <= 0) DM_FAIL(e, "dm_clip_encode: bad argument");
+    if (seq_len != CL_T) DM_FAIL(e, "dm_clip_encode: seq_len must be %d (padding=\"max_length\")", CL_T);
+    DM_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int chunk = 256;                                   // prompts per pass (workspace ~ 0.5 GB)
+    for (int n0 = 0; n0 < n_prompts; n0 += chunk) {
+        const int n = (n_prompts - n0 < chunk) ? (n_prompts - n0) : chunk;
+        const int32_t* ids = input_ids_dev + (size_t)n0 * CL_T;
+        f16* o16 = out_f16_dev ? (f16*)out_f16_dev + (size_t)n0 * CL_T * CL_H : nullptr;
+        float* o32 = out_f32_dev ? (float*)out_f32_dev + (size_t)n0 * CL_T * CL_H : nullptr;
+        DM_TRY(ensure_arena_for(e, s, [&]() { return run_clip(e, ids, n, o16, o32, s, true); }));
+        DM_TRY(run_clip(e, ids, n, o16, o32, s, false));
     }
     return 0;
 }

@@ -23,6 +23,7 @@ SYMBOLS = [
     "dm_reduce_typicality", "dm_typicality_image", "dm_prof_enable", "dm_prof_read", "dm_engine_memory",
     "dm_op_igemm", "dm_op_attention", "dm_op_groupnorm", "dm_op_layernorm",
     "dm_engine_load_vae_weight", "dm_engine_finalize_vae", "dm_vae_encode", "dm_op_attention512", "dm_patch_embed",
+    "dm_engine_load_clip_weight", "dm_engine_finalize_clip", "dm_clip_encode",
 ]
 
 
@@ -75,6 +76,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_engine_finalize_vae.argtypes = [vp]
     lib.dm_vae_encode.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.c_float, vp, vp, vp, vp]
     lib.dm_patch_embed.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
+    lib.dm_engine_load_clip_weight.argtypes = [vp, C.c_char_p, vp, i32, C.POINTER(i64), i32]
+    lib.dm_engine_finalize_clip.argtypes = [vp]
+    lib.dm_clip_encode.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     lib.dm_op_attention512.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float]
     if path is None:
         _lib = lib
@@ -173,6 +177,27 @@ class UNetEngine:
         self._load(self.lib.dm_engine_load_vae_weight, sd, "load_vae_weight")
         self._check(self.lib.dm_engine_finalize_vae(self._h), "finalize_vae")
         self._vae_ready = True
+
+    def load_clip_state_dict(self, sd: Dict[str, "np.ndarray"]):
+        """sd: `CLIPTextModel.state_dict()` (`pipe.text_encoder`, compute.py:68).  Optional."""
+        self._load(self.lib.dm_engine_load_clip_weight, sd, "load_clip_weight")
+        self._check(self.lib.dm_engine_finalize_clip(self._h), "finalize_clip")
+        self._clip_ready = True
+
+    def clip_encode(self, input_ids, out_dtype=None):
+        """`self.clip(tokens)[0]` (compute.py:51): input_ids [n, 77] (tokenizer output, padding="max_length")
+        -> last_hidden_state [n, 77, 768] on the GPU (`out_dtype` fp32 default like `.float()`, or fp16)."""
+        torch = self._torch
+        out_dtype = out_dtype or torch.float32
+        ids = torch.as_tensor(input_ids).to(self.device, torch.int32).contiguous()
+        assert ids.dim() == 2 and ids.shape[1] == 77, ids.shape
+        out = torch.empty(ids.shape[0], 77, 768, dtype=out_dtype, device=self.device)
+        p16 = C.c_void_p(out.data_ptr()) if out_dtype == torch.float16 else None
+        p32 = C.c_void_p(out.data_ptr()) if out_dtype == torch.float32 else None
+        assert p16 or p32
+        self._check(self.lib.dm_clip_encode(self._h, C.c_void_p(ids.data_ptr()), ids.shape[0], 77, p16, p32, self._stream()),
+                    "dm_clip_encode")
+        return out
 
     def load_vae_safetensors(self, path: str):
         """`vae/diffusion_pytorch_model.safetensors` of a diffusers pipeline directory."""

@@ -129,6 +129,37 @@ def synth_vae_state_dict(cfg=None, seed: int = 0, dtype=np.float32) -> dict:
     return out
 
 
+def synth_clip_state_dict(cfg=None, seed: int = 0, dtype=np.float32) -> dict:
+    """Synthetic CLIP text-tower tensors (see clip_spec.py).  Embeddings ~ N(0, 0.02) like the real model's
+    initialiser range; linear layers fan-in scaled."""
+    from .clip_spec import CLIP_L14_TEXT, clip_text_tensor_spec
+    out = {}
+    for name, shape in clip_text_tensor_spec(cfg or CLIP_L14_TEXT):
+        if "embedding" in name:
+            z = hash_normal("clip." + name, int(np.prod(shape)), seed)
+            t = (0.02 * z).astype(np.float32).astype(np.float16).astype(np.float32).reshape(shape)
+        else:
+            t = synth_tensor("clip." + name, shape, seed)
+        out[name] = t if dtype == np.float32 else t.astype(dtype)
+    return out
+
+
+def synth_token_ids(n: int, cfg=None, seed: int = 3) -> np.ndarray:
+    """[n, 77] int64 prompts shaped like the tokenizer's output (compute.py:35-37): BOS, a few random
+    tokens, EOS, then EOS padding (`padding="max_length"` pads CLIP prompts with the EOS id)."""
+    from .clip_spec import CLIP_L14_TEXT
+    cfg = cfg or CLIP_L14_TEXT
+    with np.errstate(over="ignore"):
+        key = np.uint64(fnv1a64("input.tokens")) ^ _splitmix64(np.array([seed], dtype=np.uint64) + _GOLDEN)[0]
+        bits = _splitmix64(key + np.arange(n * cfg.max_position_embeddings, dtype=np.uint64) * _GOLDEN)
+    ids = (bits % np.uint64(cfg.bos_token_id)).astype(np.int64).reshape(n, cfg.max_position_embeddings)
+    for i in range(n):
+        length = 2 + (i * 5) % 9                 # prompt "" -> BOS EOS; longer ones for the categories
+        ids[i, 0] = cfg.bos_token_id
+        ids[i, length - 1:] = cfg.eos_token_id
+    return ids
+
+
 def synth_image(n: int, H: int, W: int, seed: int = 5) -> np.ndarray:
     """Smooth synthetic RGB images in [-1, 1] (`to_tensor(img) * 2 - 1`, compute.py:126-132), fp16-representable."""
     z = hash_normal("input.image", n * 3 * H * W, seed).reshape(n, 3, H, W)

@@ -2,6 +2,7 @@
 
     reference                                         here
     ------------------------------------------------  -----------------------------------------
+    CategoryFeatures         compute.py:27-54         CategoryFeatures (optional: needs CLIP text weights)
     SD.encode_vae            compute.py:91-93         TypicalityScorer.encode_vae (optional: needs VAE weights)
     D.load_image             compute.py:126-132       TypicalityScorer.load_image
     SD.compute_loss          compute.py:95-102        TypicalityScorer.compute_loss
@@ -30,6 +31,36 @@ import numpy as np
 import torch
 
 from .engine import UNetEngine
+
+
+class CategoryFeatures:
+    """`CategoryFeatures` of compute.py:27-54 over the engine's CLIP text tower: one prompt per category
+    (templates of compute.py:41-48, '' = the null prompt), tokenised on the host by `tokenizer` (e.g.
+    transformers' `CLIPTokenizer`, called exactly like compute.py:36-37), encoded on the GPU."""
+
+    def __init__(self, engine: UNetEngine, tokenizer, which: str):
+        self.engine, self.tokenizer, self.which = engine, tokenizer, which
+
+    @staticmethod
+    def prompts(which: str, categories):
+        if which == "faces":
+            return [(f"Portrait at the {c}'s." if len(c) else "Portrait.") for c in categories]
+        if which == "cars":
+            return [(f"A car at the {c}'s." if len(c) else "A car.") for c in categories]
+        if which == "places":
+            return [("Image of " + c.replace("_", " ") + "." if len(c) else "") for c in categories]
+        return [(f"{c}" if len(c) else "") for c in categories]
+
+    def tokenize(self, prompts):
+        return self.tokenizer(prompts, max_length=self.tokenizer.model_max_length, padding="max_length", truncation=True,
+                              return_tensors="pt").input_ids
+
+    @torch.no_grad()
+    def embed(self, categories):
+        return self.engine.clip_encode(self.tokenize(self.prompts(self.which, categories)))     # [n,77,768] fp32
+
+    def __getitem__(self, x):
+        return self.embed(x)
 
 
 class _Sample:

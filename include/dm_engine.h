@@ -154,6 +154,23 @@ int dm_vae_encode(dm_engine* e, const void* image_dev, const void* noise_dev, in
                   int H, int W, float scaling_factor, void* latent_f16_dev, void* latent_f32_dev,
                   void* moments_f32_dev, void* stream);
 
+/* ---- CLIP text tower ----------------------------------------------------------
+ * Replaces `self.clip(tokens.to(self.device))[0]` of `CategoryFeatures.embed`
+ * (diffmining/typicality/compute.py:51; the pipeline's `text_encoder`, compute.py:68): CLIP ViT-L/14 text
+ * model, token ids -> last_hidden_state.  Optional.  Tokenisation (BPE vocabulary) stays on the host.
+ *
+ * dm_engine_load_clip_weight: one tensor of `CLIPTextModel.state_dict()` (optional `text_encoder.` /
+ *   `text_model.` prefixes are stripped; `position_ids` buffers are ignored).  Host memory, DM_F16 / DM_F32.
+ * dm_engine_finalize_clip: checks the 196 tensors (123,060,480 parameters), packs, uploads.
+ * dm_clip_encode: input_ids [n_prompts][seq_len = 77] int32 on the device (tokenizer output with
+ *   padding="max_length") -> last_hidden_state [n_prompts][77][768] as fp16 and/or fp32 (the reference
+ *   takes `.float()`).  The fp16 output is directly the `ctx` of dm_engine_set_prompts.               */
+int dm_engine_load_clip_weight(dm_engine* e, const char* name, const void* host_ptr, int dtype,
+                               const int64_t* shape, int ndim);
+int dm_engine_finalize_clip(dm_engine* e);
+int dm_clip_encode(dm_engine* e, const int32_t* input_ids_dev, int n_prompts, int seq_len, void* out_f16_dev,
+                   void* out_f32_dev, void* stream);
+
 /* ---- DIFT patch descriptors ---------------------------------------------------
  * Replaces the per-patch tail of `Cluster.compute_embeddings` (diffmining/typicality/cluster.py:291-299):
  *   emb = emb[:, int(x0*H):int(x1*H), int(y0*W):int(y1*W)].mean(axis=(1,2)); emb / np.linalg.norm(emb)

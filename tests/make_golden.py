@@ -1,6 +1,6 @@
 """Generates the committed golden vectors under tests/golden/ from the CPU oracle.
 
-    python tests/make_golden.py            (add --vae-only to regenerate just the VAE fixture)
+    python tests/make_golden.py            (--vae-only / --clip-only regenerate just that fixture)
 
 Inputs come from the integer-hash generator (diff-mining_amd/synth.py), weights are NOT stored
 (regenerated deterministically, seed 0); outputs are the oracle's.  The reference itself cannot
@@ -31,14 +31,47 @@ def vae():
     np.savez_compressed(os.path.join(OUT, "vae_64x64.npz"), image=img, noise=noise, moments=mom.numpy(), latents=lat.numpy())
 
 
+def clip():
+    """CLIP text tower: the REAL `transformers.CLIPTextModel` (the reference's dependency, importable in
+    the build container) with the synthetic weights -> last_hidden_state.  Pins oracle/clip_ref.py."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from diff_mining_amd.clip_spec import canonical_clip_name
+    os.makedirs(OUT, exist_ok=True)
+    cfg = CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                         num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu",
+                         layer_norm_eps=1e-5, bos_token_id=49406, eos_token_id=49407, pad_token_id=1)
+    model = CLIPTextModel(cfg).eval()
+    ours = synth.synth_clip_state_dict(seed=0)
+    sd = {}
+    for k in model.state_dict().keys():
+        c = canonical_clip_name(k)
+        if c is None:
+            sd[k] = model.state_dict()[k]
+        else:
+            sd[k] = torch.from_numpy(ours[c])
+    model.load_state_dict(sd, strict=True)
+    ids = synth.synth_token_ids(3)
+    with torch.no_grad():
+        out = model(torch.from_numpy(ids))[0]
+    import transformers
+    np.savez_compressed(os.path.join(OUT, "clip_text.npz"), input_ids=ids, last_hidden_state=out.numpy().astype(np.float32),
+                        transformers_version=np.array(transformers.__version__))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--clip-only" in sys.argv:
+        clip()
+        for f in sorted(os.listdir(OUT)):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+        return
     if "--vae-only" in sys.argv:
         vae()
         for f in sorted(os.listdir(OUT)):
             print(f, os.path.getsize(os.path.join(OUT, f)))
         return
     vae()
+    clip()
     sd = {k: torch.from_numpy(v).float() for k, v in synth.synth_state_dict(seed=0, dtype=np.float16).items()}
     # scoring, latent 8x8, 2 draws x 2 prompts
     x, eps, t, c = synth.synth_inputs(1, 2, 8, 8)

@@ -1,0 +1,91 @@
+"""CLIP text tower on the GPU against the fixture produced by
+`transformers.CLIPTextModel` itself (tests/golden/clip_text.npz) and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests import gpu_util as U  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def clip_sd():
+    from diff_mining_amd import synth
+    return synth.synth_clip_state_dict(seed=0, dtype=np.float16)
+
+
+@pytest.fixture(scope="module")
+def clip_engine(clip_sd):
+    from diff_mining_amd.engine import UNetEngine
+    assert torch.cuda.is_available()
+    eng = UNetEngine(0)
+    eng.load_clip_state_dict(clip_sd)
+    yield eng
+    eng.close()
+
+
+def test_clip_matches_transformers_fixture(clip_engine, clip_sd):
+    """fp16 engine vs the fp32 `transformers` output: rel-L2 <= 3e-3 (the fp16 emulation of the oracle sits at
+    1.1e-3 from it), and as close to the oracle's fp16 emulation."""
+    from oracle import clip_ref
+    g = np.load(os.path.join(GOLDEN, "clip_text.npz"))
+    ids = torch.from_numpy(g["input_ids"])
+    ref = torch.from_numpy(g["last_hidden_state"])
+    out = clip_engine.clip_encode(ids)
+    assert out.shape == (3, 77, 768) and out.dtype == torch.float32
+    r = U.rel_l2(out, ref)
+    sd = {k: torch.from_numpy(v).float() for k, v in clip_sd.items()}
+    r16 = U.rel_l2(out, clip_ref.clip_text_forward(sd, ids, autocast=True))
+    print(f"clip: rel-L2 vs transformers fp32 {r:.2e}, vs fp16-emulating oracle {r16:.2e}")
+    assert r < 3e-3 and r16 < 3e-3
+    out16 = clip_engine.clip_encode(ids, out_dtype=torch.float16)
+    assert torch.equal(out16.float(), out)
+
+
+def test_clip_properties(clip_engine):
+    from diff_mining_amd import synth
+    ids = torch.from_numpy(synth.synth_token_ids(5, seed=11))
+    a = clip_engine.clip_encode(ids)
+    assert torch.equal(a, clip_engine.clip_encode(ids))                      # deterministic
+    perm = torch.tensor([3, 0, 4, 1, 2])
+    assert torch.equal(clip_engine.clip_encode(ids[perm]), a[perm])          # batch-position invariant
+    ids2 = ids.clone()
+    ids2[:, 40:] = 1234                                                      # causal mask: later tokens cannot matter
+    b = clip_engine.clip_encode(ids2)
+    assert torch.equal(a[:, :40], b[:, :40]) and not torch.equal(a[:, 40:], b[:, 40:])
+    assert torch.isfinite(a).all()
+
+
+def test_clip_to_scoring(clip_engine, sd15_weights_f16):
+    """ids -> c on the GPU -> dm_engine_set_prompts -> scoring grid (compute.py:51,75-79,134-160)."""
+    from diff_mining_amd import synth
+    from diff_mining_amd.typicality import TypicalityScorer
+    eng = clip_engine
+    if not eng._finalized:
+        eng.load_state_dict(sd15_weights_f16)
+    c = eng.clip_encode(torch.from_numpy(synth.synth_token_ids(2)))          # [2,77,768] fp32: cond, null
+    x, _, _, _ = synth.synth_inputs(1, 2, 8, 8)
+    sc = TypicalityScorer(eng, seed=42, N=2, t_min=0.1, t_max=0.7)
+    grid = sc.compute_losses(torch.from_numpy(x), c)
+    assert grid.shape == (2, 2, 4, 8, 8) and torch.isfinite(grid.float()).all()
+    assert not torch.equal(grid[:, 0], grid[:, 1])
+
+
+def test_clip_rejects_bad_input(clip_sd):
+    from diff_mining_amd.engine import EngineError, UNetEngine
+    eng = UNetEngine(0)
+    try:
+        with pytest.raises(EngineError):
+            eng.clip_encode(torch.zeros(1, 77, dtype=torch.int64))           # no weights
+        sd = {("text_model." + k): v for k, v in clip_sd.items()}           # prefixed names are accepted
+        sd["text_model.embeddings.position_ids"] = np.arange(77, dtype=np.float32)[None]
+        sd.pop("text_model.final_layer_norm.bias")
+        with pytest.raises(EngineError):
+            eng.load_clip_state_dict(sd)
+    finally:
+        eng.close()

@@ -237,3 +237,44 @@ def test_vae_golden_reproduces():
     sd = _vae_sd()
     lat, mom = vae_ref.vae_encode(sd, torch.from_numpy(g["image"]).float(), torch.from_numpy(g["noise"]).float(), autocast=True)
     assert np.array_equal(mom.numpy(), g["moments"]) and np.array_equal(lat.numpy(), g["latents"])
+
+
+# ---- CLIP text tower (oracle/clip_ref.py) — PINNED against transformers ----------
+def test_clip_spec_counts():
+    from diff_mining_amd.clip_spec import canonical_clip_name, clip_text_param_count, clip_text_tensor_spec
+    spec = clip_text_tensor_spec()
+    assert len(spec) == 196 and clip_text_param_count() == 123_060_480        # CLIP ViT-L/14 text encoder
+    assert canonical_clip_name("text_model.encoder.layers.3.mlp.fc1.weight") == "encoder.layers.3.mlp.fc1.weight"
+    assert canonical_clip_name("text_encoder.text_model.final_layer_norm.bias") == "final_layer_norm.bias"
+    assert canonical_clip_name("text_model.embeddings.position_ids") is None
+
+
+def test_clip_oracle_matches_transformers_fixture():
+    """tests/golden/clip_text.npz was produced by `transformers.CLIPTextModel` itself (tests/make_golden.py)
+    on the synthetic weights: the restatement agrees to fp32 round-off, so this oracle is pinned."""
+    from diff_mining_amd import synth
+    from oracle import clip_ref
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clip_text.npz"))
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_clip_state_dict(seed=0).items()}
+    used = set()
+    out = clip_ref.clip_text_forward(sd, torch.from_numpy(g["input_ids"]), autocast=False, used_keys=used)
+    ref = torch.from_numpy(g["last_hidden_state"])
+    assert used == set(sd.keys())
+    assert (out - ref).abs().max().item() < 2e-5
+    # causal: truncating the prompt does not change the earlier positions
+    short = clip_ref.clip_text_forward(sd, torch.from_numpy(g["input_ids"][:, :9]), autocast=False)
+    assert (short - ref[:, :9]).abs().max().item() < 2e-5
+    o16 = clip_ref.clip_text_forward(sd, torch.from_numpy(g["input_ids"]), autocast=True)
+    assert ((o16 - ref).norm() / ref.norm()).item() < 3e-3
+
+
+def test_category_prompt_templates():
+    """compute.py:41-48 (the `faces` branch is dead in the CLI but kept), mirrored on the host."""
+    from diff_mining_amd.typicality import CategoryFeatures
+    from oracle import clip_ref
+    cats = ["", "1930", "new_york"]
+    for which in ("faces", "cars", "places", "geo", "ftt"):
+        assert CategoryFeatures.prompts(which, cats) == clip_ref.category_prompts(which, cats)
+    assert CategoryFeatures.prompts("cars", cats) == ["A car.", "A car at the 1930's.", "A car at the new_york's."]
+    assert CategoryFeatures.prompts("places", cats) == ["", "Image of 1930.", "Image of new york."]
+    assert CategoryFeatures.prompts("ftt", cats) == ["", "1930", "new_york"]
