@@ -18,7 +18,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 def family(name):
     if "igemm" in name:
         return "igemm_kernel+igemm_big_kernel"
-    if "attn_kernel" in name:
+    if "attn_" in name:
         return "attention"
     if "gn_" in name:
         return "groupnorm"
