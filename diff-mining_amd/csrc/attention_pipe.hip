@@ -244,7 +244,9 @@ void attn_pipe_kernel(AttnParams p) {
         const unsigned vcur = vbase + (unsigned)(s0 * STAGE); // V(t)
         if (wait3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TICK(0);
-        __syncthreads();
+        // raw barrier: __syncthreads() carries a fence that the compiler lowers to vmcnt(0), which would undo
+        // the counted wait above (all LDS reads of the previous iteration were already waited for)
+        asm volatile("s_barrier" ::: "memory");
         TICK(1);
         // ---------------- phase A: S(t+1) MFMAs || exp of S(t) || DMA issue || V^T reads ----------------
         half8 kf[KS][4];

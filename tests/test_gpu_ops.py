@@ -187,3 +187,29 @@ def test_layernorm(Cc):
     d = U.dev()
     y = U.op_layernorm(x.to(d), g.to(d), b.to(d))
     U.assert_close_fp16(y, ref, f"layernorm C={Cc}")
+
+
+@pytest.mark.parametrize("M,Cout,epi", [(131072, 320, 0), (131072 + 77, 960, 0), (140000, 2560, 1), (655360, 320, 0)])
+def test_igemm_k320_many_rows(M, Cout, epi):
+    """The K = 320 dense layers of the 64x64 transformer blocks at production row counts (>= 128 Ki rows, ragged
+    last row tile): bias, residual, GEGLU."""
+    K = 320
+    x = U.f16_randn(1, 1, M, K, seed=1)
+    w = U.f16_randn(Cout, K, seed=2, scale=K ** -0.5)
+    b = U.f16_randn(Cout, seed=3, scale=0.1)
+    d = U.dev()
+    if epi == 1:
+        wp, bp = U.pack_geglu(w, b)
+        y = U.op_igemm(x.to(d), wp.to(d), bp.to(d), epi=1).view(M, Cout // 2)
+        rows = torch.cat([torch.arange(0, 4096), torch.arange(M - 4096, M)])
+        hg = F.linear(x.view(M, K)[rows].float(), w.float(), b.float()).half().float()
+        ref = (hg[:, :Cout // 2] * F.gelu(hg[:, Cout // 2:]).half().float())
+        U.assert_close_fp16(y[rows.to(d)], ref, "k320 geglu", rel=3e-3, abs_frac=4e-3)
+    else:
+        r = U.f16_randn(1, 1, M, Cout, seed=4)
+        y = U.op_igemm(x.to(d), w.to(d), b.to(d), res=r.to(d)).view(M, Cout)
+        rows = torch.cat([torch.arange(0, 4096), torch.arange(M - 4096, M)])
+        ref = F.linear(x.view(M, K)[rows].float(), w.float(), b.float()).half().float() + r.view(M, Cout)[rows].float()
+        U.assert_close_fp16(y[rows.to(d)], ref, "k320 dense+bias+res")
+        y2 = U.op_igemm(x.to(d), w.to(d)).view(M, Cout)
+        U.assert_close_fp16(y2[rows.to(d)], F.linear(x.view(M, K)[rows].float(), w.float()), "k320 dense no bias")
