@@ -26,8 +26,16 @@ struct IGemmParams {
     int H, W, OH, OW;    // source spatial dims / output spatial dims (dense: H=OH=1, W=OW=M)
     int mode, epi;
     int ldy, ldres, temb_ld;
+    // split-K (small-M layers: too few tiles to fill the chip): > 1 -> the k range is cut into `ksplit` parts,
+    // each block writes its fp32 partial tile to partial[split][M][Cout]; launch_igemm then runs the
+    // reduction + epilogue (bias, time-embedding, residual, fp16 rounding points as in the fused epilogue)
+    int ksplit = 0;
+    float* partial = nullptr;
 };
 hipError_t launch_igemm(const IGemmParams& p, hipStream_t s);
+// number of k parts for a layer with `spatial` output positions per sample (1 = no split); batch independent;
+// the caller provides the workspace
+int igemm_splitk_parts(const IGemmParams& p, int spatial);
 
 // ---- K4/K5: flash attention (self and cross), head_dim 40/80/160 ------------------------------
 struct AttnParams {

@@ -441,7 +441,6 @@ struct Fwd {
         if (cin != cv.cin) DM_FAIL(e, "igemm: channel mismatch %d vs %d", cin, cv.cin);
         const int cout_y = (epi == EPI_GEGLU) ? cv.cout / 2 : cv.cout;
         DM_TRY(alloc(y, x.N, OH, OW, cout_y));
-        if (dry) return 0;
         IGemmParams p;
         p.X = x.p; p.X2 = x2 ? x2->p : nullptr; p.Wp = cv.w; p.bias = cv.b; p.temb = temb;
         p.res = res ? res->p : nullptr; p.Y = y->p;
@@ -449,10 +448,21 @@ struct Fwd {
         p.mode = mode; p.epi = epi; p.ldy = cout_y; p.ldres = res ? res->C : 0; p.temb_ld = temb_ld;
         if (mode == IG_DENSE) { p.M = (int)x.rows(); p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M; }
         else { p.M = x.N * OH * OW; p.H = x.H; p.W = x.W; p.OH = OH; p.OW = OW; }
-        const double flops = 2.0 * (double)p.M * cv.cout * (double)((mode == IG_DENSE ? 1 : 9) * cin);
-        DM_TRY(prof_begin(0, flops, p.M, cv.cout, (mode == IG_DENSE ? 1 : 9) * cin, mode + 10 * epi));
-        DM_HIP(e, launch_igemm(p, s));
-        DM_TRY(prof_end());
+        // small-M layers: split-K through an fp32 workspace (also accounted for in the dry run)
+        const int parts = igemm_splitk_parts(p, OH * OW);
+        size_t poff = (size_t)-1;
+        if (parts > 1) {
+            void* pp;
+            DM_TRY(alloc_raw((size_t)parts * p.M * cv.cout * sizeof(float), &poff, &pp));
+            p.ksplit = parts; p.partial = (float*)pp;
+        }
+        if (!dry) {
+            const double flops = 2.0 * (double)p.M * cv.cout * (double)((mode == IG_DENSE ? 1 : 9) * cin);
+            DM_TRY(prof_begin(0, flops, p.M, cv.cout, (mode == IG_DENSE ? 1 : 9) * cin, mode + 10 * epi));
+            DM_HIP(e, launch_igemm(p, s));
+            DM_TRY(prof_end());
+        }
+        if (parts > 1) free_raw(poff);
         return 0;
     }
     int dense(const ConvW& cv, const Tensor& x, const Tensor* x2, const Tensor* res, int epi, Tensor* y) {
@@ -1316,6 +1326,20 @@ int dm_patch_embed(dm_engine* e, const void* feat_f32_dev, int C, int h, int w, 
     DM_HIP(e, hipSetDevice(e->device));
     DM_HIP(e, launch_patch_embed((const float*)feat_f32_dev, C, h, w, boxes_dev, n_patches, (float*)out_f32_dev, (hipStream_t)stream));
     return 0;
+}
+
+int dm_op_igemm_splitk(void* stream, const void* X, const void* X2, const void* Wp, const void* bias, const void* temb,
+                       const void* res, void* Y, int N, int H, int W, int C1, int C2, int Cout, int OH, int OW, int mode,
+                       int temb_ld, int ksplit, void* workspace_f32) {
+    IGemmParams p;
+    p.X = (const f16*)X; p.X2 = (const f16*)X2; p.Wp = (const f16*)Wp; p.bias = (const f16*)bias;
+    p.temb = (const f16*)temb; p.res = (const f16*)res; p.Y = (f16*)Y;
+    p.Cout = Cout; p.Cin = C1 + C2; p.C1 = C1; p.mode = mode; p.epi = EPI_PLAIN;
+    p.ldy = Cout; p.ldres = Cout; p.temb_ld = temb_ld;
+    if (mode == IG_DENSE) { p.M = N * H * W; p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M; }
+    else { p.M = N * OH * OW; p.H = H; p.W = W; p.OH = OH; p.OW = OW; }
+    p.ksplit = ksplit; p.partial = (float*)workspace_f32;
+    return launch_igemm(p, (hipStream_t)stream) == hipSuccess ? 0 : 1;
 }
 
 int dm_op_attention512(void* stream, const void* Q, const void* K, const void* V, void* O, int B, int T, int ld, int ldo,

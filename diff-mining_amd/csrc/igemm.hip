@@ -27,6 +27,7 @@ namespace dm {
 
 hipError_t launch_igemm_big(const IGemmParams& p, hipStream_t s);     // igemm_big.hip (256 x 320 tile)
 hipError_t launch_igemm64(const IGemmParams& p, hipStream_t s);      // igemm64.hip (64-channel waves)
+hipError_t launch_igemm_splitk(const IGemmParams& p, hipStream_t s);  // igemm_splitk.hip
 
 // Shape -> tile choice (measured on MI355X at the bench batch, tools/bench_ops.py): the 256x320 tile
 // pays on the k >= 640 linears, on the >= 640-channel / concat 3x3 convs and on the wide GEGLU
@@ -42,7 +43,23 @@ static bool use_big(const IGemmParams& p) {
     return p.Cin >= 640;
 }
 
+// Layers at <= 8x8 spatial positions per sample (M = 10 240 rows at the bench batch: 320 tiles for 256 CUs):
+// cut k into up to four parts so the launch has ~5 blocks per CU (DM_IGEMM_SPLITK=0 disables).  The decision
+// depends on the layer (spatial size, k extent, Cout) and never on the batch size, so a sample's result
+// does not depend on how many samples share the call.  Returns 1 when the shape runs unsplit.
+int igemm_splitk_parts(const IGemmParams& p, int spatial) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("DM_IGEMM_SPLITK"); on = e ? atoi(e) : 1; }
+    if (!on || spatial > 64 || p.epi != EPI_PLAIN || p.Cout % 320 != 0 || p.Cin % BK != 0 || p.C1 % BK != 0) return 1;
+    const int nk = ((p.mode == IG_DENSE) ? 1 : 9) * (p.Cin / BK);
+    if (nk < 40) return 1;
+    for (int k = 4; k >= 2; --k)
+        if (nk % k == 0 && nk / k >= 10) return k;
+    return 1;
+}
+
 hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
+    if (p.ksplit > 1 && p.partial) return launch_igemm_splitk(p, s);
     if (p.Cout % 160 != 0 || p.mode == IG_CONV3_S2P0) return launch_igemm64(p, s);        // VAE channel counts
     if (p.Cout % 160 != 0 || p.Cin % BK != 0 || p.C1 % BK != 0 || p.M <= 0) return hipErrorInvalidValue;
     if (use_big(p)) return launch_igemm_big(p, s);

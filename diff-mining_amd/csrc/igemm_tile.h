@@ -139,7 +139,7 @@ __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int WC, int EPI, int NI>
+template <int WC, int EPI, int NI, bool SPLIT = false>
 __global__ __launch_bounds__(128 * WC, 2)
 void igemm_kernel(IGemmParams p) {
     constexpr int WP = 2;
@@ -168,6 +168,8 @@ void igemm_kernel(IGemmParams p) {
         const int xcd = b & 7, loc = b >> 3;
         v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
+    int split = 0;
+    if (SPLIT) { split = v % p.ksplit; v = v / p.ksplit; }    // the parts of a tile sit next to each other (same XCD)
     const int pt = v / tiles_c;
     const int ct = v - pt * tiles_c;
     const int p0 = pt * TP;
@@ -177,7 +179,9 @@ void igemm_kernel(IGemmParams p) {
     const int C2 = p.Cin - C1;
     const int ntaps = (p.mode == IG_DENSE) ? 1 : 9;
     const int cpt = p.Cin / BK;
-    const int nk = ntaps * cpt;
+    const int nk_all = ntaps * cpt;
+    const int kt_begin = SPLIT ? split * (nk_all / p.ksplit) : 0;          // ksplit divides nk_all (launcher)
+    const int nk = SPLIT ? nk_all / p.ksplit : nk_all;
     const int Ktot = ntaps * p.Cin;
     const int OHW = p.OH * p.OW;
 
@@ -187,7 +191,7 @@ void igemm_kernel(IGemmParams p) {
     const f16* wsrc[WI];
 #pragma unroll
     for (int k = 0; k < WI; ++k)
-        wsrc[k] = p.Wp + (size_t)(c0out + (wid + k * NW) * 8 + lrow) * Ktot + lchunk;
+        wsrc[k] = p.Wp + (size_t)(c0out + (wid + k * NW) * 8 + lrow) * Ktot + lchunk + (SPLIT ? kt_begin * BK : 0);
     int xn[XI], xoh[XI], xow[XI];
 #pragma unroll
     for (int k = 0; k < XI; ++k) {
@@ -236,13 +240,22 @@ void igemm_kernel(IGemmParams p) {
             xinc[k] = (off >= 0) ? BK : 0;
         }
     };
-    int ld_tap = 0, ld_cc = 0;
+    int ld_tap = SPLIT ? kt_begin / cpt : 0, ld_cc = SPLIT ? kt_begin % cpt : 0;
+    bool first_prepare = true;
     auto prepare = [&]() {                                   // pointers for the next tile to load
-        if (ld_cc == 0) set_tap(ld_tap);
+        if (SPLIT && first_prepare && ld_cc != 0) {
+            // a part may start in the middle of a tap: set the tap, then move to the right channel slab
+            set_tap(ld_tap);
+            const bool second = ld_cc * BK >= C1;
+#pragma unroll
+            for (int k = 0; k < XI; ++k)
+                if (xpix[k] >= 0) xsrc[k] = second ? (p.X2 + xpix[k] * C2 + (ld_cc * BK - C1) + lchunk) : (xsrc[k] + ld_cc * BK);
+        } else if (ld_cc == 0) set_tap(ld_tap);
         else if (ld_cc * BK == C1) {
 #pragma unroll
             for (int k = 0; k < XI; ++k) if (xpix[k] >= 0) xsrc[k] = p.X2 + xpix[k] * C2 + lchunk;
         }
+        first_prepare = false;
         if (++ld_cc == cpt) { ld_cc = 0; ++ld_tap; }
     };
     auto load_piece = [&](int buf, int idx) {                // idx in [0, NL): W pieces first, then X
@@ -316,6 +329,19 @@ void igemm_kernel(IGemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     step((nk - 1) & 1, false);
+    if (SPLIT) {
+        // fp32 partial tile straight from the fragments (16 bytes per lane): partial[split][m][c]
+        float* base = p.partial + (size_t)split * p.M * p.Cout;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = p0 + wp * 64 + 16 * j + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                *reinterpret_cast<floatx4*>(base + (size_t)m * p.Cout + c0out + wc * (16 * NI) + 16 * i + 4 * lg) = acc[i][j];
+        }
+        return;
+    }
     epilogue_lds<EPI, 128 * WC, TP, TC, NI>(p, acc, smem, smem + 2 * STAGE, p0, c0out, wc, wp, l15, lg, OHW);
 }
 

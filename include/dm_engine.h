@@ -202,6 +202,11 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
 int dm_op_attention(void* stream, const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv,
                     int ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso, const int32_t* kv_slot,
                     int B, int heads, int Tq, int Tk, int D, float scale);
+/* igemm with the k range cut into `ksplit` parts (>= 2, dividing the k steps) through an fp32 workspace of
+ * ksplit * M * Cout floats, followed by the reduction + epilogue; the engine uses it for the 8x8 layers.   */
+int dm_op_igemm_splitk(void* stream, const void* X, const void* X2, const void* Wp, const void* bias, const void* temb,
+                       const void* res, void* Y, int N, int H, int W, int C1, int C2, int Cout, int OH, int OW,
+                       int mode, int temb_ld, int ksplit, void* workspace_f32);
 /* single-head attention with head_dim 512 (VAE mid block): Q/K/V [B][T][ld], O [B][T][ldo] */
 int dm_op_attention512(void* stream, const void* Q, const void* K, const void* V, void* O, int B, int T, int ld,
                        int ldo, float scale);

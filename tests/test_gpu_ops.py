@@ -213,3 +213,30 @@ def test_igemm_k320_many_rows(M, Cout, epi):
         U.assert_close_fp16(y[rows.to(d)], ref, "k320 dense+bias+res")
         y2 = U.op_igemm(x.to(d), w.to(d)).view(M, Cout)
         U.assert_close_fp16(y2[rows.to(d)], F.linear(x.view(M, K)[rows].float(), w.float()), "k320 dense no bias")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,C2,Cout,mode,ks", [(40, 8, 8, 1280, 0, 1280, 1, 4), (16, 8, 8, 1280, 1280, 1280, 1, 8),
+                                                       (3, 9, 7, 640, 0, 320, 1, 3), (1, 1, 500, 2560, 0, 640, 0, 4)])
+def test_igemm_splitk_matches_unsplit(N, H, W, Cin, C2, Cout, mode, ks):
+    """Split-K (fp32 partial tiles + reduction/epilogue kernel) vs the fused single-pass kernel: same rounding
+    points (bias -> fp16, + time embedding -> fp16, + residual -> fp16), so results agree to fp32 summation order."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    taps = 9 if mode else 1
+    x = U.f16_randn(N, H, W, Cin, seed=1).to(d)
+    x2 = U.f16_randn(N, H, W, C2, seed=2).to(d) if C2 else None
+    w = U.f16_randn(Cout, taps * (Cin + C2), seed=3, scale=(taps * (Cin + C2)) ** -0.5).to(d)
+    b = U.f16_randn(Cout, seed=4, scale=0.1).to(d)
+    temb = U.f16_randn(N, Cout, seed=5).to(d) if mode else None
+    res = U.f16_randn(N, H, W, Cout, seed=6).to(d)
+    ref = U.op_igemm(x, w, b, X2=x2, temb=temb, res=res, mode=mode)
+    y = torch.empty_like(ref)
+    ws = torch.empty(ks * N * H * W * Cout, dtype=torch.float32, device=d)
+    rc = lib.dm_op_igemm_splitk(U.stream(), U.ptr(x), U.ptr(x2), U.ptr(w), U.ptr(b), U.ptr(temb), U.ptr(res), U.ptr(y),
+                                N, H, W, Cin, C2, Cout, H, W, mode, temb.stride(0) if temb is not None else 0, ks, U.ptr(ws))
+    assert rc == 0
+    torch.cuda.synchronize()
+    diff = (y.float() - ref.float()).abs()
+    # identical except where the fp32 summation order flips an fp16 rounding (1 ulp, rare)
+    assert (diff > 0).float().mean().item() < 0.02 and diff.max().item() <= 2e-3 * ref.float().abs().max().item()
