@@ -317,3 +317,23 @@ def test_dift_patch_embeddings(engine):
     assert len(calls) == 1 and torch.equal(torch.cat([a, b]).cpu(), torch.from_numpy(out))
     # empty window -> NaN like numpy's mean of an empty slice
     assert torch.isnan(fz.patch_embeddings(feat, [(10, 10, 10, 40)], image_hw)).all()
+
+
+def test_chunked_calls_are_batch_independent(engine):
+    """More work than one U-Net batch holds (workspace chunking of dm_score / dm_score_conds, and the
+    split-K layers): 12 draws x 2 prompts at 128x128 latents (chunks of 40 / 20 samples) equal the same
+    samples scored in other groupings, bit for bit."""
+    x, eps, t, c = _inputs(128, 128, 12)
+    engine.set_prompts(c)
+    nb, tb, cc, slots = _tile(eps, t, c)
+    full = engine.score(x, nb, tb, slots)                                  # 24 samples -> one chunk of 24
+    shared = engine.score_conds(x, eps, t, 2)                              # 12 draws -> one shared chunk
+    assert torch.equal(shared, full)
+    part = torch.cat([engine.score(x, nb[:7], tb[:7], slots[:7]), engine.score(x, nb[7:], tb[7:], slots[7:])])
+    assert torch.equal(part, full)
+    # 64x64, 100 draws x 2 prompts = 200 samples: 160 + 40 in dm_score, 80 + 20 draws in dm_score_conds
+    x, eps, t, c = _inputs(64, 64, 100)
+    nb, tb, cc, slots = _tile(eps, t, c)
+    a = engine.score_conds(x, eps, t, 2)
+    b = engine.score(x, nb, tb, slots)
+    assert a.shape == (200, 4, 64, 64) and torch.equal(a, b)
