@@ -31,6 +31,12 @@ struct IGemmParams {
     // reduction + epilogue (bias, time-embedding, residual, fp16 rounding points as in the fused epilogue)
     int ksplit = 0;
     float* partial = nullptr;
+    // LayerNorm folded into the GEMM (transformer blocks: LN -> Linear): X is the un-normalised token matrix,
+    // Wp = W * diag(gamma) (fp16), and the epilogue applies  y = rstd_r * (acc - mean_r * ln_s[c]) + ln_t[c]
+    // with ln_s[c] = sum_k Wp[c][k], ln_t[c] = sum_k W[c][k] beta[k] + bias[c];  ln_stats [M][2] = (mean, rstd)
+    const float* ln_stats = nullptr;
+    const float* ln_s = nullptr;
+    const float* ln_t = nullptr;
 };
 hipError_t launch_igemm(const IGemmParams& p, hipStream_t s);
 // number of k parts for a layer with `spatial` output positions per sample (1 = no split); batch independent;
@@ -59,6 +65,8 @@ hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, in
                            f16* Y, hipStream_t s);
 hipError_t launch_layernorm(const f16* X, int rows, int C, const float* gamma, const float* beta,
                             float eps, f16* Y, hipStream_t s);
+// per-row (mean, rstd) of X [rows][C] -> stats [rows][2] fp32 (the statistics half of LayerNorm)
+hipError_t launch_ln_stats(const f16* X, int rows, int C, float eps, float* stats, hipStream_t s);
 
 // ---- K8/K9/K10/K11 and glue -------------------------------------------------------------------
 // temb0[b][320] = fp16(sinusoid table[t[b]])

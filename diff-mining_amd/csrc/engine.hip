@@ -51,9 +51,11 @@ struct HostTensor {
 struct ConvW { const f16* w = nullptr; const f16* b = nullptr; int cin = 0, cout = 0, k = 0; };
 struct NormW { const float* g = nullptr; const float* b = nullptr; int c = 0; };
 struct ResW { NormW n1, n2; ConvW c1, c2, sc; bool has_sc = false; int temb_off = 0; int cin = 0, cout = 0; };
+struct LnFold { ConvW w; const float* s = nullptr; const float* t = nullptr; };   // Linear with the preceding LayerNorm folded in
 struct TfmW {
     NormW gn, ln1, ln2, ln3;
     ConvW proj_in, proj_out, qkv, o1, q2, kv2, o2, ff1, ff2;
+    LnFold qkv_ln, q2_ln, ff1_ln;       // LN1 -> to_q/k/v, LN2 -> to_q (cross), LN3 -> GEGLU projection
     int c = 0; int layer = 0;
 };
 struct UpBlockW { ResW res[3]; TfmW tf[3]; bool attn = false; ConvW up; bool has_up = false; };
@@ -329,6 +331,44 @@ int pack_geglu(Packer& P, const std::string& name, int c, ConvW* o) {
     return 0;
 }
 
+// LayerNorm(gamma, beta) followed by Linear(W [rows][c], bias): W' = fp16(W * gamma) (row order given by `perm`, the
+// GEGLU quad interleave, or identity), s[n] = sum_k W'[n][k], t[n] = sum_k W[n][k] beta[k] + bias[n]  (fp32).
+int pack_ln_fold(Packer& P, const std::string& ln, const std::vector<std::string>& mats, int rows_each, int c,
+                 const std::string& bias_name, bool geglu, LnFold* o) {
+    HostTensor* g = P.get(ln + ".weight", {c});
+    HostTensor* b = P.get(ln + ".bias", {c});
+    if (!g || !b) return 1;
+    const int rows = (int)mats.size() * rows_each;
+    std::vector<f16> wp((size_t)rows * c);
+    std::vector<float> sv(rows), tv(rows);
+    HostTensor* bias = bias_name.empty() ? nullptr : P.get(bias_name, {rows});
+    if (!bias_name.empty() && !bias) return 1;
+    for (int rho = 0; rho < rows; ++rho) {
+        int srcr = rho;
+        if (geglu) {            // packed row rho = 16F + 4q + r  <-  r<2 ? hidden 8F+2q+r : gate rows/2 + 8F+2q+(r-2)
+            const int F = rho >> 4, q = (rho & 15) >> 2, r = rho & 3;
+            srcr = (r < 2) ? (8 * F + 2 * q + r) : (rows / 2 + 8 * F + 2 * q + (r - 2));
+        }
+        HostTensor* w = P.get(mats[srcr / rows_each] + ".weight", {rows_each, c});
+        if (!w) return 1;
+        const f16* wr = w->data.data() + (size_t)(srcr % rows_each) * c;
+        double ss = 0.0, tt = 0.0;
+        for (int k = 0; k < c; ++k) {
+            const f16 wf = (f16)((float)wr[k] * (float)g->data[k]);
+            wp[(size_t)rho * c + k] = wf;
+            ss += (double)(float)wf;
+            tt += (double)(float)wr[k] * (double)(float)b->data[k];
+        }
+        sv[rho] = (float)ss;
+        tv[rho] = (float)(tt + (bias ? (double)(float)bias->data[srcr] : 0.0));
+    }
+    o->w.w = as_ptr(P.put(wp.data(), wp.size() * 2));
+    o->w.b = nullptr; o->w.cin = c; o->w.cout = rows; o->w.k = 1;
+    o->s = as_fptr(P.put(sv.data(), sv.size() * 4));
+    o->t = as_fptr(P.put(tv.data(), tv.size() * 4));
+    return 0;
+}
+
 int pack_resnet(Packer& P, const std::string& name, int cin, int cout, ResW* r, std::vector<f16>& tw, std::vector<f16>& tb) {
     r->cin = cin; r->cout = cout;
     DM_TRY(pack_norm(P, name + ".norm1", cin, &r->n1));
@@ -374,6 +414,10 @@ int pack_tfm(Packer& P, const std::string& name, int c, TfmW* t, dm_engine* e) {
     DM_TRY(pack_geglu(P, b + ".ff.net.0.proj", c, &t->ff1));
     DM_TRY(pack_dense(P, b + ".ff.net.2", c, 4 * c, false, true, &t->ff2));
     DM_TRY(pack_dense(P, name + ".proj_out", c, c, true, true, &t->proj_out));
+    // the three LayerNorm -> Linear pairs, folded (the unfused weights above stay for DM_LN_FOLD=0)
+    DM_TRY(pack_ln_fold(P, b + ".norm1", {b + ".attn1.to_q", b + ".attn1.to_k", b + ".attn1.to_v"}, c, c, "", false, &t->qkv_ln));
+    DM_TRY(pack_ln_fold(P, b + ".norm2", {b + ".attn2.to_q"}, c, c, "", false, &t->q2_ln));
+    DM_TRY(pack_ln_fold(P, b + ".norm3", {b + ".ff.net.0.proj"}, 8 * c, c, b + ".ff.net.0.proj.bias", true, &t->ff1_ln));
     return 0;
 }
 
@@ -389,6 +433,7 @@ void rebase_tfm(TfmW& t, char* base) {
     rebase_norm(t.gn, base); rebase_norm(t.ln1, base); rebase_norm(t.ln2, base); rebase_norm(t.ln3, base);
     rebase_conv(t.proj_in, base); rebase_conv(t.proj_out, base); rebase_conv(t.qkv, base); rebase_conv(t.o1, base);
     rebase_conv(t.q2, base); rebase_conv(t.kv2, base); rebase_conv(t.o2, base); rebase_conv(t.ff1, base); rebase_conv(t.ff2, base);
+    for (LnFold* f : {&t.qkv_ln, &t.q2_ln, &t.ff1_ln}) { rebase_conv(f->w, base); rebase(f->s, base); rebase(f->t, base); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -436,7 +481,8 @@ struct Fwd {
 
     // Y = igemm(X [, X2]) with fused epilogue.  Output spatial dims given by (OH, OW).
     int igemm(const ConvW& cv, int mode, const Tensor& x, const Tensor* x2, int OH, int OW,
-              const f16* temb, int temb_ld, const Tensor* res, int epi, Tensor* y) {
+              const f16* temb, int temb_ld, const Tensor* res, int epi, Tensor* y, const LnFold* ln = nullptr,
+              const float* ln_stats = nullptr) {
         const int cin = x.C + (x2 ? x2->C : 0);
         if (cin != cv.cin) DM_FAIL(e, "igemm: channel mismatch %d vs %d", cin, cv.cin);
         const int cout_y = (epi == EPI_GEGLU) ? cv.cout / 2 : cv.cout;
@@ -448,8 +494,9 @@ struct Fwd {
         p.mode = mode; p.epi = epi; p.ldy = cout_y; p.ldres = res ? res->C : 0; p.temb_ld = temb_ld;
         if (mode == IG_DENSE) { p.M = (int)x.rows(); p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M; }
         else { p.M = x.N * OH * OW; p.H = x.H; p.W = x.W; p.OH = OH; p.OW = OW; }
+        if (ln) { p.ln_stats = ln_stats; p.ln_s = ln->s; p.ln_t = ln->t; }
         // small-M layers: split-K through an fp32 workspace (also accounted for in the dry run)
-        const int parts = igemm_splitk_parts(p, OH * OW);
+        const int parts = ln ? 1 : igemm_splitk_parts(p, OH * OW);
         size_t poff = (size_t)-1;
         if (parts > 1) {
             void* pp;
@@ -484,6 +531,21 @@ struct Fwd {
         }
         free_raw(poff); free_raw(soff);
         return 0;
+    }
+    // LayerNorm folded into the following Linear: per-row (mean, rstd), then the GEMM on the raw tokens with
+    // the correction in its epilogue (saves writing and re-reading the normalised token matrix)
+    int ln_dense(const LnFold& f, const Tensor& x, int epi, Tensor* y) {
+        size_t soff; void* sp;
+        DM_TRY(alloc_raw((size_t)x.rows() * 2 * sizeof(float), &soff, &sp));
+        if (!dry) DM_HIP(e, launch_ln_stats(x.p, (int)x.rows(), x.C, LN_EPS, (float*)sp, s));
+        const int rc = igemm(f.w, IG_DENSE, x, nullptr, x.H, x.W, nullptr, 0, nullptr, epi, y, &f, (const float*)sp);
+        free_raw(soff);
+        return rc;
+    }
+    static bool ln_fold_enabled() {
+        static int on = -1;
+        if (on < 0) { const char* ev = getenv("DM_LN_FOLD"); on = ev ? atoi(ev) : 1; }
+        return on != 0;
     }
     int layernorm(const NormW& nw, const Tensor& x, Tensor* y) {
         DM_TRY(alloc(y, x.N, x.H, x.W, x.C));
@@ -531,9 +593,12 @@ struct Fwd {
         DM_TRY(groupnorm(t.gn, x, nullptr, ATTN_GN_EPS, false, &n));
         DM_TRY(dense(t.proj_in, n, nullptr, nullptr, EPI_PLAIN, &t0));
         free(n);
-        DM_TRY(layernorm(t.ln1, t0, &ln));
-        DM_TRY(dense(t.qkv, ln, nullptr, nullptr, EPI_PLAIN, &qkv));
-        free(ln);
+        if (ln_fold_enabled()) DM_TRY(ln_dense(t.qkv_ln, t0, EPI_PLAIN, &qkv));
+        else {
+            DM_TRY(layernorm(t.ln1, t0, &ln));
+            DM_TRY(dense(t.qkv, ln, nullptr, nullptr, EPI_PLAIN, &qkv));
+            free(ln);
+        }
         DM_TRY(alloc(&a, B, x.H, x.W, C));
         if (!dry) DM_TRY(attention(qkv.p, 3 * C, (long long)T * 3 * C, qkv.p + C, qkv.p + 2 * C, 3 * C, (long long)T * 3 * C,
                                    nullptr, B, T, T, C, a.p));
@@ -547,9 +612,12 @@ struct Fwd {
     int transformer_post(const TfmW& t, const Tensor& x, Tensor& t1, const int32_t* slots, Tensor* out) {
         const int C = t.c, T = x.H * x.W, B = x.N;
         Tensor ln, a, q, t2, ff, t3;
-        DM_TRY(layernorm(t.ln2, t1, &ln));
-        DM_TRY(dense(t.q2, ln, nullptr, nullptr, EPI_PLAIN, &q));
-        free(ln);
+        if (ln_fold_enabled()) DM_TRY(ln_dense(t.q2_ln, t1, EPI_PLAIN, &q));
+        else {
+            DM_TRY(layernorm(t.ln2, t1, &ln));
+            DM_TRY(dense(t.q2, ln, nullptr, nullptr, EPI_PLAIN, &q));
+            free(ln);
+        }
         DM_TRY(alloc(&a, B, x.H, x.W, C));
         if (!dry) {
             const f16* kv = e->kv_cache[t.layer];
@@ -567,9 +635,12 @@ struct Fwd {
         free(q);
         DM_TRY(dense(t.o2, a, nullptr, &t1, EPI_PLAIN, &t2));
         free(a); free(t1);
-        DM_TRY(layernorm(t.ln3, t2, &ln));
-        DM_TRY(dense(t.ff1, ln, nullptr, nullptr, EPI_GEGLU, &ff));
-        free(ln);
+        if (ln_fold_enabled()) DM_TRY(ln_dense(t.ff1_ln, t2, EPI_GEGLU, &ff));
+        else {
+            DM_TRY(layernorm(t.ln3, t2, &ln));
+            DM_TRY(dense(t.ff1, ln, nullptr, nullptr, EPI_GEGLU, &ff));
+            free(ln);
+        }
         DM_TRY(dense(t.ff2, ff, nullptr, &t2, EPI_PLAIN, &t3));
         free(ff); free(t2);
         DM_TRY(dense(t.proj_out, t3, nullptr, &x, EPI_PLAIN, out));
@@ -1326,6 +1397,21 @@ int dm_patch_embed(dm_engine* e, const void* feat_f32_dev, int C, int h, int w, 
     DM_HIP(e, hipSetDevice(e->device));
     DM_HIP(e, launch_patch_embed((const float*)feat_f32_dev, C, h, w, boxes_dev, n_patches, (float*)out_f32_dev, (hipStream_t)stream));
     return 0;
+}
+
+int dm_op_ln_stats(void* stream, const void* X, int rows, int C, float eps, void* stats_f32) {
+    return launch_ln_stats((const f16*)X, rows, C, eps, (float*)stats_f32, (hipStream_t)stream) == hipSuccess ? 0 : 1;
+}
+
+int dm_op_igemm_ln(void* stream, const void* X, const void* Wp_folded, const void* ln_s, const void* ln_t, const void* stats,
+                   void* Y, int M, int Cin, int Cout, int epi) {
+    IGemmParams p;
+    p.X = (const f16*)X; p.X2 = nullptr; p.Wp = (const f16*)Wp_folded; p.bias = nullptr; p.temb = nullptr; p.res = nullptr;
+    p.Y = (f16*)Y; p.Cout = Cout; p.Cin = Cin; p.C1 = Cin; p.mode = IG_DENSE; p.epi = epi;
+    p.ldy = (epi == EPI_GEGLU) ? Cout / 2 : Cout; p.ldres = 0; p.temb_ld = 0;
+    p.M = M; p.H = 1; p.W = M; p.OH = 1; p.OW = M;
+    p.ln_stats = (const float*)stats; p.ln_s = (const float*)ln_s; p.ln_t = (const float*)ln_t;
+    return launch_igemm(p, (hipStream_t)stream) == hipSuccess ? 0 : 1;
 }
 
 int dm_op_igemm_splitk(void* stream, const void* X, const void* X2, const void* Wp, const void* bias, const void* temb,

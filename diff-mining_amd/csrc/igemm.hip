@@ -28,6 +28,8 @@ namespace dm {
 hipError_t launch_igemm_big(const IGemmParams& p, hipStream_t s);     // igemm_big.hip (256 x 320 tile)
 hipError_t launch_igemm64(const IGemmParams& p, hipStream_t s);      // igemm64.hip (64-channel waves)
 hipError_t launch_igemm_splitk(const IGemmParams& p, hipStream_t s);  // igemm_splitk.hip
+hipError_t launch_igemm_tile_ln(const IGemmParams& p, hipStream_t s);  // igemm_ln.hip
+hipError_t launch_igemm_big_ln(const IGemmParams& p, hipStream_t s);   // igemm_big_ln.hip
 
 // Shape -> tile choice (measured on MI355X at the bench batch, tools/bench_ops.py): the 256x320 tile
 // pays on the k >= 640 linears, on the >= 640-channel / concat 3x3 convs and on the wide GEGLU
@@ -60,6 +62,10 @@ int igemm_splitk_parts(const IGemmParams& p, int spatial) {
 
 hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
     if (p.ksplit > 1 && p.partial) return launch_igemm_splitk(p, s);
+    if (p.ln_stats) {
+        if (!p.ln_s || !p.ln_t || p.Cout % 160 != 0) return hipErrorInvalidValue;
+        return use_big(p) ? launch_igemm_big_ln(p, s) : launch_igemm_tile_ln(p, s);
+    }
     if (p.Cout % 160 != 0 || p.mode == IG_CONV3_S2P0) return launch_igemm64(p, s);        // VAE channel counts
     if (p.Cout % 160 != 0 || p.Cin % BK != 0 || p.C1 % BK != 0 || p.M <= 0) return hipErrorInvalidValue;
     if (use_big(p)) return launch_igemm_big(p, s);

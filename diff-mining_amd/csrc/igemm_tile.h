@@ -45,17 +45,34 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // in-order, so a per-fragment "load, wait, use" chain (or a load queued behind the previous stores)
 // made this epilogue as long as ten k steps.  The bias of the tile's channels is staged in LDS before
 // the main loop (`bias_lds`, zeros when there is no bias).
-template <int EPI, int NTH, int TP, int TC, int NI>
+template <int EPI, int NTH, int TP, int TC, int NI, bool LN = false>
 __device__ __forceinline__ void epilogue_lds(const IGemmParams& p, floatx4 (&acc)[NI][4], char* smem, const char* bias_lds,
                                              int p0, int c0out, int wc, int wp, int l15, int lg, int OHW) {
     constexpr int TCO = (EPI == EPI_GEGLU) ? TC / 2 : TC;     // output channels of the tile
     constexpr int ROWB = TCO * 2 + 8;
-    float bz[NI][4];
+    // plain: bz = bias.  folded LayerNorm: bz = ln_t, sz = ln_s (fp32, staged behind the bias slot) and the
+    // per-row (mean, rstd) of this lane's four pixel rows.
+    float bz[NI][4], sz[LN ? NI : 1][4], mu[4], rs[4];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const half4 bv = *reinterpret_cast<const half4*>(bias_lds + (wc * (16 * NI) + 16 * i + 4 * lg) * 2);
+        const int cl = wc * (16 * NI) + 16 * i + 4 * lg;
+        if (LN) {
+            const floatx4 tv = *reinterpret_cast<const floatx4*>(bias_lds + 1024 + TC * 4 + cl * 4);
+            const floatx4 sv = *reinterpret_cast<const floatx4*>(bias_lds + 1024 + cl * 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bz[i][r] = (float)bv[r];
+            for (int r = 0; r < 4; ++r) { bz[i][r] = tv[r]; sz[i][r] = sv[r]; }
+        } else {
+            const half4 bv = *reinterpret_cast<const half4*>(bias_lds + cl * 2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bz[i][r] = (float)bv[r];
+        }
+    }
+    if (LN) {          // (mean, rstd) of the tile's rows were staged in LDS before the k loop
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float2 st = *reinterpret_cast<const float2*>(bias_lds + 1024 + 8 * TC + (wp * 64 + 16 * j + l15) * 8);
+            mu[j] = st.x; rs[j] = st.y;
+        }
     }
     __syncthreads();                                           // every wave is done with the operand tiles
     auto stage = [&](auto has_temb) __attribute__((always_inline)) {
@@ -74,8 +91,14 @@ __device__ __forceinline__ void epilogue_lds(const IGemmParams& p, floatx4 (&acc
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int cl = wc * (16 * NI) + 16 * i + 4 * lg;              // tile-local channel
-                const float v0 = acc[i][j][0] + bz[i][0], v1 = acc[i][j][1] + bz[i][1];
-                const float v2 = acc[i][j][2] + bz[i][2], v3 = acc[i][j][3] + bz[i][3];
+                float v0, v1, v2, v3;
+                if (LN) {
+                    v0 = rs[j] * (acc[i][j][0] - mu[j] * sz[i][0]) + bz[i][0]; v1 = rs[j] * (acc[i][j][1] - mu[j] * sz[i][1]) + bz[i][1];
+                    v2 = rs[j] * (acc[i][j][2] - mu[j] * sz[i][2]) + bz[i][2]; v3 = rs[j] * (acc[i][j][3] - mu[j] * sz[i][3]) + bz[i][3];
+                } else {
+                    v0 = acc[i][j][0] + bz[i][0]; v1 = acc[i][j][1] + bz[i][1];
+                    v2 = acc[i][j][2] + bz[i][2]; v3 = acc[i][j][3] + bz[i][3];
+                }
                 if (EPI == EPI_GEGLU) {
                     const f16 h0 = (f16)v0, h1 = (f16)v1, g0 = (f16)v2, g1 = (f16)v3;
                     const f16 q0 = (f16)gelu_erf((float)g0), q1 = (f16)gelu_erf((float)g1);
@@ -139,7 +162,7 @@ __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int WC, int EPI, int NI, bool SPLIT = false>
+template <int WC, int EPI, int NI, bool SPLIT = false, bool LN = false>
 __global__ __launch_bounds__(128 * WC, 2)
 void igemm_kernel(IGemmParams p) {
     constexpr int WP = 2;
@@ -288,6 +311,15 @@ void igemm_kernel(IGemmParams p) {
         half4 bv = half4{0, 0, 0, 0};
         if (p.bias) bv = *reinterpret_cast<const half4*>(p.bias + c0out + tid * 4);
         *reinterpret_cast<half4*>(smem + 2 * STAGE + tid * 8) = bv;
+        if (LN) {      // ln_s, ln_t of the tile's channels (fp32) behind the 1 KB bias slot
+            *reinterpret_cast<floatx4*>(smem + 2 * STAGE + 1024 + tid * 16) = *reinterpret_cast<const floatx4*>(p.ln_s + c0out + tid * 4);
+            *reinterpret_cast<floatx4*>(smem + 2 * STAGE + 1024 + TC * 4 + tid * 16) = *reinterpret_cast<const floatx4*>(p.ln_t + c0out + tid * 4);
+        }
+    }
+    if (LN && tid < TP) {      // per-row (mean, rstd) of the tile's rows behind them
+        int m = p0 + tid;
+        m = m < p.M ? m : p.M - 1;
+        *reinterpret_cast<float2*>(smem + 2 * STAGE + 1024 + 8 * TC + tid * 8) = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (size_t)m);
     }
     prepare();
 #pragma unroll
@@ -342,28 +374,28 @@ void igemm_kernel(IGemmParams p) {
         }
         return;
     }
-    epilogue_lds<EPI, 128 * WC, TP, TC, NI>(p, acc, smem, smem + 2 * STAGE, p0, c0out, wc, wp, l15, lg, OHW);
+    epilogue_lds<EPI, 128 * WC, TP, TC, NI, LN>(p, acc, smem, smem + 2 * STAGE, p0, c0out, wc, wp, l15, lg, OHW);
 }
 
 }  // namespace
 
-template <int WC, int NI>
+template <int WC, int NI, bool LN = false>
 static hipError_t launch_t(const IGemmParams& p, hipStream_t s) {
     constexpr int TP = 128, TC = 16 * NI * WC;
-    constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 1024;      // operand stages + the tile's bias
+    constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 1024 + (LN ? 8 * TC + 8 * TP : 0);      // operand stages + bias (+ ln_s, ln_t, row stats)
     const int tiles_p = (p.M + TP - 1) / TP;
     const int tiles_c = p.Cout / TC;
     dim3 grid(tiles_p * tiles_c), block(128 * WC);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_PLAIN, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_GEGLU, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_PLAIN, NI, false, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_GEGLU, NI, false, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     if (p.epi == EPI_GEGLU)
-        hipLaunchKernelGGL((igemm_kernel<WC, EPI_GEGLU, NI>), grid, block, lds, s, p);
+        hipLaunchKernelGGL((igemm_kernel<WC, EPI_GEGLU, NI, false, LN>), grid, block, lds, s, p);
     else
-        hipLaunchKernelGGL((igemm_kernel<WC, EPI_PLAIN, NI>), grid, block, lds, s, p);
+        hipLaunchKernelGGL((igemm_kernel<WC, EPI_PLAIN, NI, false, LN>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 

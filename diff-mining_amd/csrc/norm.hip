@@ -178,6 +178,43 @@ __global__ void layernorm_kernel(const f16* __restrict__ X, int rows, int C, con
     }
 }
 
+// LayerNorm statistics only (the normalisation itself is folded into the following GEMM's epilogue):
+// same two-pass arithmetic as layernorm_kernel, one wavefront per row, writes (mean, rstd).
+template <int NV>
+__global__ void ln_stats_kernel(const f16* __restrict__ X, int rows, int C, float eps, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const f16* x = X + (size_t)row * C;
+    const int nvec = C >> 3;
+    half8 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = lane + 64 * i;
+        if (vi < nvec) {
+            v[i] = *reinterpret_cast<const half8*>(x + vi * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += (float)v[i][k];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = lane + 64 * i;
+        if (vi < nvec) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float d = (float)v[i][k] - mean; q += d * d; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rsqrtf(q / (float)C + eps); }
+}
+
 }  // namespace
 
 static int gn_pix(int HW) { int p = GN_PIX_MAX; while (p > 32 && HW / p < 16) p >>= 1; return p; }
@@ -223,6 +260,17 @@ hipError_t launch_layernorm(const f16* X, int rows, int C, const float* gamma, c
     if (nvec <= 64) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, X, rows, C, gamma, beta, eps, Y);
     else if (nvec <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, X, rows, C, gamma, beta, eps, Y);
     else hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, X, rows, C, gamma, beta, eps, Y);
+    return hipGetLastError();
+}
+
+hipError_t launch_ln_stats(const f16* X, int rows, int C, float eps, float* stats, hipStream_t s) {
+    if (C % 8 || C > 64 * 8 * 3) return hipErrorInvalidValue;
+    const int wpb = 4;
+    dim3 grid((rows + wpb - 1) / wpb), block(64 * wpb);
+    const int nvec = C / 8;
+    if (nvec <= 64) hipLaunchKernelGGL(ln_stats_kernel<1>, grid, block, 0, s, X, rows, C, eps, stats);
+    else if (nvec <= 128) hipLaunchKernelGGL(ln_stats_kernel<2>, grid, block, 0, s, X, rows, C, eps, stats);
+    else hipLaunchKernelGGL(ln_stats_kernel<3>, grid, block, 0, s, X, rows, C, eps, stats);
     return hipGetLastError();
 }
 

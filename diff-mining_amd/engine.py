@@ -24,6 +24,7 @@ SYMBOLS = [
     "dm_op_igemm", "dm_op_attention", "dm_op_groupnorm", "dm_op_layernorm",
     "dm_engine_load_vae_weight", "dm_engine_finalize_vae", "dm_vae_encode", "dm_op_attention512", "dm_patch_embed",
     "dm_engine_load_clip_weight", "dm_engine_finalize_clip", "dm_clip_encode", "dm_op_igemm_splitk",
+    "dm_op_ln_stats", "dm_op_igemm_ln",
 ]
 
 
@@ -76,6 +77,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_engine_finalize_vae.argtypes = [vp]
     lib.dm_vae_encode.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.c_float, vp, vp, vp, vp]
     lib.dm_patch_embed.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
+    lib.dm_op_ln_stats.argtypes = [vp, vp, i32, i32, C.c_float, vp]
+    lib.dm_op_igemm_ln.argtypes = [vp] * 7 + [i32] * 4
     lib.dm_op_igemm_splitk.argtypes = [vp] * 8 + [i32] * 11 + [vp]
     lib.dm_engine_load_clip_weight.argtypes = [vp, C.c_char_p, vp, i32, C.POINTER(i64), i32]
     lib.dm_engine_finalize_clip.argtypes = [vp]

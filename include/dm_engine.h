@@ -202,6 +202,13 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
 int dm_op_attention(void* stream, const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv,
                     int ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso, const int32_t* kv_slot,
                     int B, int heads, int Tq, int Tk, int D, float scale);
+/* LayerNorm folded into a Linear (the transformer blocks' LN -> to_q/k/v, LN -> to_q, LN -> GEGLU projection):
+ * dm_op_ln_stats writes (mean, rstd) per row of X [rows][C]; dm_op_igemm_ln computes
+ *   Y[m][c] = rstd_m * (sum_k X[m][k] Wp[c][k] - mean_m * ln_s[c]) + ln_t[c]     (then GEGLU when epi = 1)
+ * with Wp = fp16(W * gamma), ln_s[c] = sum_k Wp[c][k], ln_t[c] = sum_k W[c][k] beta[k] + bias[c]  (fp32).   */
+int dm_op_ln_stats(void* stream, const void* X, int rows, int C, float eps, void* stats_f32);
+int dm_op_igemm_ln(void* stream, const void* X, const void* Wp_folded, const void* ln_s, const void* ln_t,
+                   const void* stats, void* Y, int M, int Cin, int Cout, int epi);
 /* igemm with the k range cut into `ksplit` parts (>= 2, dividing the k steps) through an fp32 workspace of
  * ksplit * M * Cout floats, followed by the reduction + epilogue; the engine uses it for the 8x8 layers.   */
 int dm_op_igemm_splitk(void* stream, const void* X, const void* X2, const void* Wp, const void* bias, const void* temb,

@@ -240,3 +240,43 @@ def test_igemm_splitk_matches_unsplit(N, H, W, Cin, C2, Cout, mode, ks):
     diff = (y.float() - ref.float()).abs()
     # identical except where the fp32 summation order flips an fp16 rounding (1 ulp, rare)
     assert (diff > 0).float().mean().item() < 0.02 and diff.max().item() <= 2e-3 * ref.float().abs().max().item()
+
+
+@pytest.mark.parametrize("M,C,Cout,epi", [(300, 320, 960, 0), (4096, 640, 640, 0), (131072 + 5, 320, 2560, 1), (8192, 1280, 10240, 1),
+                                          (655360, 320, 320, 0)])
+def test_layernorm_folded_into_linear(M, C, Cout, epi):
+    """LN -> Linear (-> GEGLU) with the LayerNorm folded into the GEMM (weights scaled by gamma, per-row mean / rstd
+    correction in the epilogue) vs F.linear(F.layer_norm(x)) in fp32; covers the 128x320 / 128x160 and 256x320 tiles."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    x = (U.f16_randn(M, C, seed=1).float() * 1.5 + 0.7 * U.f16_randn(M, 1, seed=2).float()).half()   # rows with non-zero mean
+    w = U.f16_randn(Cout, C, seed=3, scale=C ** -0.5)
+    b = U.f16_randn(Cout, seed=4, scale=0.1)
+    gamma = (1 + 0.1 * U.f16_randn(C, seed=5).float()).half()
+    beta = (0.05 * U.f16_randn(C, seed=6).float()).half()
+    if epi == 1:
+        wq, bq = U.pack_geglu(w, b)
+    else:
+        wq, bq = w, b
+    wf = (wq.float() * gamma.float()[None]).half()
+    ln_s = wf.float().sum(1)
+    ln_t = (wq.float() @ beta.float()) + bq.float()
+    xg = x.to(d)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=d)
+    assert lib.dm_op_ln_stats(U.stream(), U.ptr(xg), M, C, 1e-5, U.ptr(stats)) == 0
+    y = torch.empty(M, Cout // 2 if epi else Cout, dtype=torch.float16, device=d)
+    wfd, sd_, td_ = wf.to(d), ln_s.to(d), ln_t.to(d)
+    assert lib.dm_op_igemm_ln(U.stream(), U.ptr(xg), U.ptr(wfd), U.ptr(sd_), U.ptr(td_), U.ptr(stats), U.ptr(y), M, C, Cout, epi) == 0
+    torch.cuda.synchronize()
+    rows = torch.arange(M) if M <= 8192 else torch.cat([torch.arange(0, 2048), torch.arange(M - 2048, M)])
+    xr = x[rows].float()
+    st = stats[rows.to(d)].cpu()
+    assert torch.allclose(st[:, 0], xr.mean(1), atol=1e-5) and torch.allclose(st[:, 1], (xr.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4)
+    h = F.linear(F.layer_norm(xr, (C,), gamma.float(), beta.float(), 1e-5), w.float(), b.float())
+    if epi == 1:
+        hh = h.half().float()
+        ref = hh[:, :Cout // 2] * F.gelu(hh[:, Cout // 2:]).half().float()
+    else:
+        ref = h
+    U.assert_close_fp16(y[rows.to(d)], ref, f"LN-folded linear epi={epi}", rel=3e-3, abs_frac=4e-3)
