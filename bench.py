@@ -3,7 +3,8 @@
 
 One "step" = one pass of the hot path over one batch of synthetic input PER GPU:
     8 images of 512x512 (latent 4x64x64), each scored with 10 (t, eps) draws x 2 prompts
-    = 160 SDv1.5 U-Net forwards of the fused add_noise -> U-Net -> eps-MSE path (dm_score), then the
+    = 160 SDv1.5 U-Net forwards of the fused add_noise -> U-Net -> eps-MSE path (dm_score_conds: the
+    reference's draw-tiled-over-prompts batch, prompt-independent head computed once per draw), then the
     on-device typicality reduction (dm_reduce_typicality) per image; N > 1: plus ONE all-gather of
     the per-image T(x|c) scalars (RCCL over xGMI).  This is BASELINE.json configs[1] (and [2] for N>1).
 Inputs (latents, draws, prompt embeddings) and the synthetic fp16 weights are resident in HBM
@@ -14,7 +15,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
                  achieved = its algorithmic FLOPs / its summed launch time, measured with HIP events
                  on the launch stream over the timed steps (dm_prof_*); peak = 2.5 PFLOP/s dense fp16.
   cpu_baseline — the oracle (fp32 PyTorch-CPU restatement; kind "port") timed on this host's cores on
-                 a bounded sample (2 U-Net forwards @64x64 = 1/10 of one image's work).
+                 a bounded sample (4 U-Net forwards @64x64 = 1/5 of one image's work).
 """
 import argparse
 import json
@@ -126,7 +127,7 @@ def main():
                                    f"batch {n_img} images/GPU = {n_img * per_img} U-Net forwards/step/GPU, synthetic weights",
                        "images_per_gpu_per_step": n_img, "unet_forwards_per_image": per_img,
                        "parallelism": f"image-sharded x{world}, one all-gather of T(x|c)"},
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel + igemm_big_kernel (implicit-GEMM conv3x3/1x1/linear, 128x320 and 256x320 tiles)",
+            "roofline": {"bound": "mfma", "kernel": "igemm family: igemm_kernel + igemm_big_kernel incl. their LayerNorm-folded and split-K instantiations (implicit-GEMM conv3x3/1x1/linear, 128x320 and 256x320 tiles)",
                          "achieved": round(ig_tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ig_tf / PEAK_TFLOPS, 4), "traffic": hbm_traffic_per_launch(),
                          "launches": prof["igemm_launches"], "kernel_ms_total": round(prof["igemm_ms"], 3),
