@@ -36,7 +36,7 @@ ATTN_SHAPES = [("self D40 T4096", 40, 4096, 4096), ("self D80 T1024", 80, 1024, 
                ("cross D40 T4096x77", 40, 4096, 77), ("cross D80 T1024x77", 80, 1024, 77)]
 
 
-def timeit(fn, iters=5):
+def timeit(fn, iters=int(os.environ.get("DM_BENCH_ITERS", "5"))):
     fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
