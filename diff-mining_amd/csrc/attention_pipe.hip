@@ -57,6 +57,11 @@ __device__ unsigned long long g_attnp_span[2] = {~0ull, 0ull};
 
 #define PIN(x) asm volatile("" : "+v"(x))
 
+// max through inline asm: __builtin_fmaxf (llvm.maxnum) first canonicalises operands that come out of MFMAs
+// or asm (v_max x, x), 2-3 extra VALU per row block and tile; scores are never NaN here
+__device__ __forceinline__ float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 template <int OFF>
 __device__ __forceinline__ void tr_read(u32x2& out, unsigned base) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(out) : "v"(base), "n"(OFF) : "memory");
@@ -165,7 +170,9 @@ void attn_pipe_kernel(AttnParams p) {
     auto rescale = [&](floatx4 (&X)[4][QF], const float (&mxl)[QF], bool first) __attribute__((always_inline)) {
 #pragma unroll
         for (int jq = 0; jq < QF; ++jq) {
-            float mx = __builtin_fmaxf(mxl[jq], __shfl_xor(mxl[jq], 16));
+            float mown = mxl[jq];
+            PIN(mown);          // keeps the cross-lane reduction inside the rare branch (it was being speculated into the loop)
+            float mx = __builtin_fmaxf(mown, __shfl_xor(mown, 16));
             mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32));
             const float delta = first ? mx : __builtin_fmaxf(mx, 0.f);
             const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
@@ -305,7 +312,7 @@ void attn_pipe_kernel(AttnParams p) {
                 for (int k = 0; k < 2; ++k) {
                     const int o = (m & 3) * 2 + k;           // 0..7: scores 2o, 2o+1 of row block j2
                     const float a0 = Y[o >> 1][j2][(o & 1) * 2], a1 = Y[o >> 1][j2][(o & 1) * 2 + 1];
-                    mx[j2] = (o == 0) ? __builtin_fmaxf(a0, a1) : __builtin_fmaxf(__builtin_fmaxf(mx[j2], a0), a1);
+                    mx[j2] = (o == 0) ? vmax2(a0, a1) : vmax3(mx[j2], a0, a1);
                 }
                 PIN(mx[j2]);
             }
@@ -313,7 +320,7 @@ void attn_pipe_kernel(AttnParams p) {
         }
         TICK(5);
         if (next) {
-            if (__builtin_amdgcn_ballot_w64(__builtin_fmaxf(mx[0], mx[1]) > RESCALE_THR) != 0ull) rescale(Y, mx, false);
+            if (__builtin_amdgcn_ballot_w64(vmax2(mx[0], mx[1]) > RESCALE_THR) != 0ull) rescale(Y, mx, false);
         }
         s0 = s1;
     };
