@@ -1623,7 +1623,7 @@ int dm_prof_read(dm_engine* e, double* igemm_ms, double* igemm_flops, int64_t* i
 
 int dm_engine_memory(dm_engine* e, size_t* weights_bytes, size_t* arena_bytes) {
     if (!e) return 1;
-    if (weights_bytes) *weights_bytes = e->wslab_bytes;
+    if (weights_bytes) *weights_bytes = e->wslab_bytes + e->vslab_bytes + e->cslab_bytes;     // U-Net + optional VAE / CLIP slabs
     if (arena_bytes) *arena_bytes = e->arena_cap;
     return 0;
 }

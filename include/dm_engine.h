@@ -180,7 +180,8 @@ int dm_clip_encode(dm_engine* e, const int32_t* input_ids_dev, int n_prompts, in
 int dm_patch_embed(dm_engine* e, const void* feat_f32_dev, int C, int h, int w, const int32_t* boxes_dev,
                    int n_patches, void* out_f32_dev, void* stream);
 
-/* Bytes of device memory currently held by the engine (weights + workspace arena). */
+/* Bytes of device memory currently held by the engine: packed weights (U-Net + optional VAE / CLIP slabs) and
+ * the workspace arena (the per-prompt K/V cache, a few MB, is not included). */
 int dm_engine_memory(dm_engine* e, size_t* weights_bytes, size_t* arena_bytes);
 
 /* ---- operator-level entry points ------------------------------------------------------------------
