@@ -36,10 +36,21 @@ __global__ void gn_stats_partial(const f16* __restrict__ X, const f16* __restric
     const int c = col * 8;
     const int C2 = C - C1;
     if (rg < R) {
-        for (int px = px0 + rg; px < px1; px += R) {
-            const size_t pix = (size_t)n * HW + px;
-            const f16* src = (c < C1) ? (X + pix * C1 + c) : (X2 + pix * C2 + (c - C1));
-            const half8 v = *reinterpret_cast<const half8*>(src);
+        // four pixels per trip: the loads are independent, the accumulation order is unchanged (px ascending)
+        const f16* base = (c < C1) ? (X + (size_t)n * HW * C1 + c) : (X2 + (size_t)n * HW * C2 + (c - C1));
+        const size_t cs = (c < C1) ? (size_t)C1 : (size_t)C2;
+        int px = px0 + rg;
+        for (; px + 3 * R < px1; px += 4 * R) {
+            half8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8*>(base + (size_t)(px + u * R) * cs);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float f = (float)v[u][k]; s[k] += f; q[k] += f * f; }
+        }
+        for (; px < px1; px += R) {
+            const half8 v = *reinterpret_cast<const half8*>(base + (size_t)px * cs);
 #pragma unroll
             for (int k = 0; k < 8; ++k) { const float f = (float)v[k]; s[k] += f; q[k] += f * f; }
         }
