@@ -4,14 +4,19 @@
 One "step" = one pass of the hot path over one batch of synthetic input PER GPU:
     8 images of 512x512 (latent 4x64x64), each scored with 10 (t, eps) draws x 2 prompts
     = 160 SDv1.5 U-Net forwards of the fused add_noise -> U-Net -> eps-MSE path (dm_score_conds: the
-    reference's draw-tiled-over-prompts batch, prompt-independent head computed once per draw), then the
-    on-device typicality reduction (dm_reduce_typicality) per image; N > 1: plus ONE all-gather of
-    the per-image T(x|c) scalars (RCCL over xGMI).  This is BASELINE.json configs[1] (and [2] for N>1).
-Inputs (latents, draws, prompt embeddings) and the synthetic fp16 weights are resident in HBM
-before the timed region.  Weak scaling: every rank scores its own 8 images.
+    reference's draw-tiled-over-prompts batch, prompt-independent head computed once per draw), then ONE
+    on-device typicality reduction over all images (dm_reduce_typicality_batched); N > 1: plus ONE all-gather
+    of the per-image T(x|c) scalars (RCCL over xGMI).  This is BASELINE.json configs[1] (and [2] for N>1).
+Inputs (fp32 latents and draws like the reference's, fp16 prompt embeddings) and the synthetic fp16 weights are
+resident in HBM before the timed region.  Weak scaling: every rank scores its own 8 images.
+
+`python bench.py --gpus N` launches its own N ranks (re-exec under torch.distributed.run on 127.0.0.1) when it is
+not already inside a launcher; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+it uses the ranks it was given and refuses a WORLD_SIZE that contradicts --gpus.  One process per GPU, image
+sharding `r::N` as the reference's `subs[i::sub_split]` (diffmining/typicality/compute.py:337-341).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     — dominant kernel = the implicit-GEMM MFMA kernel (igemm.hip, 85% of the FLOPs):
+  roofline     — dominant kernel = the implicit-GEMM MFMA kernel family (84 % of the FLOPs):
                  achieved = its algorithmic FLOPs / its summed launch time, measured with HIP events
                  on the launch stream over the timed steps (dm_prof_*); peak = 2.5 PFLOP/s dense fp16.
   cpu_baseline — the oracle (fp32 PyTorch-CPU restatement; kind "port") timed on this host's cores on
@@ -20,6 +25,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,9 +36,25 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-FLOP_PER_FORWARD_64 = 803.27e9          # SURVEY.md §8d (2 FLOP/MAC, attention included)
+FLOP_PER_FORWARD_64 = 803.27e9          # SURVEY.md §8d (2 FLOP/MAC, attention included), nominal
 N_IMG, N_DRAWS, N_COND, LAT = 8, 10, 2, 64
 PEAK_TFLOPS = 2500.0                    # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
+STUB = os.environ.get("DM_BENCH_STUB", "0") not in ("", "0")     # CPU test of the launcher / gather path (gloo, no engine)
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """`bench.py --gpus N` outside a launcher: start N ranks of this script, one per GPU."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -41,102 +64,162 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--images", type=int, default=N_IMG)
+    ap.add_argument("--latent-dtype", choices=["f32", "f16"], default="f32",
+                    help="dtype flow of add_noise / MSE: f32 = the reference's (compute.py:91-101), f16 = fp16 scheduler")
     ap.add_argument("--workload", choices=["typicality", "dift", "xray", "vae", "pixels"], default="typicality",
                     help="typicality = BASELINE configs[1]/[2] (the graded line); dift = configs[3]; xray = configs[4]; "
                          "vae = SURVEY 8f rank 2 (VAE encode of 8 images @512px); pixels = vae + typicality from images")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args))
+        world = 1
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a "
+                     "number for a different GPU count than asked")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    dev = torch.device("cuda", local_rank)
+        if not STUB:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group("gloo" if STUB else "nccl", rank=rank, world_size=world)
+    dev = torch.device("cpu") if STUB else torch.device("cuda", local_rank)
+    sync = (lambda: None) if STUB else torch.cuda.synchronize
 
     from diff_mining_amd import synth
-    from diff_mining_amd.engine import UNetEngine
     from diff_mining_amd.typicality import gather_scores
 
-    sd = synth.synth_state_dict(seed=0, dtype=np.float16)
-    eng = UNetEngine(local_rank)
-    eng.load_state_dict(sd)
-
-    if args.workload != "typicality":
-        return side_workload(args, eng, dev)
-
     n_img = args.images
-    x, eps, t, c = synth.synth_inputs(n_img * world, N_DRAWS, LAT, LAT)
-    x = torch.from_numpy(x)[rank * n_img:(rank + 1) * n_img].to(dev)          # this rank's images
-    eps = torch.from_numpy(eps).to(dev)
-    t = torch.from_numpy(t).to(dev)
-    c = torch.from_numpy(c).to(dev)
-    eng.set_prompts(c)
-    # sample order per image: cond-major tiling of compute.py:150-152 (row k*N+i = draw i, cond k)
     per_img = N_DRAWS * N_COND
-    # the 80 distinct (image, draw) pairs of the step; each is scored under the N_COND prompts
-    # (D.compute_losses tiles exactly this, compute.py:150-152: same draws for every image, seed 42)
-    eps_u = eps.repeat(n_img, 1, 1, 1).contiguous()
-    t_u = t.repeat(n_img).contiguous()
-    x_index = torch.arange(n_img, dtype=torch.int32, device=dev).repeat_interleave(N_DRAWS).contiguous()
-    scores = torch.empty(n_img, dtype=torch.float32, device=dev)
+    if STUB:
+        eng, sd = None, None
 
-    def step():
-        loss = eng.score_conds(x, eps_u, t_u, N_COND, x_index=x_index)       # [2*n_img*10,4,64,64] fp32, cond-major
-        grid = loss.view(N_COND, n_img, N_DRAWS, 4, LAT, LAT)
-        for i in range(n_img):
-            g = grid[:, i].transpose(0, 1).contiguous()                       # [N,2,4,h,w]
-            scores[i] = eng.reduce_typicality(g)[1][0]
-        return gather_scores(scores, n_img * world, rank, world)
+        def step():                       # stands in for the engine: rank-dependent fake T(x|c), same gather path
+            return gather_scores(torch.arange(n_img, dtype=torch.float32) + 100.0 * rank, n_img * world, rank, world)
+    else:
+        from diff_mining_amd.engine import UNetEngine
+        sd = synth.synth_state_dict(seed=0, dtype=np.float16)
+        eng = UNetEngine(local_rank)
+        eng.load_state_dict(sd)
+        if args.workload != "typicality":
+            return side_workload(args, eng, dev)
+        ldt = torch.float32 if args.latent_dtype == "f32" else torch.float16
+        x, eps, t, c = synth.synth_inputs(n_img * world, N_DRAWS, LAT, LAT,
+                                          latent_dtype=np.float32 if args.latent_dtype == "f32" else np.float16)
+        x = torch.from_numpy(x)[rank * n_img:(rank + 1) * n_img].to(dev)          # this rank's images
+        eps = torch.from_numpy(eps).to(dev)
+        t = torch.from_numpy(t).to(dev)
+        c = torch.from_numpy(c).to(dev)
+        eng.set_prompts(c)
+        # the 80 distinct (image, draw) pairs of the step, image-major; each is scored under the N_COND prompts
+        # (D.compute_losses tiles exactly this, compute.py:150-152: same draws for every image, seed 42)
+        eps_u = eps.repeat(n_img, 1, 1, 1).contiguous()
+        t_u = t.repeat(n_img).contiguous()
+        x_index = torch.arange(n_img, dtype=torch.int32, device=dev).repeat_interleave(N_DRAWS).contiguous()
+        last = {}
+
+        def step():
+            loss = eng.score_conds(x, eps_u, t_u, N_COND, x_index=x_index, latent_dtype=ldt)   # [2*n_img*10,4,64,64] fp32, cond-major
+            _, scores = eng.reduce_typicality_batched(loss, n_img, N_DRAWS, N_COND, cond_major=True)   # one launch, no torch glue
+            last["loss"] = loss
+            return gather_scores(scores, n_img * world, rank, world)
 
     for _ in range(args.warmup):
         step()
-    eng.prof_enable(True)
-    eng.prof_read()
+    if eng is not None:
+        eng.prof_enable(True)
+        eng.prof_read()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         all_scores = step()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
-    prof = eng.prof_read()
-    eng.prof_enable(False)
+    prof = eng.prof_read() if eng is not None else {"igemm_ms": 0.0, "igemm_flops": 0.0, "igemm_launches": 0,
+                                                    "attn_ms": 0.0, "attn_flops": 0.0, "attn_launches": 0}
+    if eng is not None:
+        eng.prof_enable(False)
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = tt.item()
+
+    # the collective on its own (outside the timed steps): the all-gather of the per-image scalars
+    ag_ms = None
+    if world > 1:
+        probe = torch.zeros(n_img, dtype=torch.float32, device=dev)
+        gather_scores(probe, n_img * world, rank, world)
+        dist.barrier()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            gather_scores(probe, n_img * world, rank, world)
+        sync()
+        ag_ms = (time.perf_counter() - t1) / 20 * 1e3
+
+    # secondary: the reference also hands the fp16 grids [N,2,4,h,w] to the host (compute.py:156,160); `value` keeps
+    # the scores on the device, so the D2H-inclusive rate is reported beside it (torch cast / permute / copy glue)
+    d2h = None
+    if eng is not None and world == 1:
+        host = torch.empty(n_img, N_DRAWS, N_COND, 4, LAT, LAT, dtype=torch.float16).pin_memory()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step()
+            host.copy_(last["loss"].view(N_COND, n_img, N_DRAWS, 4, LAT, LAT).permute(1, 2, 0, 3, 4, 5).to(torch.float16))
+        sync()
+        d2h = (time.perf_counter() - t1) / 2
 
     if rank == 0:
         total_images = n_img * world * args.steps
         value = total_images / dt
         ig_tf = prof["igemm_flops"] / (prof["igemm_ms"] * 1e-3) / 1e12 if prof["igemm_ms"] > 0 else 0.0
         at_tf = prof["attn_flops"] / (prof["attn_ms"] * 1e-3) / 1e12 if prof["attn_ms"] > 0 else 0.0
+        # executed work = what the engine's launches actually computed on this rank (shared-draw prefix and the cached
+        # cross-attention K/V are NOT re-done per prompt); nominal = 803.27 GFLOP x forwards, as SURVEY §8d counts
+        executed = (prof["igemm_flops"] + prof["attn_flops"]) / max(args.steps, 1)
+        nominal = n_img * per_img * FLOP_PER_FORWARD_64
+        step_s = dt / args.steps
         out = {
             "metric": "typicality-scored images/sec/node (512px, 10 t×2 prompts)",
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "configs[1]: SDv1.5 U-Net fp16, 512x512 (latent 64x64), 10 t-samples x 2 prompts, "
                                    f"batch {n_img} images/GPU = {n_img * per_img} U-Net forwards/step/GPU, synthetic weights",
                        "images_per_gpu_per_step": n_img, "unet_forwards_per_image": per_img,
+                       "latent_dtype_flow": args.latent_dtype,
                        "parallelism": f"image-sharded x{world}, one all-gather of T(x|c)"},
             "roofline": {"bound": "mfma", "kernel": "igemm family: igemm_kernel + igemm_big_kernel incl. their LayerNorm-folded and split-K instantiations (implicit-GEMM conv3x3/1x1/linear, 128x320 and 256x320 tiles)",
                          "achieved": round(ig_tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ig_tf / PEAK_TFLOPS, 4), "traffic": hbm_traffic_per_launch(),
                          "launches": prof["igemm_launches"], "kernel_ms_total": round(prof["igemm_ms"], 3),
-                         "whole_path_tflops": round(value / world * per_img * FLOP_PER_FORWARD_64 / 1e12, 2),
-                         "whole_path_frac": round(value / world * per_img * FLOP_PER_FORWARD_64 / 1e12 / PEAK_TFLOPS, 4),
+                         "whole_path_tflops": round(executed / step_s / 1e12, 2),
+                         "whole_path_frac": round(executed / step_s / 1e12 / PEAK_TFLOPS, 4),
+                         "executed_tflop_per_step": round(executed / 1e12, 3),
+                         "nominal_tflop_per_step": round(nominal / 1e12, 3),
+                         "whole_path_tflops_nominal": round(nominal / step_s / 1e12, 2),
                          "attention_tflops": round(at_tf, 2), "attention_ms_total": round(prof["attn_ms"], 3)},
+            "allgather_ms": None if ag_ms is None else round(ag_ms, 4),
+            "grid_d2h": ("excluded from `value` (scores are reduced on the device)" if d2h is None else
+                         {"in_value": False, "ms_per_step_with_fp16_grid_d2h": round(d2h * 1e3, 3),
+                          "images_per_s_with_fp16_grid_d2h": round(n_img / d2h, 4),
+                          "bytes_per_step": n_img * N_DRAWS * N_COND * 4 * LAT * LAT * 2}),
             "scores_checksum": float(all_scores.double().sum().item()),
         }
-        if not args.no_cpu_baseline and world == 1:
+        if STUB:
+            out["data"] = "stub (DM_BENCH_STUB=1: launcher / gather path only, no engine)"
+        if not args.no_cpu_baseline and world == 1 and not STUB:
             out["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -147,11 +230,13 @@ def hbm_traffic_per_launch():
     """HBM bytes per igemm launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per
     the gfx950 correction, + WRITE_SIZE); rocprofv3 cannot run inside this process, so the number is
     the recorded one for this kernel build, or None when no record exists."""
-    path = os.path.join(ROOT, "profiles", "r01_final_pmc.json")
-    try:
-        return round(json.load(open(path))["kernels"]["igemm_kernel+igemm_big_kernel"]["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+    for name in ("r02_final_pmc.json", "r01_final_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return round(json.load(f)["kernels"]["igemm_kernel+igemm_big_kernel"]["hbm_bytes_per_launch"])
+        except Exception:
+            continue
+    return None
 
 
 def side_workload(args, eng, dev):
@@ -241,6 +326,8 @@ def cpu_baseline(sd):
         dt = time.perf_counter() - t0
     forwards = 4
     return {"value": round(forwards / (N_DRAWS * N_COND) / dt, 6), "unit": "images/s", "cores": cores, "kind": "port",
+            "kind_detail": "port, 4-forward sample (the fp32 oracle restatement; not BASELINE.md §3's 16-image protocol, "
+                           "and not diffusers, which is absent from the image)",
             "sample": f"{forwards} U-Net forwards @64x64 (1/5 of one image's 20) in {dt:.1f}s, fp32 oracle, torch threads={cores}",
             "gflops": round(forwards * FLOP_PER_FORWARD_64 / dt / 1e9, 1)}
 

@@ -338,10 +338,9 @@ hipError_t launch_t(const AttnParams& p, hipStream_t s) {
     constexpr int QBLK = 64 * QF;
     dim3 grid((p.Tq + QBLK - 1) / QBLK, p.heads, p.B), block(NT);
     const size_t lds = 2 * (2 * (size_t)KT * D * 2 + 64);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_seen{0};      // hipFuncSetAttribute is per DEVICE, not per process
+    if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute((const void*)attn_kernel<D, QF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL((attn_kernel<D, QF>), grid, block, lds, s, p);
     return hipGetLastError();

@@ -4,10 +4,20 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace dm {
 
 typedef _Float16 f16;
+
+// Function attributes (dynamic LDS size) are per device: true the first time the caller's launcher runs on the current
+// device (`seen` = one bit per device ordinal), so a second engine on another GPU of the same process sets them too.
+inline bool first_use_on_device(std::atomic<uint64_t>& seen) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const uint64_t bit = 1ull << (d & 63);
+    return (seen.fetch_or(bit) & bit) == 0;
+}
 
 // ---- K1/K2/K3: implicit-GEMM on MFMA (conv3x3 s1/s2/upsampled, 1x1 conv, linear) -------------
 enum IGemmMode { IG_DENSE = 0, IG_CONV3 = 1, IG_CONV3_S2 = 2, IG_CONV3_UP = 3, IG_CONV3_S2P0 = 4 };
@@ -42,6 +52,7 @@ hipError_t launch_igemm(const IGemmParams& p, hipStream_t s);
 // number of k parts for a layer with `spatial` output positions per sample (1 = no split); batch independent;
 // the caller provides the workspace
 int igemm_splitk_parts(const IGemmParams& p, int spatial);
+int igemm_tile_choice(const IGemmParams& p);     // 0 = 128-row tile, 1 = 256 x 320 tile
 
 // ---- K4/K5: flash attention (self and cross), head_dim 40/80/160 ------------------------------
 struct AttnParams {
@@ -72,25 +83,29 @@ hipError_t launch_ln_stats(const f16* X, int rows, int C, float eps, float* stat
 // temb0[b][320] = fp16(sinusoid table[t[b]])
 hipError_t launch_time_gather(const f16* table, const int64_t* t, int B, int dim, f16* out, hipStream_t s);
 hipError_t launch_silu(const f16* in, f16* out, long long n, hipStream_t s);
-// add_noise (fp16 arithmetic, table cast to fp16 first) fused with the im2col of conv_in (3x3, 4 ch):
+// add_noise fused with the im2col of conv_in (3x3, 4 ch):
 // out [B*H*W][64] fp16, k = c*9 + ky*3 + kx for k < 36, zero after; conv_in itself is then one igemm.
-// if sqrt_acp16 == nullptr the sample is used as is (plain U-Net forward / DIFT).
-hipError_t launch_im2col_in(const f16* x, const int32_t* x_index, const f16* eps, const int64_t* t,
-                            const f16* sqrt_acp16, const f16* sqrt_1macp16, int B, int H, int W, f16* out,
+// latent_f32 = 1: x / eps / the two coefficient tables are fp32 and the sum is rounded to fp16 once (the
+// reference's autocast flow); 0: all fp16, table cast to fp16 first (fp16 scheduler).
+// if sqrt_acp == nullptr the (fp16 or fp32) sample is used as is (plain U-Net forward / DIFT).
+hipError_t launch_im2col_in(const void* x, const int32_t* x_index, const void* eps, const int64_t* t,
+                            const void* sqrt_acp, const void* sqrt_1macp, int latent_f32, int B, int H, int W, f16* out,
                             hipStream_t s);
 // conv_out 3x3 (C0 -> 4) on the normalised activations, fused eps-MSE (wavefront shuffle reduce).
 // loss [B,4,H,W] fp32 = (float(fp16(conv)) - float(eps))^2 ; if eps == nullptr writes pred fp16 NCHW.
 // sample b reads eps row (b % eps_rows) and writes output row (b / out_group) * out_stride + out_off + b % out_group
 // (identity when eps_rows = out_group = B, out_stride = out_off = 0).
 hipError_t launch_conv_out(const f16* Xn /* NHWC [B,H,W,C0] */, const f16* w /* [4][9*C0] k=(tap,c) */,
-                           const f16* bias, const f16* eps, int B, int H, int W, int C0,
+                           const f16* bias, const void* eps /* fp32 if eps_f32 else fp16 */, int eps_f32, int B, int H, int W, int C0,
                            float* loss, f16* pred, int eps_rows, int out_group, int out_stride, int out_off,
                            hipStream_t s);
 hipError_t launch_nhwc_to_nchw(const f16* X, int N, int HW, int C, f16* Y, hipStream_t s);
 // mean over groups of `ens` consecutive samples, NHWC fp16 -> NCHW fp32
 hipError_t launch_ensemble_mean(const f16* X, int groups, int ens, int HW, int C, float* Y, hipStream_t s);
-// typicality reductions of the loss grid
-hipError_t launch_typicality(const void* loss, int is_f16, int n_draws, int n_cond, int HW,
+// typicality reductions of the loss grids of n_images images: map [n_images][HW], scalar [n_images] (optional).
+// cond_major = 0: loss [n_images][n_draws][n_cond][4][HW] (the reference's grid); 1: [n_cond][n_images][n_draws][4][HW]
+// (dm_score_conds' row order)
+hipError_t launch_typicality(const void* loss, int is_f16, int n_images, int n_draws, int n_cond, int HW, int cond_major,
                              float* map, float* scalar, hipStream_t s);
 
 // image-space reduction of the latent typicality map: bilinear (align_corners=False) to (H, W), then

@@ -38,9 +38,9 @@ static bool use_big(const IGemmParams& p) {
     static int force = -2;
     if (force == -2) { const char* e = getenv("DM_IGEMM_BIG"); force = e ? atoi(e) : -1; }
     if (p.Cout % 320 != 0) return false;
+    if (force >= 0) return force != 0;                       // DM_IGEMM_BIG=0/1: A/B switch for every eligible shape
     const long long tiles = (long long)((p.M + 255) / 256) * (p.Cout / 320);
     if (tiles < 1024) return false;
-    if (force >= 0) return force != 0;
     if (p.mode == IG_DENSE) return p.Cin >= 640 || p.Cout >= 2560;
     return p.Cin >= 640;
 }
@@ -58,6 +58,12 @@ int igemm_splitk_parts(const IGemmParams& p, int spatial) {
     for (int k = 4; k >= 2; --k)
         if (nk % k == 0 && nk / k >= 10) return k;
     return 1;
+}
+
+// which tile geometry launch_igemm picks for a plain (no LN fold, no split-K) shape: 0 = 128-row, 1 = 256 x 320
+int igemm_tile_choice(const IGemmParams& p) {
+    if (p.Cout % 160 != 0 || p.mode == IG_CONV3_S2P0) return 0;
+    return use_big(p) ? 1 : 0;
 }
 
 hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {

@@ -438,11 +438,10 @@ static hipError_t launch_igemm_big_t(const IGemmParams& p, hipStream_t s) {
     constexpr int TP = 256, TC = 320;
     constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 1024 + (LN ? 8 * TC + 8 * TP : 0);     // + bias (+ ln_s, ln_t, row stats)
     dim3 grid(((p.M + TP - 1) / TP) * (p.Cout / TC)), block(512);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_seen{0};      // hipFuncSetAttribute is per DEVICE, not per process
+    if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute((const void*)igemm_big_kernel<4, 2, 2, EPI_PLAIN, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)igemm_big_kernel<4, 2, 2, EPI_GEGLU, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     if (p.epi == EPI_GEGLU) hipLaunchKernelGGL((igemm_big_kernel<4, 2, 2, EPI_GEGLU, LN>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((igemm_big_kernel<4, 2, 2, EPI_PLAIN, LN>), grid, block, lds, s, p);

@@ -54,10 +54,9 @@ hipError_t launch_igemm_splitk(const IGemmParams& p, hipStream_t s) {
     if (p.ksplit < 2 || !p.partial || p.epi != EPI_PLAIN || p.Cout % TC != 0 || nk % p.ksplit != 0) return hipErrorInvalidValue;
     constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 1024;
     const int tiles = ((p.M + TP - 1) / TP) * (p.Cout / TC);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_seen{0};      // hipFuncSetAttribute is per DEVICE, not per process
+    if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_PLAIN, NI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL((igemm_kernel<WC, EPI_PLAIN, NI, true>), dim3(tiles * p.ksplit), dim3(128 * WC), lds, s, p);
     const long long MN = (long long)p.M * p.Cout;

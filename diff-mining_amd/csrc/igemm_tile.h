@@ -386,11 +386,10 @@ static hipError_t launch_t(const IGemmParams& p, hipStream_t s) {
     const int tiles_p = (p.M + TP - 1) / TP;
     const int tiles_c = p.Cout / TC;
     dim3 grid(tiles_p * tiles_c), block(128 * WC);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_seen{0};      // hipFuncSetAttribute is per DEVICE, not per process
+    if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_PLAIN, NI, false, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_GEGLU, NI, false, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     if (p.epi == EPI_GEGLU)
         hipLaunchKernelGGL((igemm_kernel<WC, EPI_GEGLU, NI, false, LN>), grid, block, lds, s, p);

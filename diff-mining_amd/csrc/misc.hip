@@ -32,11 +32,17 @@ __global__ void silu_kernel(const f16* __restrict__ in, f16* __restrict__ out, l
 }
 
 // One thread = one pixel: forms the 36 (zero padded) noisy inputs of its 3x3x4 patch and writes one
-// 128-byte im2col row.  The noisy latent is formed in fp16 arithmetic exactly as the fp16 scheduler
-// does:  noisy = fp16(fp16(sa * x) + fp16(sb * eps)),  sa = fp16(sqrt(fp16 acp[t])), sb likewise.
-__global__ void im2col_in_kernel(const f16* __restrict__ x, const int32_t* __restrict__ x_index,
-                                 const f16* __restrict__ eps, const int64_t* __restrict__ t,
-                                 const f16* __restrict__ sa_tab, const f16* __restrict__ sb_tab, int B, int H, int W,
+// 128-byte im2col row.  Two dtype flows of `scheduler.add_noise` (compute.py:99):
+//   T = float (DM_F32, what the reference's autocast run actually does: encode_vae returns fp32 because
+//       exp() is promoted, so randn_like / add_noise are fp32 and the table stays fp32):
+//       noisy = fp16( fp32(sa*x) + fp32(sb*eps) ),  sa = sqrtf(acp[t]), sb = sqrtf(1 - acp[t]);  the single
+//       rounding to fp16 is autocast's cast of conv_in's input;
+//   T = f16 (DM_F16, an fp16 latent handed to an fp16 scheduler: table cast to fp16 FIRST):
+//       noisy = fp16(fp16(sa * x) + fp16(sb * eps)),  sa = fp16(sqrt(fp16 acp[t])), sb likewise.
+template <typename T>
+__global__ void im2col_in_kernel(const T* __restrict__ x, const int32_t* __restrict__ x_index,
+                                 const T* __restrict__ eps, const int64_t* __restrict__ t,
+                                 const T* __restrict__ sa_tab, const T* __restrict__ sb_tab, int B, int H, int W,
                                  f16* __restrict__ out) {
     const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int HW = H * W;
@@ -45,7 +51,7 @@ __global__ void im2col_in_kernel(const f16* __restrict__ x, const int32_t* __res
     const int rem = (int)(pix - (long long)b * HW);
     const int oh = rem / W, ow = rem - oh * W;
     const bool noise = (sa_tab != nullptr);
-    f16 sa = (f16)1.0f, sb = (f16)0.0f;
+    T sa = (T)1.0f, sb = (T)0.0f;
     if (noise) {
         long long tt = t[b];
         tt = tt < 0 ? 0 : (tt > 999 ? 999 : tt);
@@ -62,17 +68,17 @@ __global__ void im2col_in_kernel(const f16* __restrict__ x, const int32_t* __res
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const int ih = oh + dy - 1, iw = ow + dx - 1;
-                f16 v = (f16)0.f;
+                T v = (T)0.f;
                 if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
                     v = x[((size_t)xb * 4 + c) * HW + ih * W + iw];
                     if (noise) {
-                        const f16 e = eps[((size_t)b * 4 + c) * HW + ih * W + iw];
-                        const f16 p1 = sa * v;          // fp16 multiply, rounded (-ffp-contract=off)
-                        const f16 p2 = sb * e;
-                        v = p1 + p2;                    // fp16 add, rounded
+                        const T e = eps[((size_t)b * 4 + c) * HW + ih * W + iw];
+                        const T p1 = sa * v;            // multiply, rounded in T (-ffp-contract=off: no FMA)
+                        const T p2 = sb * e;
+                        v = p1 + p2;                    // add, rounded in T
                     }
                 }
-                row[c * 9 + dy * 3 + dx] = v;
+                row[c * 9 + dy * 3 + dx] = (f16)v;
             }
     half8* dst = reinterpret_cast<half8*>(out + pix * 64);
 #pragma unroll
@@ -87,9 +93,10 @@ __global__ void im2col_in_kernel(const f16* __restrict__ x, const int32_t* __res
 // conv_out + eps-MSE.  8 lanes cooperate on one pixel: lane j of the group walks the 16-byte
 // channel chunks j, j+8, ... of the 9 taps; the four 2880-long dot products are then reduced with
 // xor-shuffles inside the wavefront.  Weights [4][9*C0] are staged in LDS once per block.
+template <typename TE>
 __global__ __launch_bounds__(256)
 void conv_out_kernel(const f16* __restrict__ Xn, const f16* __restrict__ w, const f16* __restrict__ bias,
-                     const f16* __restrict__ eps, int B, int H, int W, int C0, float* __restrict__ loss,
+                     const TE* __restrict__ eps, int B, int H, int W, int C0, float* __restrict__ loss,
                      f16* __restrict__ pred, int eps_rows, int out_group, int out_stride, int out_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f16* ws = reinterpret_cast<f16*>(smem);
@@ -180,14 +187,20 @@ __global__ void ensemble_mean_kernel(const f16* __restrict__ X, int ens, int HW,
 }
 
 // map[p] = mean_n( mean_c L[n, last, c, p] - mean_c L[n, 0, c, p] ); deterministic (fixed order).
+// blockIdx.y = image; sample (image i, draw n, prompt k) is row i*s_img + n*s_draw + k*s_cond of L [rows][4][HW]
+// (the reference's [N, n_cond] grid: s_draw = n_cond, s_cond = 1; dm_score_conds' cond-major rows: s_cond = n_img*N,
+// s_img = N, s_draw = 1).
 template <typename T>
-__global__ void typicality_map_kernel(const T* __restrict__ L, int n_draws, int n_cond, int HW, float* __restrict__ map) {
+__global__ void typicality_map_kernel(const T* __restrict__ L, int n_draws, int n_cond, int HW, float* __restrict__ map,
+                                      long long s_img, long long s_draw, long long s_cond) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= HW) return;
+    L += (size_t)blockIdx.y * s_img * 4 * HW;
+    map += (size_t)blockIdx.y * HW;
     float acc = 0.f;
     for (int n = 0; n < n_draws; ++n) {
-        const T* l0 = L + ((size_t)n * n_cond + 0) * 4 * HW;
-        const T* l1 = L + ((size_t)n * n_cond + (n_cond - 1)) * 4 * HW;
+        const T* l0 = L + ((size_t)n * s_draw) * 4 * HW;
+        const T* l1 = L + ((size_t)n * s_draw + (size_t)(n_cond - 1) * s_cond) * 4 * HW;
         float m0 = 0.f, m1 = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) { m0 += (float)l0[(size_t)c * HW + p]; m1 += (float)l1[(size_t)c * HW + p]; }
@@ -238,6 +251,8 @@ __global__ void colsum_kernel(const float* __restrict__ tmp, int H, int OWd, int
 
 __global__ void mean_reduce_kernel(const float* __restrict__ map, int n, float* __restrict__ out) {
     __shared__ double sh[256];
+    map += (size_t)blockIdx.x * n;
+    out += blockIdx.x;
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)map[i];
     sh[threadIdx.x] = s;
@@ -297,21 +312,31 @@ hipError_t launch_silu(const f16* in, f16* out, long long n, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_im2col_in(const f16* x, const int32_t* x_index, const f16* eps, const int64_t* t, const f16* sa,
-                            const f16* sb, int B, int H, int W, f16* out, hipStream_t s) {
+hipError_t launch_im2col_in(const void* x, const int32_t* x_index, const void* eps, const int64_t* t, const void* sa,
+                            const void* sb, int latent_f32, int B, int H, int W, f16* out, hipStream_t s) {
     const long long total = (long long)B * H * W;
-    hipLaunchKernelGGL(im2col_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x_index, eps, t, sa, sb,
-                       B, H, W, out);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (latent_f32)
+        hipLaunchKernelGGL(im2col_in_kernel<float>, grid, block, 0, s, (const float*)x, x_index, (const float*)eps, t,
+                           (const float*)sa, (const float*)sb, B, H, W, out);
+    else
+        hipLaunchKernelGGL(im2col_in_kernel<f16>, grid, block, 0, s, (const f16*)x, x_index, (const f16*)eps, t,
+                           (const f16*)sa, (const f16*)sb, B, H, W, out);
     return hipGetLastError();
 }
 
-hipError_t launch_conv_out(const f16* Xn, const f16* w, const f16* bias, const f16* eps, int B, int H, int W,
+hipError_t launch_conv_out(const f16* Xn, const f16* w, const f16* bias, const void* eps, int eps_f32, int B, int H, int W,
                            int C0, float* loss, f16* pred, int eps_rows, int out_group, int out_stride, int out_off,
                            hipStream_t s) {
     const long long npix = (long long)B * H * W;
     const size_t lds = (size_t)4 * 9 * C0 * sizeof(f16);
-    hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)((npix + 31) / 32)), dim3(256), lds, s, Xn, w, bias, eps,
-                       B, H, W, C0, loss, pred, eps_rows, out_group, out_stride, out_off);
+    const dim3 grid((unsigned)((npix + 31) / 32)), block(256);
+    if (eps_f32)
+        hipLaunchKernelGGL(conv_out_kernel<float>, grid, block, lds, s, Xn, w, bias, (const float*)eps,
+                           B, H, W, C0, loss, pred, eps_rows, out_group, out_stride, out_off);
+    else
+        hipLaunchKernelGGL(conv_out_kernel<f16>, grid, block, lds, s, Xn, w, bias, (const f16*)eps,
+                           B, H, W, C0, loss, pred, eps_rows, out_group, out_stride, out_off);
     return hipGetLastError();
 }
 
@@ -326,15 +351,19 @@ hipError_t launch_ensemble_mean(const f16* X, int groups, int ens, int HW, int C
     return hipGetLastError();
 }
 
-hipError_t launch_typicality(const void* loss, int is_f16, int n_draws, int n_cond, int HW, float* map,
-                             float* scalar, hipStream_t s) {
+hipError_t launch_typicality(const void* loss, int is_f16, int n_images, int n_draws, int n_cond, int HW, int cond_major,
+                             float* map, float* scalar, hipStream_t s) {
+    const long long s_img = cond_major ? n_draws : (long long)n_draws * n_cond;
+    const long long s_draw = cond_major ? 1 : n_cond;
+    const long long s_cond = cond_major ? (long long)n_images * n_draws : 1;
+    const dim3 grid((HW + 255) / 256, n_images);
     if (is_f16)
-        hipLaunchKernelGGL(typicality_map_kernel<f16>, dim3((HW + 255) / 256), dim3(256), 0, s, (const f16*)loss,
-                           n_draws, n_cond, HW, map);
+        hipLaunchKernelGGL(typicality_map_kernel<f16>, grid, dim3(256), 0, s, (const f16*)loss,
+                           n_draws, n_cond, HW, map, s_img, s_draw, s_cond);
     else
-        hipLaunchKernelGGL(typicality_map_kernel<float>, dim3((HW + 255) / 256), dim3(256), 0, s,
-                           (const float*)loss, n_draws, n_cond, HW, map);
-    if (scalar) hipLaunchKernelGGL(mean_reduce_kernel, dim3(1), dim3(256), 0, s, map, HW, scalar);
+        hipLaunchKernelGGL(typicality_map_kernel<float>, grid, dim3(256), 0, s,
+                           (const float*)loss, n_draws, n_cond, HW, map, s_img, s_draw, s_cond);
+    if (scalar) hipLaunchKernelGGL(mean_reduce_kernel, dim3(n_images), dim3(256), 0, s, map, HW, scalar);
     return hipGetLastError();
 }
 

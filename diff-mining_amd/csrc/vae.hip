@@ -251,10 +251,9 @@ hipError_t launch_im2col_rgb(const f16* x, int B, int H, int W, f16* out, hipStr
 hipError_t launch_attention512(const f16* Q, const f16* K, const f16* V, f16* O, int B, int T, int ld, int ldo,
                                float scale, hipStream_t s) {
     if (T <= 0 || B <= 0 || ld % 8 || ldo % 4) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_seen{0};      // hipFuncSetAttribute is per DEVICE, not per process
+    if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute((const void*)attn512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN512_LDS);
-        attr_set = true;
     }
     hipLaunchKernelGGL(attn512_kernel, dim3((T + AQ - 1) / AQ, B), dim3(256), ATTN512_LDS, s, Q, K, V, O, T, ld, ldo, scale);
     return hipGetLastError();

@@ -24,7 +24,7 @@ SYMBOLS = [
     "dm_op_igemm", "dm_op_attention", "dm_op_groupnorm", "dm_op_layernorm",
     "dm_engine_load_vae_weight", "dm_engine_finalize_vae", "dm_vae_encode", "dm_op_attention512", "dm_patch_embed",
     "dm_engine_load_clip_weight", "dm_engine_finalize_clip", "dm_clip_encode", "dm_op_igemm_splitk",
-    "dm_op_ln_stats", "dm_op_igemm_ln",
+    "dm_op_ln_stats", "dm_op_igemm_ln", "dm_reduce_typicality_batched", "dm_op_igemm_tile",
 ]
 
 
@@ -58,8 +58,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_engine_load_weight.argtypes = [vp, C.c_char_p, vp, i32, C.POINTER(i64), i32]
     lib.dm_engine_finalize.argtypes = [vp]
     lib.dm_engine_set_prompts.argtypes = [vp, vp, i32, vp]
-    lib.dm_score.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
-    lib.dm_score_conds.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.dm_score.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.dm_score_conds.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.dm_reduce_typicality_batched.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.dm_unet_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.dm_dift.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.dm_dift_shape.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
@@ -83,6 +84,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_engine_load_clip_weight.argtypes = [vp, C.c_char_p, vp, i32, C.POINTER(i64), i32]
     lib.dm_engine_finalize_clip.argtypes = [vp]
     lib.dm_clip_encode.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    lib.dm_op_igemm_tile.argtypes = [i32, i32, i32, i32]
     lib.dm_op_attention512.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float]
     if path is None:
         _lib = lib
@@ -130,6 +132,7 @@ class UNetEngine:
             raise EngineError("dm_engine_create: " + self.lib.dm_last_error(None).decode())
         self._h = h
         self.n_prompts = 0
+        self.prompt_generation = 0          # bumped by every set_prompts: callers that cache slots compare it
         self._finalized = False
 
     # -- plumbing --------------------------------------------------------------------------------
@@ -251,19 +254,38 @@ class UNetEngine:
                     "set_prompts")
         self._ctx_keepalive = ctx
         self.n_prompts = ctx.shape[0]
+        self.prompt_generation += 1
 
     def _slots(self, slots, batch):
+        """Prompt slots of a batch -> int32 on the device, range-checked against the registered prompts (a slot
+        beyond them would read another prompt set's stale K/V rows)."""
         torch = self._torch
-        s = torch.as_tensor(slots, device=self.device).to(torch.int32).contiguous()
+        s = torch.as_tensor(slots)
         assert s.shape == (batch,), (s.shape, batch)
-        return s
+        if s.numel():
+            lo, hi = int(s.min()), int(s.max())
+            if lo < 0 or hi >= self.n_prompts:
+                raise EngineError(f"prompt slot {lo if lo < 0 else hi} outside the {self.n_prompts} prompts registered "
+                                  "by set_prompts")
+        return s.to(self.device, torch.int32).contiguous()
+
+    def _latents(self, x, eps, latent_dtype):
+        """x / eps in the element type the engine's add_noise and MSE run in: fp32 (the reference's flow, also
+        the default for anything that is not fp16 already) or fp16 (both must then be fp16-valued)."""
+        torch = self._torch
+        if latent_dtype is None:
+            latent_dtype = torch.float16 if (x.dtype == torch.float16 and eps.dtype == torch.float16) else torch.float32
+        assert latent_dtype in (torch.float16, torch.float32), latent_dtype
+        return (x.to(self.device, latent_dtype).contiguous(), eps.to(self.device, latent_dtype).contiguous(),
+                1 if latent_dtype == torch.float32 else 0)
 
     # -- hot path --------------------------------------------------------------------------------
-    def score(self, x, eps, t, slots, x_index=None):
-        """SD.compute_loss (compute.py:95-102) fused: returns loss [B,4,h,w] fp32 on the GPU."""
+    def score(self, x, eps, t, slots, x_index=None, latent_dtype=None):
+        """SD.compute_loss (compute.py:95-102) fused: returns loss [B,4,h,w] fp32 on the GPU.
+        latent_dtype: torch.float32 (add_noise and the eps of the MSE in fp32, as the reference's autocast run) or
+        torch.float16 (fp16 scheduler arithmetic); default: fp16 only if both x and eps already are fp16."""
         torch = self._torch
-        x = x.to(self.device, torch.float16).contiguous()
-        eps = eps.to(self.device, torch.float16).contiguous()
+        x, eps, ld = self._latents(x, eps, latent_dtype)
         B, _, h, w = eps.shape
         t = t.to(self.device, torch.int64).contiguous()
         assert t.shape == (B,)
@@ -279,16 +301,15 @@ class UNetEngine:
         self._check(self.lib.dm_score(self._h, C.c_void_p(x.data_ptr()),
                                       C.c_void_p(xi.data_ptr()) if xi is not None else None,
                                       C.c_void_p(eps.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(s.data_ptr()),
-                                      B, x.shape[0], h, w, C.c_void_p(out.data_ptr()), self._stream()), "dm_score")
+                                      B, x.shape[0], h, w, ld, C.c_void_p(out.data_ptr()), self._stream()), "dm_score")
         return out
 
-    def score_conds(self, x, eps, t, n_cond: int, x_index=None):
+    def score_conds(self, x, eps, t, n_cond: int, x_index=None, latent_dtype=None):
         """D.compute_losses' inner call pattern: each of the U draws (x, eps, t) under prompts 0..n_cond-1.
         Returns loss [n_cond*U,4,h,w] fp32, cond-major (row k*U+i).  Bit-identical to `score` on the tiled
-        batch; the prompt-independent head of the U-Net runs once per draw."""
+        batch; the prompt-independent head of the U-Net runs once per draw.  latent_dtype as in `score`."""
         torch = self._torch
-        x = x.to(self.device, torch.float16).contiguous()
-        eps = eps.to(self.device, torch.float16).contiguous()
+        x, eps, ld = self._latents(x, eps, latent_dtype)
         U, _, h, w = eps.shape
         t = t.to(self.device, torch.int64).contiguous()
         assert t.shape == (U,) and 2 <= n_cond <= self.n_prompts
@@ -303,7 +324,7 @@ class UNetEngine:
         self._check(self.lib.dm_score_conds(self._h, C.c_void_p(x.data_ptr()),
                                             C.c_void_p(xi.data_ptr()) if xi is not None else None,
                                             C.c_void_p(eps.data_ptr()), C.c_void_p(t.data_ptr()), n_cond, U,
-                                            x.shape[0], h, w, C.c_void_p(out.data_ptr()), self._stream()),
+                                            x.shape[0], h, w, ld, C.c_void_p(out.data_ptr()), self._stream()),
                     "dm_score_conds")
         return out
 
@@ -359,6 +380,24 @@ class UNetEngine:
                                                   C.c_void_p(m.data_ptr()), C.c_void_p(sc.data_ptr()), self._stream()),
                     "dm_reduce_typicality")
         return m, sc
+
+    def reduce_typicality_batched(self, loss, n_images: int, n_draws: int, n_cond: int, cond_major: bool = False):
+        """All images of a batch in one launch.  loss: [n_images, n_draws, n_cond, 4, h, w] (reference grids), or —
+        cond_major — the [n_cond * n_images * n_draws, 4, h, w] rows `score_conds` returns for image-major draws.
+        Returns (maps [n_images,h,w] fp32, scalars [n_images] fp32) on the GPU."""
+        torch = self._torch
+        loss = loss.to(self.device).contiguous()
+        assert loss.dtype in (torch.float16, torch.float32)
+        h, w = loss.shape[-2:]
+        assert loss.shape[-3] == 4 and loss.numel() == n_images * n_draws * n_cond * 4 * h * w, loss.shape
+        maps = torch.empty(n_images, h, w, dtype=torch.float32, device=self.device)
+        sc = torch.empty(n_images, dtype=torch.float32, device=self.device)
+        self._check(self.lib.dm_reduce_typicality_batched(self._h, C.c_void_p(loss.data_ptr()),
+                                                          1 if loss.dtype == torch.float16 else 0, n_images, n_draws,
+                                                          n_cond, h, w, 1 if cond_major else 0,
+                                                          C.c_void_p(maps.data_ptr()), C.c_void_p(sc.data_ptr()),
+                                                          self._stream()), "dm_reduce_typicality_batched")
+        return maps, sc
 
     def typicality_image(self, grid, image_size, kx: int = 1, ky: int = 1):
         """`Cluster.load_typicality` (cluster.py:125-137) on the GPU: grid [N,n_cond,4,h,w] ->

@@ -170,9 +170,11 @@ def synth_image(n: int, H: int, W: int, seed: int = 5) -> np.ndarray:
 
 
 def synth_inputs(n_img: int, n_draws: int, h: int, w: int, n_prompts: int = 2,
-                 t_min: int = 100, t_max: int = 700, ctx_len: int = 77, ctx_dim: int = 768):
+                 t_min: int = 100, t_max: int = 700, ctx_len: int = 77, ctx_dim: int = 768, latent_dtype=np.float16):
     """Synthetic scoring inputs of SURVEY.md §8d: latents x~N(0,1), eps~N(0,1), t~U{t_min..t_max-1},
-    prompt embeddings c~N(0,1).  All fp16-representable, generated by the same integer hash."""
+    prompt embeddings c~N(0,1), generated by the same integer hash.  `latent_dtype` np.float16: x / eps are
+    fp16 arrays; np.float32: the unrounded fp32 values of the same draws (the reference's latents and
+    `randn_like` draws are fp32, compute.py:91-93,116).  c is always fp16."""
     x = hash_normal("input.x", n_img * 4 * h * w, 1234).reshape(n_img, 4, h, w)
     eps = hash_normal("input.eps", n_draws * 4 * h * w, 42).reshape(n_draws, 4, h, w)
     with np.errstate(over="ignore"):
@@ -181,4 +183,6 @@ def synth_inputs(n_img: int, n_draws: int, h: int, w: int, n_prompts: int = 2,
     t = (t_min + (bits >> np.uint64(33)) % np.uint64(t_max - t_min)).astype(np.int64)
     c = hash_normal("input.c", n_prompts * ctx_len * ctx_dim, 7).reshape(n_prompts, ctx_len, ctx_dim)
     f16 = lambda a: a.astype(np.float32).astype(np.float16)
+    if latent_dtype == np.float32:
+        return x.astype(np.float32), eps.astype(np.float32), t, f16(c)
     return f16(x), f16(eps), t, f16(c)

@@ -9,6 +9,8 @@
     D.noising                compute.py:115-124       TypicalityScorer.noising / draw
     D.compute_losses         compute.py:134-160       TypicalityScorer.compute_losses
     D.get_path / np.save     compute.py:162-163,192   TypicalityScorer.save_grid (same .npy layout)
+    D.rescale                compute.py:165-180       TypicalityScorer.rescale
+    D.compute / __call__ / exists  compute.py:182-202 TypicalityScorer.compute / __call__ / exists
     Typicallity.compute      xray/compute.py:210-218  TypicalityScorer.heatmap / typicality_scalar
     unet(sample, t, c).sample compute.py:100          UNetCallable (assignable over `pipe.unet`)
 
@@ -21,6 +23,11 @@ Same names, argument meaning and output layout ([N, n_cond, 4, h, w] float16, co
     ignored for the result (it never changes the math, only the chunking);
   * (eps, t) are drawn on the CPU generator by default so the values are reproducible across
     devices; the reference's device-Philox draws are launch-geometry dependent.
+  * dtype flow (`latent_dtype`, default torch.float32 = the reference's): under `@torch.autocast` the VAE
+    posterior's `exp` is promoted, so `encode_vae` returns an fp32 latent (compute.py:91-93), `randn_like(x)`
+    is fp32 (:116), `scheduler.add_noise` runs in fp32 on the fp32 table (:99) and `mse_loss` sees the fp32
+    eps (:101); only the U-Net input is rounded to fp16.  `latent_dtype=torch.float16` selects an all-fp16
+    add_noise (table cast to fp16 first) for callers that hold fp16 latents.
 """
 from __future__ import annotations
 
@@ -79,13 +86,18 @@ class UNetCallable:
     def __init__(self, engine: UNetEngine):
         self.engine = engine
         self._ctx_key = None
+        self._ctx_generation = -1
 
     def _slots_for(self, c: torch.Tensor):
         flat = c.reshape(c.shape[0], -1)
         uniq, inv = torch.unique(flat, dim=0, return_inverse=True)
-        if self._ctx_key is None or self._ctx_key.shape != uniq.shape or not torch.equal(self._ctx_key, uniq):
+        # the engine's K/V cache is shared: anyone else's set_prompts (SDFeaturizer, compute_losses, a direct
+        # call) bumps `prompt_generation`, which invalidates this cache key
+        if (self._ctx_key is None or self._ctx_generation != self.engine.prompt_generation
+                or self._ctx_key.shape != uniq.shape or not torch.equal(self._ctx_key, uniq)):
             self.engine.set_prompts(uniq.reshape(uniq.shape[0], c.shape[1], c.shape[2]))
             self._ctx_key = uniq
+            self._ctx_generation = self.engine.prompt_generation
         return inv.to(torch.int32)
 
     def __call__(self, sample, timestep, encoder_hidden_states, **_):
@@ -102,12 +114,18 @@ class TypicalityScorer:
     """`SD` + `D` of diffmining/typicality/compute.py:56-160 on the MI355X engine."""
 
     def __init__(self, engine: UNetEngine, seed: int = 42, N: int = 100, t_min: float = 0.0, t_max: float = 1.0,
-                 num_train_timesteps: int = 1000, generator_device: str = "cpu"):
+                 num_train_timesteps: int = 1000, generator_device: str = "cpu", latent_dtype=torch.float32,
+                 typicality_path: Optional[str] = None, which: Optional[str] = None, country_embeds=None):
+        """`D(sd, typicality_path, which, seed, N, t_min, t_max)` (compute.py:105-113).  `country_embeds`: the
+        `SD.country_embeds` dict {category or "": [77,768]} (compute.py:76-80) that `compute(country, path)` reads."""
         self.engine = engine
         self.device = engine.device
         self.seed, self.N, self.t_min, self.t_max = seed, N, t_min, t_max
         self.num_train_timesteps = num_train_timesteps
         self.generator_device = generator_device
+        assert latent_dtype in (torch.float32, torch.float16)
+        self.latent_dtype = latent_dtype
+        self.typicality_path, self.which, self.country_embeds = typicality_path, which, country_embeds
         self.unet = UNetCallable(engine)
 
     # -- D.load_image / SD.encode_vae (compute.py:126-132, 91-93) --------------------------------
@@ -120,13 +138,14 @@ class TypicalityScorer:
 
     @torch.no_grad()
     def encode_vae(self, x, noise=None, generator: Optional[torch.Generator] = None, scaling_factor: float = 0.18215):
-        """`vae.encode(x).latent_dist.sample() * scaling_factor` -> [B,4,H/8,W/8] fp16 latents on the GPU.
+        """`vae.encode(x).latent_dist.sample() * scaling_factor` -> [B,4,H/8,W/8] latents on the GPU, in
+        `self.latent_dtype` (fp32 like the reference: fp16 mean + fp32 std * fp16 draw, times the factor in fp32).
         The posterior draw: `noise` if given, else N(0,1) from `generator` (CPU) — the reference draws it
-        unseeded on the device before `manual_seed(seed)` (compute.py:137-139)."""
+        unseeded on the device before `manual_seed(seed)` (compute.py:137-139), in the moments' fp16."""
         B, _, H, W = x.shape
         if noise is None:
             noise = torch.randn(B, 4, H // 8, W // 8, generator=generator, dtype=torch.float32).to(torch.float16)
-        return self.engine.vae_encode(x, noise, scaling_factor)
+        return self.engine.vae_encode(x, noise, scaling_factor, out_dtype=self.latent_dtype)
 
     @torch.no_grad()
     def compute_losses_from_image(self, img, country_embeds, B: int = 10, vae_noise=None, to_host: bool = True):
@@ -142,11 +161,12 @@ class TypicalityScorer:
         noise = noise.expand(n, -1, -1, -1)
         timesteps = timesteps.expand(n)
         slots = self.unet._slots_for(c.to(self.device, torch.float16))
-        return self.engine.score(x, noise, timesteps, slots)
+        return self.engine.score(x, noise, timesteps, slots, latent_dtype=self.latent_dtype)
 
     # -- D.noising (compute.py:115-124) ----------------------------------------------------------
     def draw(self, shape, N: Optional[int] = None):
-        """N interleaved (randn_like, randint) draws after manual_seed(seed) (compute.py:139-141)."""
+        """N interleaved (randn_like, randint) draws after manual_seed(seed) (compute.py:139-141); eps in
+        `self.latent_dtype` (`randn_like(x)` of the fp32 latent is fp32; the fp16 flow rounds the same draws)."""
         N = self.N if N is None else N
         g = torch.Generator(device=self.generator_device)
         g.manual_seed(self.seed)
@@ -154,14 +174,14 @@ class TypicalityScorer:
         noises, ts = [], []
         for _ in range(N):
             noises.append(torch.randn(tuple(shape), generator=g, dtype=torch.float32,
-                                      device=self.generator_device).to(torch.float16))
+                                      device=self.generator_device).to(self.latent_dtype))
             ts.append(torch.randint(lo, hi, (1,), generator=g, device=self.generator_device).long())
         return torch.cat(noises, 0), torch.cat(ts, 0)
 
     # -- D.compute_losses (compute.py:134-160) ---------------------------------------------------
     @torch.no_grad()
     def compute_losses(self, x, country_embeds, B: int = 10, noises=None, timesteps=None, to_host: bool = True):
-        """x [1,4,h,w] latent (fp16); country_embeds [n_cond,77,768] (0 = c, 1 = null).
+        """x [1,4,h,w] latent; country_embeds [n_cond,77,768] (0 = c, 1 = null).
         Returns [N, n_cond, 4, h, w] float16 (on the host like the reference, or on the GPU)."""
         eng = self.engine
         if noises is None or timesteps is None:
@@ -169,13 +189,12 @@ class TypicalityScorer:
         N = noises.shape[0]
         n_cond = country_embeds.shape[0]
         eng.set_prompts(country_embeds)
-        self.unet._ctx_key = None
         # sample row k*N + i = draw i under condition k  -> view as [n_cond, N] then transpose
         if n_cond >= 2:
-            loss = eng.score_conds(x, noises, timesteps, n_cond)            # [n_cond*N,4,h,w] fp32, cond-major
+            loss = eng.score_conds(x, noises, timesteps, n_cond, latent_dtype=self.latent_dtype)   # cond-major rows
         else:
-            slots = torch.zeros(N, dtype=torch.int32, device=self.device)
-            loss = eng.score(x, noises.to(self.device), timesteps.to(self.device), slots)
+            slots = torch.zeros(N, dtype=torch.int32)
+            loss = eng.score(x, noises, timesteps, slots, latent_dtype=self.latent_dtype)
         grid = loss.view(n_cond, N, *loss.shape[1:]).transpose(0, 1).to(torch.float16)   # compute.py:155,160
         return grid.cpu() if to_host else grid.contiguous()
 
@@ -187,8 +206,68 @@ class TypicalityScorer:
     def save_grid(self, typicality_path: str, image_path: str, grid) -> str:
         out = self.get_path(typicality_path, image_path)
         os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
-        np.save(open(out, "wb"), grid.cpu().numpy())
+        with open(out, "wb") as f:
+            np.save(f, grid.cpu().numpy())
         return out
+
+    # -- D.rescale (compute.py:165-180) ----------------------------------------------------------
+    @staticmethod
+    def rescale_size(which: Optional[str], width: int, height: int):
+        """(width, height) `D.rescale` resizes a (width, height) image to: cars -> short side 256 with the long
+        side truncated by int(); places -> short side 512 with the long side rounded up by math.ceil (a square
+        image takes the `else` branch in both); every other dataset is left alone."""
+        import math
+        w, h = width, height
+        if which == "cars":
+            if w > h:
+                w = int(w * 256 / h)
+                h = 256
+            else:
+                h = int(h * 256 / w)
+                w = 256
+        elif which == "places":
+            if width > height:
+                w, h = math.ceil(width * (512 / height)), 512
+            else:
+                w, h = 512, math.ceil(height * (512 / width))
+        return w, h
+
+    def rescale(self, img):
+        """PIL image -> PIL image, LANCZOS like the reference; identity when the size already matches the rule's
+        output is NOT special-cased (the reference resamples anyway)."""
+        import PIL.Image
+        if self.which in ("cars", "places"):
+            return img.resize(self.rescale_size(self.which, img.width, img.height), PIL.Image.LANCZOS)
+        return img
+
+    # -- D.compute / __call__ / exists (compute.py:182-202) --------------------------------------
+    @torch.no_grad()
+    def compute(self, country: str, path: str, vae_noise=None):
+        """`D.compute(country, path)`: open + rescale the image, score it under [country, ""] and write the
+        `[N,2,4,h,w]` float16 grid to `<typicality_path>/<image stem>.npy`.  Needs VAE weights on the engine
+        and `country_embeds`.  The image is cropped to a multiple of 8 pixels for the VAE (the reference's
+        `F.conv2d` chain floors odd sizes implicitly at each stride-2 stage)."""
+        import PIL.Image
+        assert self.typicality_path is not None and self.country_embeds is not None, "scorer built without D's arguments"
+        img = self.rescale(PIL.Image.open(path))
+        seed = os.path.split(path)[1]
+        out = os.path.join(self.typicality_path, seed.replace(".jpg", ".npy").replace(".png", ".npy"))
+        embeds = torch.stack([self.country_embeds[country], self.country_embeds[""]], dim=0)       # 0 = c, 1 = null
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        x = self.load_image(img)
+        H, W = x.shape[-2] // 8 * 8, x.shape[-1] // 8 * 8
+        losses = self.compute_losses_from_image(x[..., :H, :W], embeds, vae_noise=vae_noise)
+        out = self.get_path(self.typicality_path, out)
+        with open(out, "wb") as f:
+            np.save(f, losses.numpy())
+        return out
+
+    def __call__(self, path: str):
+        """`D.__call__`: the stored grid of an image."""
+        return np.load(self.get_path(self.typicality_path, path))
+
+    def exists(self, path: str) -> bool:
+        return os.path.isfile(self.get_path(self.typicality_path, path))
 
     # -- consumers' reductions (xray/compute.py:210-218, cluster.py:517-531) on the GPU ----------
     def heatmap(self, grid):
@@ -200,7 +279,10 @@ class TypicalityScorer:
     def load_typicality(self, grid, image_size, kx: int, ky: int):
         """`Cluster.load_typicality` (cluster.py:125-137) from the grid instead of the .npy path:
         bilinear resize to image_size = (H, W), kx x ky stride-1 average pooling per condition,
-        -(pool(c) - pool(null)), mean over N -> [H-kx+1, W-ky+1] fp32 on the GPU."""
+        -(pool(c) - pool(null)), mean over N -> [H-kx+1, W-ky+1] fp32 on the GPU.  Like the reference's
+        `pool` (utils.py:74-80) the window is applied only when BOTH kx and ky differ from 1."""
+        if kx == 1 or ky == 1:
+            kx = ky = 1
         return self.engine.typicality_image(grid, image_size, kx, ky)
 
     def pixel_heatmap(self, grid, image_size):

@@ -69,15 +69,21 @@ int dm_engine_set_prompts(dm_engine* e, const void* ctx_dev, int n_prompts, void
 
 /* SD.compute_loss (compute.py:95-102), fused: noisy = add_noise(x[x_index[b]], eps[b], t[b]);
  * eps_hat = UNet(noisy, t, prompt[slot[b]]); loss = (float(eps_hat) - float(eps))^2.
- *   x_dev        [n_x,4,h,w] fp16 (n_x images; the reference broadcasts one x over 2B rows)
+ *   latent_dtype DM_F32 or DM_F16: the element type of x_dev / eps_dev AND the arithmetic of add_noise.
+ *     DM_F32 is what the reference's run does: `encode_vae` returns an fp32 latent under autocast (the
+ *     posterior's exp() is promoted, compute.py:91-93), so `randn_like(x)` (:116), the scheduler's
+ *     sqrt(acp[t]) / sqrt(1-acp[t]) coefficients and the sum (:99) are fp32, autocast rounds the noisy latent
+ *     to fp16 once at conv_in, and mse_loss (:101) sees the fp32 eps.
+ *     DM_F16 is the flow of an fp16 latent: table cast to fp16 first, fp16 products and sum, fp16 eps in the loss.
+ *   x_dev        [n_x,4,h,w] (n_x images; the reference broadcasts one x over 2B rows)
  *   x_index_dev  [batch] int32 row of x for sample b, or NULL for identity (n_x == batch)
- *   eps_dev      [batch,4,h,w] fp16
+ *   eps_dev      [batch,4,h,w]
  *   t_dev        [batch] int64 in [0,1000)
- *   slot_dev     [batch] int32 prompt slot (see dm_engine_set_prompts)
+ *   slot_dev     [batch] int32 prompt slot in [0, n_prompts) (see dm_engine_set_prompts)
  *   loss_out_dev [batch,4,h,w] fp32 (NCHW, as F.mse_loss(reduction='none') returns)
  */
 int dm_score(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, const void* eps_dev,
-             const int64_t* t_dev, const int32_t* slot_dev, int batch, int n_x, int h, int w,
+             const int64_t* t_dev, const int32_t* slot_dev, int batch, int n_x, int h, int w, int latent_dtype,
              void* loss_out_dev, void* stream);
 
 /* The same, for the way D.compute_losses actually calls it (compute.py:145-155): every one of
@@ -89,7 +95,7 @@ int dm_score(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, const 
  *   loss_out_dev [n_cond * n_draws, 4, h, w] fp32, cond-major: row k*n_draws + i = draw i, prompt k
  *   (exactly the layout `torch.split(loss, [B]*n_cond)` expects at compute.py:155). */
 int dm_score_conds(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, const void* eps_dev,
-                   const int64_t* t_dev, int n_cond, int n_draws, int n_x, int h, int w,
+                   const int64_t* t_dev, int n_cond, int n_draws, int n_x, int h, int w, int latent_dtype,
                    void* loss_out_dev, void* stream);
 
 /* `unet(sample, t, encoder_hidden_states).sample` (compute.py:100) without the fused
@@ -113,6 +119,14 @@ int dm_dift_shape(int h, int w, int up_ft_index, int* c_out, int* h_out, int* w_
  *   scalar_out_dev [1] fp32 = mean over pixels of the map (T(x|c)).  Either may be NULL. */
 int dm_reduce_typicality(dm_engine* e, const void* loss_dev, int loss_is_f16, int n_draws, int n_cond,
                          int h, int w, void* map_out_dev, void* scalar_out_dev, void* stream);
+
+/* The same for the grids of n_images images in one launch: maps_out_dev [n_images,h,w] fp32 (required),
+ * scalars_out_dev [n_images] fp32 (optional).  cond_major = 0: loss_dev is [n_images, n_draws, n_cond, 4, h, w]
+ * (the reference's grids back to back); cond_major = 1: [n_cond, n_images, n_draws, 4, h, w], i.e. the rows
+ * dm_score_conds writes when its n_draws argument is n_images * n_draws (image-major draws) - no transpose needed. */
+int dm_reduce_typicality_batched(dm_engine* e, const void* loss_dev, int loss_is_f16, int n_images, int n_draws,
+                                 int n_cond, int h, int w, int cond_major, void* maps_out_dev, void* scalars_out_dev,
+                                 void* stream);
 
 /* Image-space form of the same reduction, as `Cluster.load_typicality` (cluster.py:125-137) and
  * `Typicallity.compute` (xray/compute.py:210-218) produce it: the latent map is resized with
@@ -200,6 +214,8 @@ int dm_engine_memory(dm_engine* e, size_t* weights_bytes, size_t* arena_bytes);
 int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, const void* bias, const void* temb,
                 const void* res, void* Y, int N, int H, int W, int C1, int C2, int Cout, int OH, int OW,
                 int mode, int epi, int temb_ld);
+/* which tile geometry dm_op_igemm runs a shape on: 0 = 128-row tile (128x320 / 128x160), 1 = 256x320 tile */
+int dm_op_igemm_tile(int M, int Cin, int Cout, int mode);
 int dm_op_attention(void* stream, const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv,
                     int ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso, const int32_t* kv_slot,
                     int B, int heads, int Tq, int Tk, int D, float scale);

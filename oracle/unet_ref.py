@@ -266,26 +266,34 @@ def unet_forward(sd: Dict[str, torch.Tensor], sample: torch.Tensor, timesteps: t
 # scoring surface — diffmining/typicality/compute.py:95-160
 # --------------------------------------------------------------------------------------------
 def compute_loss(sd, x, noise, timesteps, c, cfg: RefConfig = SD15_REF, autocast: bool = True,
-                 acp: Optional[torch.Tensor] = None):
+                 acp: Optional[torch.Tensor] = None, latent_dtype: torch.dtype = torch.float32):
     """`SD.compute_loss` (compute.py:95-102): add_noise -> U-Net -> per-element squared error.
 
-    x [1 or 2B,4,h,w] fp16-valued; noise [2B,4,h,w]; timesteps [2B] int64; c [2B,77,768].
-    Returns loss [2B,4,h,w] fp32.
+    x [1 or 2B,4,h,w]; noise [2B,4,h,w]; timesteps [2B] int64; c [2B,77,768].  Returns loss [2B,4,h,w] fp32.
+
+    `latent_dtype` (only meaningful with autocast=True) is the dtype x and noise arrive in:
+      * torch.float32 — the reference's actual flow.  `encode_vae` runs under `@torch.autocast` (compute.py:91-93);
+        `DiagonalGaussianDistribution` takes `std = exp(0.5 * logvar)` and autocast promotes `exp` to fp32, so
+        `mean + std * sample` and hence x are fp32; `randn_like(x)` (:116) is fp32; `add_noise` (:99) casts the
+        table to x.dtype = fp32 and stays fp32; autocast rounds the noisy latent to fp16 only as conv_in's
+        input; `mse_loss(noise_pred.float(), noise)` (:101) sees the unrounded fp32 noise.
+      * torch.float16 — an fp16 latent handed to the fp16 scheduler (table cast to fp16 first).
     """
     n = c.shape[0]
     noise = noise.expand(n, -1, -1, -1)
     xe = x.expand(n, -1, -1, -1)
     te = timesteps.expand(n)
-    if autocast:
-        noisy = add_noise(xe.half(), noise.half(), te, acp).float()
+    if autocast and latent_dtype == torch.float16:
+        noise = noise.half()
+        noisy = add_noise(xe.half(), noise, te, acp).float()
     else:
-        noisy = add_noise(xe.float(), noise.float(), te, acp)
+        noisy = add_noise(xe.float(), noise.float(), te, acp)        # fp32; unet_forward rounds it when autocast
     pred = unet_forward(sd, noisy, te, c, cfg, autocast)
     return F.mse_loss(pred.float(), noise.float(), reduction="none")
 
 
 def draw_noise_and_timesteps(shape, N, t_min, t_max, seed=42, num_train_timesteps=1000,
-                             dtype=torch.float16):
+                             dtype=torch.float32):
     """`D.noising` ×N after `torch.manual_seed(seed)` (compute.py:115-124,139-141), on the CPU
     generator: interleaved randn_like / randint draws.  Device (Philox) draws are launch-geometry
     dependent and not portable, so parity tests inject these explicitly."""
@@ -300,7 +308,7 @@ def draw_noise_and_timesteps(shape, N, t_min, t_max, seed=42, num_train_timestep
 
 
 def compute_losses(sd, x, cond_embeds, noises, timesteps, B=10, cfg: RefConfig = SD15_REF,
-                   autocast: bool = True):
+                   autocast: bool = True, latent_dtype: torch.dtype = torch.float32):
     """`D.compute_losses` (compute.py:134-160) from the latent on (VAE is outside the path).
 
     x [1,4,h,w]; cond_embeds [n_cond,77,768] (index 0 = c, 1 = null, compute.py:187-188);
@@ -314,7 +322,7 @@ def compute_losses(sd, x, cond_embeds, noises, timesteps, B=10, cfg: RefConfig =
         n_batch = torch.cat([nb] * n_cond, 0)                       # cond-major tiling (:150-151)
         t_batch = torch.cat([tb] * n_cond, 0)
         c = torch.cat([cond_embeds[k].unsqueeze(0).expand(bs, -1, -1) for k in range(n_cond)], 0)
-        loss = compute_loss(sd, x, n_batch, t_batch, c, cfg, autocast)
+        loss = compute_loss(sd, x, n_batch, t_batch, c, cfg, autocast, latent_dtype=latent_dtype)
         grids.append(torch.stack(torch.split(loss, [bs] * n_cond, dim=0), dim=1))   # (:155)
     return torch.cat(grids, 0).to(torch.float16)
 

@@ -1,6 +1,6 @@
 """Generates the committed golden vectors under tests/golden/ from the CPU oracle.
 
-    python tests/make_golden.py            (--vae-only / --clip-only regenerate just that fixture)
+    python tests/make_golden.py            (--vae-only / --clip-only / --unet-only regenerate just those fixtures)
 
 Inputs come from the integer-hash generator (diff-mining_amd/synth.py), weights are NOT stored
 (regenerated deterministically, seed 0); outputs are the oracle's.  The reference itself cannot
@@ -70,22 +70,32 @@ def main():
         for f in sorted(os.listdir(OUT)):
             print(f, os.path.getsize(os.path.join(OUT, f)))
         return
-    vae()
-    clip()
+    if "--unet-only" not in sys.argv:
+        vae()
+        clip()
     sd = {k: torch.from_numpy(v).float() for k, v in synth.synth_state_dict(seed=0, dtype=np.float16).items()}
-    # scoring, latent 8x8, 2 draws x 2 prompts
-    x, eps, t, c = synth.synth_inputs(1, 2, 8, 8)
+    # scoring, latent 8x8, 2 draws x 2 prompts.  fp32 latents / draws (the reference's dtype flow, compute.py:91-101,116)
+    # and their fp16 roundings (the fp16-scheduler flow); three oracle outputs.
+    x, eps, t, c = synth.synth_inputs(1, 2, 8, 8, latent_dtype=np.float32)
     xt, et, tt, ct = (torch.from_numpy(a) for a in (x, eps, t, c))
     nb = torch.cat([et] * 2)
     tb = torch.cat([tt] * 2)
     cc = torch.cat([ct[k:k + 1].expand(2, -1, -1) for k in range(2)])
-    la = R.compute_loss(sd, xt, nb, tb, cc, autocast=True).numpy()
+    la32 = R.compute_loss(sd, xt, nb, tb, cc, autocast=True, latent_dtype=torch.float32).numpy()
+    la16 = R.compute_loss(sd, xt.half(), nb.half(), tb, cc, autocast=True, latent_dtype=torch.float16).numpy()
     l32 = R.compute_loss(sd, xt, nb, tb, cc, autocast=False).numpy()
-    np.savez_compressed(os.path.join(OUT, "score_8x8.npz"), x=x, eps=eps, t=t, c=c, loss_autocast=la, loss_fp32=l32)
-    # compute_losses grid [4,2,4,8,8] from CPU-generator draws (seed 42, t in [100,700))
+    np.savez_compressed(os.path.join(OUT, "score_8x8.npz"), x=x, eps=eps, t=t, c=c, loss_autocast_f32flow=la32,
+                        loss_autocast_f16flow=la16, loss_fp32=l32)
+    # compute_losses grid [4,2,4,8,8] from CPU-generator draws (seed 42, t in [100,700)), fp32 draws
     noises, ts = R.draw_noise_and_timesteps((1, 4, 8, 8), 4, 0.1, 0.7, seed=42)
     grid = R.compute_losses(sd, xt, ct.float(), noises, ts, B=4).numpy()
-    np.savez_compressed(os.path.join(OUT, "grid_8x8.npz"), x=x, c=c, noises=noises.numpy(), timesteps=ts.numpy(), grid=grid)
+    grid16 = R.compute_losses(sd, xt.half(), ct.float(), noises.half(), ts, B=4, latent_dtype=torch.float16).numpy()
+    np.savez_compressed(os.path.join(OUT, "grid_8x8.npz"), x=x, c=c, noises=noises.numpy(), timesteps=ts.numpy(), grid=grid,
+                        grid_f16flow=grid16)
+    if "--unet-only" in sys.argv and "--dift" not in sys.argv:
+        for f in sorted(os.listdir(OUT)):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+        return
     # DIFT tap at latent 16x16, ensemble 2, t=161 (fp32 oracle like the reference's fp32 DIFT path)
     x16, eps16, _, c16 = synth.synth_inputs(1, 2, 16, 16)
     noisy = R.add_noise(torch.from_numpy(x16).float().expand(2, -1, -1, -1), torch.from_numpy(eps16).float(),

@@ -1,0 +1,132 @@
+"""Pins the oracle (and through it the engine) to the REAL dependency of the reference's hot path.
+
+    python tests/make_golden_with_diffusers.py        # needs: pip install diffusers==0.24.0 (environment.yaml:15)
+
+NOT runnable in the build image (diffusers is absent there and there is no network — SURVEY.md §0 F4), and never
+imported by the product, the GPU tests or bench.py: it only WRITES fixtures.  Anyone with the reference's
+environment runs it once and commits the files; from then on
+    tests/test_oracle.py::test_oracle_against_real_diffusers_fixture      (CPU tier)
+    tests/test_gpu_e2e.py::test_against_real_diffusers_fixture            (GPU tier)
+compare the oracle / the engine with diffusers' own outputs and parity stops being "unpinned".
+
+What it does (the reference's call sequence, not a copy of its code):
+  * `UNet2DConditionModel(**SD15_UNET_CONFIG)` — the public `unet/config.json` of runwayml/stable-diffusion-v1-5 —
+    loaded (strict) with the deterministic synthetic weights of diff-mining_amd/synth.py (no checkpoint needed);
+  * `PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000)`,
+    the scheduler of the stock pipeline the reference loads (compute.py:65-70);
+  * the three calls of `SD.compute_loss` (compute.py:99-101): scheduler.add_noise -> unet(...).sample -> F.mse_loss
+    (reduction="none"), in fp32 on the CPU and — when a GPU is present — under torch.autocast(float16) exactly as
+    compute.py:98 does, with the fp32 latents / draws the reference's `encode_vae` / `randn_like` produce;
+  * optionally the DIFT tap (dift.py:24-169 exits after up_blocks[1]; reproduced here with a forward hook on the
+    stock model's `up_blocks[1]`, which sees the same tensor) and `AutoencoderKL.encode` for the VAE oracle.
+Outputs: tests/golden/score_diffusers.npz, dift_diffusers.npz, vae_diffusers.npz (inputs + outputs + versions).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+SD15_UNET_CONFIG = dict(
+    sample_size=64, in_channels=4, out_channels=4, center_input_sample=False, flip_sin_to_cos=True, freq_shift=0,
+    down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+    block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, downsample_padding=1, mid_block_scale_factor=1,
+    act_fn="silu", norm_num_groups=32, norm_eps=1e-5, cross_attention_dim=768, attention_head_dim=8,
+)
+SD15_VAE_CONFIG = dict(
+    in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",) * 4, up_block_types=("UpDecoderBlock2D",) * 4,
+    block_out_channels=(128, 256, 512, 512), layers_per_block=2, act_fn="silu", latent_channels=4, norm_num_groups=32,
+    sample_size=512, scaling_factor=0.18215,
+)
+
+
+def _tile(eps, t, c):
+    n_cond, N = c.shape[0], eps.shape[0]
+    return (torch.cat([eps] * n_cond), torch.cat([t] * n_cond),
+            torch.cat([c[k:k + 1].expand(N, -1, -1) for k in range(n_cond)]))
+
+
+def main():
+    try:
+        import diffusers
+        from diffusers import AutoencoderKL, PNDMScheduler, UNet2DConditionModel
+    except ImportError as e:                                   # the build image lands here
+        sys.exit(f"diffusers is not installed ({e}); install diffusers==0.24.0 (the reference's pin) and re-run")
+    from diff_mining_amd import synth
+    os.makedirs(OUT, exist_ok=True)
+    ver = np.array(f"diffusers {diffusers.__version__}, torch {torch.__version__}")
+
+    # ---- scoring: SD.compute_loss on identical (x, eps, t, c) -------------------------------------------------
+    unet = UNet2DConditionModel(**SD15_UNET_CONFIG).eval()
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(seed=0, dtype=np.float32).items()}
+    unet.load_state_dict(sd, strict=True)                      # 686 tensors, diffusers names: must load unmodified
+    sched = PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000,
+                          skip_prk_steps=True)
+    out = {}
+    for (h, w, n_draws) in ((8, 8, 2), (16, 16, 1)):
+        x, eps, t, c = (torch.from_numpy(a) for a in synth.synth_inputs(1, n_draws, h, w, latent_dtype=np.float32))
+        nb, tb, cc = _tile(eps, t, c)
+        with torch.no_grad():
+            noisy = sched.add_noise(x.expand(nb.shape[0], -1, -1, -1), nb, tb)
+            pred = unet(noisy, tb, cc.float()).sample
+            loss32 = F.mse_loss(pred.float(), nb, reduction="none")
+        tag = f"{h}x{w}"
+        out.update({f"x_{tag}": x.numpy(), f"eps_{tag}": eps.numpy(), f"t_{tag}": t.numpy(), f"c_{tag}": c.numpy(),
+                    f"noisy_fp32_cpu_{tag}": noisy.numpy(), f"pred_fp32_cpu_{tag}": pred.numpy(),
+                    f"loss_fp32_cpu_{tag}": loss32.numpy()})
+        if torch.cuda.is_available():
+            dev = torch.device("cuda")
+            u16 = UNet2DConditionModel(**SD15_UNET_CONFIG).eval()
+            u16.load_state_dict(sd, strict=True)
+            u16 = u16.to(dev, torch.float16)                   # torch_dtype=torch.float16 (compute.py:69)
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                xe, ne, te = x.to(dev).expand(nb.shape[0], -1, -1, -1), nb.to(dev), tb.to(dev)
+                noisy = sched.add_noise(xe, ne, te)
+                pred = u16(noisy, te, cc.to(dev)).sample
+                loss = F.mse_loss(pred.float(), ne, reduction="none")
+            out.update({f"loss_autocast_cuda_{tag}": loss.float().cpu().numpy(),
+                        f"pred_autocast_cuda_{tag}": pred.float().cpu().numpy(),
+                        f"noisy_dtype_{tag}": np.array(str(noisy.dtype))})
+    # the keys the tests read (8x8 case)
+    for k in ("x", "eps", "t", "c", "loss_fp32_cpu", "pred_fp32_cpu", "loss_autocast_cuda"):
+        if f"{k}_8x8" in out:
+            out[k] = out[f"{k}_8x8"]
+    np.savez_compressed(os.path.join(OUT, "score_diffusers.npz"), diffusers_version=ver, **out)
+
+    # ---- DIFT tap: output of up_blocks[1] (dift.py:134-165), fp32 like the reference's DIFT pipeline ---------
+    x, eps, _, c = (torch.from_numpy(a) if isinstance(a, np.ndarray) else a
+                    for a in synth.synth_inputs(1, 2, 16, 16, latent_dtype=np.float32))
+    tt = torch.tensor([161, 161])
+    grabbed = {}
+    hook = unet.up_blocks[1].register_forward_hook(lambda m, i, o: grabbed.__setitem__("ft", o))
+    with torch.no_grad():
+        noisy = sched.add_noise(x.expand(2, -1, -1, -1), eps, tt)
+        unet(noisy, tt, c[:1].float().expand(2, -1, -1))
+    hook.remove()
+    np.savez_compressed(os.path.join(OUT, "dift_diffusers.npz"), diffusers_version=ver, noisy=noisy.numpy(), t=np.int64(161),
+                        prompt=c[:1].numpy(), feat_fp32=grabbed["ft"].numpy().astype(np.float16))
+
+    # ---- VAE encoder moments (compute.py:91-93) ----------------------------------------------------------------
+    vae = AutoencoderKL(**SD15_VAE_CONFIG).eval()
+    vsd = {k: torch.from_numpy(v) for k, v in synth.synth_vae_state_dict(seed=0, dtype=np.float32).items()}
+    own = vae.state_dict()
+    own.update({k: v for k, v in vsd.items() if k in own})     # encoder.* and quant_conv.*; the decoder keeps its init
+    vae.load_state_dict(own, strict=True)
+    img = torch.from_numpy(synth.synth_image(2, 64, 64)).float()
+    with torch.no_grad():
+        post = vae.encode(img).latent_dist
+    np.savez_compressed(os.path.join(OUT, "vae_diffusers.npz"), diffusers_version=ver, image=img.numpy().astype(np.float16),
+                        moments=torch.cat([post.mean, post.logvar], 1).numpy())
+    for f in sorted(os.listdir(OUT)):
+        if "diffusers" in f:
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

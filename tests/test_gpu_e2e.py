@@ -1,15 +1,16 @@
 """End-to-end parity of the HIP engine against the CPU oracle on identical (x, t, eps, c) and
 identical synthetic SDv1.5 weights, through the C ABI.
 
-Tolerance statement (north_star: "<= 1e-3 rel fp16"): the reference path itself is fp16 autocast,
-whose own rounding noise against exact fp32 arithmetic measures ~1.5e-3 rel-L2 on eps_hat with
-these weights (oracle autocast-vs-fp32).  Two independent fp16 implementations therefore cannot
-agree elementwise to 1e-3; what is asserted is
-   rel-L2(eps_hat_engine, eps_hat_oracle_autocast) <= 3e-3   and the same against oracle fp32,
-   rel-L2(loss grid) <= 6e-3 (loss = squared error doubles the relative error),
-   |T(x|c)_engine - T(x|c)_oracle| <= 2e-3 * mean loss   (absolute, for the difference of two
-   near-equal losses, SURVEY.md §7 hard part 3).
-Measured values are printed so the judge can see the margins."""
+Both dtype flows of `SD.compute_loss` are tested: "f32" (the reference's: fp32 latent and draws, fp32 add_noise,
+fp32 eps in the MSE — compute.py:91-101,116) and "f16" (fp16 scheduler arithmetic).
+
+Tolerance statement (north_star: "<= 1e-3 rel fp16"): the reference path itself is fp16 autocast, whose own
+rounding noise against exact fp32 arithmetic measures ~1.5e-3 rel-L2 on eps_hat with these weights (oracle
+autocast-vs-fp32, printed below).  Two independent fp16 implementations therefore cannot agree elementwise to
+1e-3; every bound asserted here is <= 2x the value measured on MI355X (r02, printed by each test and tabulated
+in DESIGN.md §2), so a regression of 2x fails:
+   rel-L2(eps_hat_engine, oracle autocast / fp32), rel-L2(loss grid), and for the score north_star ends on,
+   |T_engine - T_oracle| relative to |T| and to the mean loss at N = 10 draws."""
 import json
 import os
 
@@ -24,6 +25,14 @@ from oracle import unet_ref as R  # noqa: E402
 from tests import gpu_util as U  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+FLOW = {"f32": (np.float32, torch.float32), "f16": (np.float16, torch.float16)}
+
+# asserted bounds (<= 2x the r02 measurements on MI355X; see the module docstring)
+TOL_EPS_HAT = 3e-3        # eps_hat rel-L2 vs autocast oracle and vs fp32 oracle
+TOL_LOSS = 3e-3           # loss grid rel-L2 vs autocast oracle
+TOL_T_MEANLOSS = 6e-4     # |dT| / mean loss, few draws
+TOL_T10_MEANLOSS = 3e-4   # |dT| / mean loss at N = 10 draws
+TOL_T10_REL = 1.5e-2      # |dT| / |T| at N = 10 draws
 
 
 @pytest.fixture(scope="module")
@@ -36,8 +45,8 @@ def engine(sd15_weights_f16):
     e.close()
 
 
-def _inputs(h, w, n_draws, n_img=1):
-    x, eps, t, c = synth.synth_inputs(n_img, n_draws, h, w)
+def _inputs(h, w, n_draws, n_img=1, flow="f16"):
+    x, eps, t, c = synth.synth_inputs(n_img, n_draws, h, w, latent_dtype=FLOW[flow][0])
     return torch.from_numpy(x), torch.from_numpy(eps), torch.from_numpy(t), torch.from_numpy(c)
 
 
@@ -50,56 +59,190 @@ def _tile(eps, t, c):
     return nb, tb, cc, slots
 
 
+def _T(loss, N, h, w):
+    return R.typicality_scalar(loss.view(2, N, 4, h, w).transpose(0, 1)).item()
+
+
+@pytest.mark.parametrize("flow", ["f32", "f16"])
 @pytest.mark.parametrize("h,w,n_draws", [(8, 8, 2), (16, 16, 2), (12, 10, 1), (32, 32, 1)])
-def test_unet_and_loss_vs_oracle(engine, sd15_weights_torch, h, w, n_draws):
-    x, eps, t, c = _inputs(h, w, n_draws)
+def test_unet_and_loss_vs_oracle(engine, sd15_weights_torch, h, w, n_draws, flow):
+    x, eps, t, c = _inputs(h, w, n_draws, flow=flow)
+    ldt = FLOW[flow][1]
     nb, tb, cc, slots = _tile(eps, t, c)
     engine.set_prompts(c)
-    # 1) plain U-Net forward on the same noisy latents
-    noisy = R.add_noise(x.expand(nb.shape[0], -1, -1, -1), nb, tb)            # fp16 arithmetic
+    # 1) plain U-Net forward on the same noisy latents (the flow's own add_noise arithmetic, rounded to fp16 once)
+    noisy = R.add_noise(x.expand(nb.shape[0], -1, -1, -1), nb, tb).half()
     pred = engine.unet(noisy, tb, slots).float().cpu()
     ref_ac = R.unet_forward(sd15_weights_torch, noisy.float(), tb, cc.float(), autocast=True)
     ref_32 = R.unet_forward(sd15_weights_torch, noisy.float(), tb, cc.float(), autocast=False)
     r_ac, r_32 = U.rel_l2(pred, ref_ac), U.rel_l2(pred, ref_32)
     r_oo = U.rel_l2(ref_ac, ref_32)
-    print(f"[{h}x{w}] eps_hat rel-L2: engine/autocast-oracle {r_ac:.2e}, engine/fp32-oracle {r_32:.2e}, "
+    print(f"[{h}x{w} {flow}] eps_hat rel-L2: engine/autocast-oracle {r_ac:.2e}, engine/fp32-oracle {r_32:.2e}, "
           f"autocast-oracle/fp32-oracle {r_oo:.2e}; max|err| {U.max_abs(pred, ref_ac):.2e} of max|ref| {ref_ac.abs().max():.2f}")
     assert not torch.isnan(pred).any()
-    assert r_ac < 3e-3 and r_32 < 3e-3, (r_ac, r_32)
-    # 2) fused score path (add_noise + U-Net + eps-MSE)
-    loss = engine.score(x, nb, tb, slots).cpu()
-    ref_loss = R.compute_loss(sd15_weights_torch, x, nb, tb, cc, autocast=True)
+    assert r_ac < TOL_EPS_HAT and r_32 < TOL_EPS_HAT, (r_ac, r_32)
+    # 2) fused score path (add_noise + U-Net + eps-MSE) in this dtype flow
+    loss = engine.score(x, nb, tb, slots, latent_dtype=ldt).cpu()
+    ref_loss = R.compute_loss(sd15_weights_torch, x, nb, tb, cc, autocast=True, latent_dtype=ldt)
     rl = U.rel_l2(loss, ref_loss)
-    print(f"[{h}x{w}] loss rel-L2 {rl:.2e}")
+    print(f"[{h}x{w} {flow}] loss rel-L2 {rl:.2e}")
     assert loss.shape == ref_loss.shape and loss.dtype == torch.float32
-    assert rl < 6e-3, rl
-    # fused path == unfused path bit for bit (same kernels, add_noise fused into conv_in)
+    assert rl < TOL_LOSS, rl
+    # fused path == unfused path bit for bit (same kernels, add_noise fused into conv_in; fp32 eps in the f32 flow)
     loss_unfused = (pred - nb.float()) ** 2
     assert torch.equal(loss, loss_unfused)
     # 3) typicality scalar
-    N = n_draws
-    grid = loss.view(2, N, 4, h, w).transpose(0, 1)
-    grid_ref = ref_loss.view(2, N, 4, h, w).transpose(0, 1)
-    T, T_ref = R.typicality_scalar(grid).item(), R.typicality_scalar(grid_ref).item()
-    print(f"[{h}x{w}] T(x|c) engine {T:.5f} oracle {T_ref:.5f} mean loss {ref_loss.mean():.4f}")
-    assert abs(T - T_ref) <= 2e-3 * ref_loss.mean().item()
+    T, T_ref = _T(loss, n_draws, h, w), _T(ref_loss, n_draws, h, w)
+    dm = abs(T - T_ref) / ref_loss.mean().item()
+    print(f"[{h}x{w} {flow}] T(x|c) engine {T:.5f} oracle {T_ref:.5f} mean loss {ref_loss.mean():.4f}: "
+          f"|dT|/|T| {abs(T - T_ref) / abs(T_ref):.2e}, |dT|/mean-loss {dm:.2e}")
+    assert dm <= TOL_T_MEANLOSS, dm
+
+
+def test_dtype_flows_differ_as_the_oracle_says(engine, sd15_weights_torch):
+    """The two flows are different computations (fp16-rounded sqrt(1 - acp) differs by up to 7 % at small t): the
+    engine's f32-vs-f16 difference must match the oracle's f32-vs-f16 difference, and at t = 0 the coefficient gap
+    (0.029155 vs 0.03125) must show."""
+    x, eps, t, c = _inputs(8, 8, 2, flow="f32")
+    t = torch.tensor([0, 5])
+    nb, tb, cc, slots = _tile(eps, t, c)
+    engine.set_prompts(c)
+    l32 = engine.score(x, nb, tb, slots, latent_dtype=torch.float32).cpu()
+    l16 = engine.score(x.half(), nb.half(), tb, slots, latent_dtype=torch.float16).cpu()
+    r32 = R.compute_loss(sd15_weights_torch, x, nb, tb, cc, autocast=True, latent_dtype=torch.float32)
+    r16 = R.compute_loss(sd15_weights_torch, x.half(), nb.half(), tb, cc, autocast=True, latent_dtype=torch.float16)
+    d_eng, d_ref = U.rel_l2(l32, l16), U.rel_l2(r32, r16)
+    print(f"t in (0, 5): flow difference engine {d_eng:.2e} oracle {d_ref:.2e}; engine-vs-oracle f32 {U.rel_l2(l32, r32):.2e} "
+          f"f16 {U.rel_l2(l16, r16):.2e}")
+    assert d_eng > 5e-3 and abs(d_eng - d_ref) < 0.25 * d_ref
+    assert U.rel_l2(l32, r32) < TOL_LOSS and U.rel_l2(l16, r16) < TOL_LOSS
 
 
 def test_baseline_shape_vs_oracle(engine, sd15_weights_torch):
-    """BASELINE configs[1] geometry (512 px -> 64x64 latent), 1 draw x 2 prompts, against the oracle.
-    Exercises the 256x320 igemm tiles and the 4096-token attention that the small cases do not."""
-    x, eps, t, c = _inputs(64, 64, 1)
+    """BASELINE configs[1] geometry (512 px -> 64x64 latent), 1 draw x 2 prompts, against the oracle: the 4096-token
+    attention and the 64x64 layers that the small cases do not reach.  (Two samples give <= 256 row tiles, so the
+    256x320 igemm tile is NOT reached here: test_gpu_ops.py::test_igemm_conv3x3_big_tile_vs_conv2d and
+    test_score_at_baseline_draw_count cover it.)"""
+    x, eps, t, c = _inputs(64, 64, 1, flow="f32")
     nb, tb, cc, slots = _tile(eps, t, c)
     engine.set_prompts(c)
     loss = engine.score(x, nb, tb, slots).cpu()
     torch.set_num_threads(min(16, torch.get_num_threads()))
     ref = R.compute_loss(sd15_weights_torch, x, nb, tb, cc, autocast=True)
     rl = U.rel_l2(loss, ref)
-    T = R.typicality_scalar(loss.view(2, 1, 4, 64, 64).transpose(0, 1)).item()
-    T_ref = R.typicality_scalar(ref.view(2, 1, 4, 64, 64).transpose(0, 1)).item()
-    print(f"[64x64] loss rel-L2 {rl:.2e}; T(x|c) engine {T:.5f} oracle {T_ref:.5f}; mean loss {ref.mean():.4f}")
-    assert rl < 6e-3, rl
-    assert abs(T - T_ref) <= 2e-3 * ref.mean().item()
+    T, T_ref = _T(loss, 1, 64, 64), _T(ref, 1, 64, 64)
+    dm = abs(T - T_ref) / ref.mean().item()
+    print(f"[64x64] loss rel-L2 {rl:.2e}; T(x|c) engine {T:.5f} oracle {T_ref:.5f}; mean loss {ref.mean():.4f}; "
+          f"|dT|/|T| {abs(T - T_ref) / abs(T_ref):.2e} |dT|/mean-loss {dm:.2e}")
+    assert rl < TOL_LOSS, rl
+    assert dm <= TOL_T_MEANLOSS
+
+
+@pytest.mark.parametrize("n_img,N,h,w", [(2, 10, 32, 32), (1, 4, 64, 64)])
+def test_score_at_baseline_draw_count(engine, sd15_weights_torch, n_img, N, h, w):
+    """The quantity north_star ends on — T(x|c) = E_N[L_null - L_c] — at the BASELINE draw count (N = 10 draws x 2
+    prompts per image; 8 images x N = 10 @64x64 is beyond the CPU oracle's reach, so 2 images x 10 @32x32 and
+    1 image x 4 @64x64), through `TypicalityScorer.compute_losses` (dm_score_conds) in the reference's dtype flow.
+    Reports |dT|/|T| and |dT|/mean-loss per image."""
+    from diff_mining_amd.typicality import TypicalityScorer
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    sc = TypicalityScorer(engine, seed=42, N=N, t_min=0.1, t_max=0.7)
+    xs, _, _, c = _inputs(h, w, 1, n_img=n_img, flow="f32")
+    out = []
+    for i in range(n_img):
+        x = xs[i:i + 1]
+        noises, ts = sc.draw(x.shape)
+        assert noises.dtype == torch.float32
+        grid = sc.compute_losses(x, c, noises=noises, timesteps=ts, to_host=False)
+        ref = R.compute_losses(sd15_weights_torch, x, c.float(), noises, ts, B=N)
+        assert grid.shape == ref.shape == (N, 2, 4, h, w) and grid.dtype == torch.float16
+        rl = U.rel_l2(grid.float().cpu(), ref.float())
+        T = engine.reduce_typicality(grid)[1].item()
+        T_ref = R.typicality_scalar(ref).item()
+        ml = ref.float().mean().item()
+        out.append((rl, abs(T - T_ref) / abs(T_ref), abs(T - T_ref) / ml))
+        print(f"[{h}x{w} N={N} image {i}] grid rel-L2 {rl:.2e}; T engine {T:.6f} oracle {T_ref:.6f} mean loss {ml:.4f}: "
+              f"|dT|/|T| {out[-1][1]:.2e}  |dT|/mean-loss {out[-1][2]:.2e}")
+        assert rl < TOL_LOSS
+        assert out[-1][2] <= (TOL_T10_MEANLOSS if N >= 10 else TOL_T_MEANLOSS)
+        if N >= 10:
+            assert out[-1][1] <= TOL_T10_REL
+
+
+def test_config1_substitute_cars_geometry(engine, sd15_weights_torch):
+    """BASELINE configs[0] stand-in (the CarDB / CPU-diffusers run itself cannot exist here): 16
+    synthetic latents [1,4,32,48] (cars geometry: 256 x 384 px), N = 2 draws, cond vs null -> T(x|c) per image,
+    engine vs oracle ("restatement, not diffusers")."""
+    from diff_mining_amd.typicality import TypicalityScorer
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    n_img, N, h, w = 16, 2, 32, 48
+    sc = TypicalityScorer(engine, seed=42, N=N, t_min=0.1, t_max=0.7)
+    xs, _, _, c = _inputs(h, w, 1, n_img=n_img, flow="f32")
+    noises, ts = sc.draw((1, 4, h, w))
+    # all 16 images in one engine call (image-major draws, batched on-device reduction) ...
+    engine.set_prompts(c)
+    xi = torch.arange(n_img, dtype=torch.int32).repeat_interleave(N)
+    loss = engine.score_conds(xs, noises.repeat(n_img, 1, 1, 1), ts.repeat(n_img), 2, x_index=xi)
+    maps, T = engine.reduce_typicality_batched(loss, n_img, N, 2, cond_major=True)
+    T = T.cpu()
+    # ... against the oracle image by image
+    T_ref, ml = [], []
+    for i in range(n_img):
+        ref = R.compute_losses(sd15_weights_torch, xs[i:i + 1], c.float(), noises, ts, B=N)
+        T_ref.append(R.typicality_scalar(ref).item())
+        ml.append(ref.float().mean().item())
+        # same image through the per-image surface: bit-identical to its rows of the batched call
+        if i in (0, n_img - 1):
+            g = sc.compute_losses(xs[i:i + 1], c, noises=noises, timesteps=ts, to_host=False)
+            rows = loss.view(2, n_img, N, 4, h, w)[:, i].transpose(0, 1)
+            assert torch.equal(g, rows.half())
+            assert torch.allclose(engine.reduce_typicality(rows.contiguous())[0], maps[i], atol=0, rtol=0)
+    T_ref, ml = torch.tensor(T_ref), torch.tensor(ml)
+    dm = ((T - T_ref).abs() / ml)
+    print("config-1 substitute: T engine", [round(v, 5) for v in T.tolist()])
+    print("                     T oracle", [round(v, 5) for v in T_ref.tolist()])
+    print(f"                     max |dT|/mean-loss {dm.max():.2e}, rank agreement "
+          f"{(T.argsort() == T_ref.argsort()).float().mean():.2f}")
+    assert dm.max().item() <= TOL_T_MEANLOSS
+
+
+def test_golden_grid_fixture(engine):
+    """tests/golden/grid_8x8.npz: `D.compute_losses` grid [4,2,4,8,8] from the oracle (CPU-generator draws, seed 42)
+    vs the engine, in both dtype flows."""
+    from diff_mining_amd.typicality import TypicalityScorer
+    g = np.load(os.path.join(GOLDEN, "grid_8x8.npz"))
+    x, c = torch.from_numpy(g["x"]), torch.from_numpy(g["c"])
+    noises, ts = torch.from_numpy(g["noises"]), torch.from_numpy(g["timesteps"])
+    assert x.dtype == torch.float32 and noises.dtype == torch.float32
+    sc = TypicalityScorer(engine, seed=42, N=4, t_min=0.1, t_max=0.7)
+    n2, t2 = sc.draw(x.shape)
+    assert torch.equal(n2, noises) and torch.equal(t2, ts)                 # the scorer draws what the fixture holds
+    grid = sc.compute_losses(x, c)
+    r32 = U.rel_l2(grid.float(), torch.from_numpy(g["grid"]).float())
+    sc16 = TypicalityScorer(engine, seed=42, N=4, t_min=0.1, t_max=0.7, latent_dtype=torch.float16)
+    grid16 = sc16.compute_losses(x.half(), c)
+    r16 = U.rel_l2(grid16.float(), torch.from_numpy(g["grid_f16flow"]).float())
+    print(f"golden grid 8x8 rel-L2: f32 flow {r32:.2e}, f16 flow {r16:.2e}")
+    assert grid.shape == (4, 2, 4, 8, 8) and grid.dtype == torch.float16
+    assert r32 < TOL_LOSS and r16 < TOL_LOSS
+
+
+DIFFUSERS_GOLDEN = os.path.join(GOLDEN, "score_diffusers.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(DIFFUSERS_GOLDEN), reason="tests/golden/score_diffusers.npz absent: generate it "
+                    "with tests/make_golden_with_diffusers.py where diffusers 0.24 is installed (it is not in this image)")
+def test_against_real_diffusers_fixture(engine):
+    """Pins parity to the REAL dependency: inputs + outputs of diffusers' UNet2DConditionModel / scheduler.add_noise /
+    F.mse_loss under autocast, produced by tests/make_golden_with_diffusers.py from the same synthetic weights."""
+    g = np.load(DIFFUSERS_GOLDEN)
+    x, eps, t, c = (torch.from_numpy(g[k]) for k in ("x", "eps", "t", "c"))
+    nb, tb, cc, slots = _tile(eps, t, c)
+    engine.set_prompts(c)
+    loss = engine.score(x, nb, tb, slots, latent_dtype=torch.float32).cpu()
+    rl = U.rel_l2(loss, torch.from_numpy(g["loss_autocast_cuda"] if "loss_autocast_cuda" in g else g["loss_fp32_cpu"]))
+    print(f"vs diffusers {str(g['diffusers_version'])}: loss rel-L2 {rl:.2e}")
+    assert rl < TOL_LOSS
 
 
 def test_golden_fixture(engine):
@@ -107,13 +250,13 @@ def test_golden_fixture(engine):
     path = os.path.join(GOLDEN, "score_8x8.npz")
     g = np.load(path)
     x, eps, t, c = (torch.from_numpy(g[k]) for k in ("x", "eps", "t", "c"))
+    assert x.dtype == torch.float32 and eps.dtype == torch.float32
     nb, tb, cc, slots = _tile(eps, t, c)
     engine.set_prompts(c)
-    loss = engine.score(x, nb, tb, slots).cpu()
-    ref = torch.from_numpy(g["loss_autocast"])
-    rl = U.rel_l2(loss, ref)
-    print(f"golden 8x8 loss rel-L2 {rl:.2e}")
-    assert rl < 6e-3
+    rl32 = U.rel_l2(engine.score(x, nb, tb, slots).cpu(), torch.from_numpy(g["loss_autocast_f32flow"]))
+    rl16 = U.rel_l2(engine.score(x.half(), nb.half(), tb, slots).cpu(), torch.from_numpy(g["loss_autocast_f16flow"]))
+    print(f"golden 8x8 loss rel-L2: f32 flow {rl32:.2e}, f16 flow {rl16:.2e}")
+    assert rl32 < TOL_LOSS and rl16 < TOL_LOSS
     gd = np.load(os.path.join(GOLDEN, "dift_16x16.npz"))
     noisy, tt, pe = torch.from_numpy(gd["noisy"]), int(gd["t"]), torch.from_numpy(gd["prompt"])
     engine.set_prompts(pe)
@@ -150,13 +293,14 @@ def test_surface_compute_losses_and_reductions(engine, sd15_weights_torch):
     from diff_mining_amd.typicality import TypicalityScorer
     sc = TypicalityScorer(engine, seed=42, N=3, t_min=0.1, t_max=0.7)
     x, _, _, c = _inputs(8, 8, 1)
+    x = x.float()
     noises, ts = sc.draw(x.shape)
     n_ref, t_ref = R.draw_noise_and_timesteps(tuple(x.shape), 3, 0.1, 0.7, seed=42)
-    assert torch.equal(noises, n_ref) and torch.equal(ts, t_ref)          # same CPU-generator draws
+    assert noises.dtype == torch.float32 and torch.equal(noises, n_ref) and torch.equal(ts, t_ref)   # same CPU-generator draws
     grid = sc.compute_losses(x, c, noises=noises, timesteps=ts)
     assert grid.shape == (3, 2, 4, 8, 8) and grid.dtype == torch.float16 and grid.device.type == "cpu"
     ref = R.compute_losses(sd15_weights_torch, x, c.float(), noises, ts, B=3)
-    assert U.rel_l2(grid.float(), ref.float()) < 6e-3
+    assert U.rel_l2(grid.float(), ref.float()) < TOL_LOSS
     # compute_loss with a tiled c tensor (reference calling convention) gives the same numbers
     nb, tb, cc, _ = _tile(noises, ts, c)
     loss = sc.compute_loss(x, nb, tb, cc).cpu()
@@ -337,3 +481,76 @@ def test_chunked_calls_are_batch_independent(engine):
     a = engine.score_conds(x, eps, t, 2)
     b = engine.score(x, nb, tb, slots)
     assert a.shape == (200, 4, 64, 64) and torch.equal(a, b)
+
+
+def test_dift_descriptor_deviation_vs_fp32_oracle(engine, sd15_weights_torch):
+    """The reference's DIFT U-Net is fp32 (dift.py:197-199: no torch_dtype, no autocast); the engine is fp16 storage /
+    fp32 accumulate.  What that costs where it matters: the L2-normalised patch descriptors `cluster.py:291-299` feeds
+    KMeans, at 32x32 latents (256 px images), ensemble 2 — cosine between engine and fp32-oracle descriptors."""
+    from diff_mining_amd.dift import SDFeaturizer
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    h = w = 32
+    ens = 2
+    x, eps, _, c = _inputs(h, w, ens, flow="f32")
+    fz = SDFeaturizer(engine)
+    mean = fz.forward(x, c[:1], t=261, up_ft_index=1, ensemble_size=ens, noise=eps)          # [1,1280,16,16] fp32
+    noisy = R.add_noise(x.expand(ens, -1, -1, -1), eps, torch.tensor(261))                   # fp32, as the reference
+    _, mean_ref = R.dift_features(sd15_weights_torch, noisy, 261, c[:1].float().expand(ens, -1, -1), 1, autocast=False)
+    assert mean.shape == mean_ref.shape == (1, 1280, h // 2, w // 2)
+    image_hw = (h * 8, w * 8)
+    boxes = [(r, cc_, r + 64, cc_ + 64) for r in range(0, 256, 64) for cc_ in range(0, 256, 64)]       # 16 patches of 64 px
+    boxes += [(0, 0, 256, 256), (96, 96, 160, 160), (16, 48, 80, 112)]
+    d_eng = fz.patch_embeddings(mean, boxes, image_hw).cpu().double()
+    d_ref = torch.stack([torch.from_numpy(R.dift_patch_embedding(mean_ref[0].numpy().astype(np.float64), b, image_hw))
+                         for b in boxes])
+    cos = (d_eng * d_ref).sum(1)
+    rf = U.rel_l2(mean.cpu(), mean_ref)
+    print(f"DIFT fp16 engine vs fp32 oracle @32x32: feature-map rel-L2 {rf:.2e}; descriptor cosine min {cos.min():.7f} "
+          f"mean {cos.mean():.7f}; max |d_eng - d_ref| {(d_eng - d_ref).abs().max():.2e}")
+    assert rf < 4e-3
+    assert cos.min().item() > 1 - 2e-5
+    json.dump({"dift_descriptor_cos_min": cos.min().item(), "dift_feature_rel_l2": rf},
+              open(os.path.join(os.environ.get("GRAFT_OUT", "/tmp"), "dift_dev.json"), "w"))
+
+
+def test_dift_full_size_properties(engine):
+    """BASELINE configs[3] at full size — 8 latents x ensemble 8 = batch 64 @64x64, tap up_blocks[1] -> [64,1280,32,32]:
+    run-to-run determinism, batch-position invariance, ensemble mean == mean of the per-sample features."""
+    n_lat, ens, lat = 8, 8, 64
+    x, eps, _, c = _inputs(lat, lat, ens, n_img=n_lat, flow="f32")
+    a = float(R.alphas_cumprod()[161])
+    noisy = ((a ** 0.5) * x.repeat_interleave(ens, 0) + ((1 - a) ** 0.5) * eps.repeat(n_lat, 1, 1, 1)).half()
+    engine.set_prompts(c[:1])
+    slots = torch.zeros(n_lat * ens, dtype=torch.int32)
+    tt = torch.tensor(161)
+    feat, mean = engine.dift(noisy, tt, slots, 1, ens)
+    assert feat.shape == (64, 1280, 32, 32) and feat.dtype == torch.float16
+    assert mean.shape == (8, 1280, 32, 32) and mean.dtype == torch.float32
+    assert torch.isfinite(feat.float()).all() and torch.isfinite(mean).all()
+    feat2, mean2 = engine.dift(noisy, tt, slots, 1, ens)
+    assert torch.equal(feat, feat2) and torch.equal(mean, mean2)                       # deterministic
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(5))
+    featp, _ = engine.dift(noisy[perm], tt, slots, 1)
+    assert torch.equal(featp, feat[perm.to(feat.device)])                              # batch-position invariant
+    ref_mean = feat.float().view(n_lat, ens, 1280, 32, 32).mean(1)
+    torch.testing.assert_close(mean, ref_mean, atol=1e-6, rtol=1e-6)                   # ensemble mean of dift.py:231
+    one, _ = engine.dift(noisy[8:16], tt, slots[:8], 1)                                # a sample's features do not
+    assert torch.equal(one, feat[8:16])                                                # depend on the batch it rides in
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process")
+def test_two_engines_in_one_process(sd15_weights_f16):
+    """Kernel function attributes (dynamic LDS size) are per device: a second engine on another GPU of the same
+    process must set them again (r01 used a process-global flag)."""
+    from diff_mining_amd.engine import UNetEngine
+    x, eps, t, c = _inputs(16, 16, 2)
+    nb, tb, cc, slots = _tile(eps, t, c)
+    outs = []
+    for d in (0, 1):
+        e = UNetEngine(d)
+        e.load_state_dict(sd15_weights_f16)
+        e.set_prompts(c)
+        with torch.cuda.device(d):
+            outs.append(e.score(x, nb, tb, slots).cpu())
+        e.close()
+    assert torch.equal(outs[0], outs[1])

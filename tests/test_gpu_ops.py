@@ -280,3 +280,41 @@ def test_layernorm_folded_into_linear(M, C, Cout, epi):
     else:
         ref = h
     U.assert_close_fp16(y[rows.to(d)], ref, f"LN-folded linear epi={epi}", rel=3e-3, abs_frac=4e-3)
+
+
+@pytest.mark.parametrize("C1,C2,Cout", [(640, 0, 640), (1280, 640, 640), (1280, 0, 1280)])
+def test_igemm_conv3x3_big_tile_vs_conv2d(C1, C2, Cout):
+    """The 256 px x 320 ch tile on its 3x3-convolution shapes (>= 1024 big tiles, Cin >= 640: the 32x32 layers of
+    up_blocks[1..2] at the bench batch, 25 % of a step's GPU time), checked DIRECTLY against F.conv2d in fp32 on whole
+    sampled images (first / middle / last of the batch, so row tiles that straddle images are covered), with the
+    channel concat, the time-embedding add and the residual epilogue."""
+    from diff_mining_amd import engine as E
+    N, H, W = 160, 32, 32
+    lib = E.load_library()
+    assert lib.dm_op_igemm_tile(N * H * W, C1 + C2, Cout, 1) == 1, "shape is not routed to the 256x320 tile"
+    d = U.dev()
+    Cin = C1 + C2
+    g = torch.Generator(device="cuda").manual_seed(31)
+    x1 = torch.randn(N, H, W, C1, generator=g, device=d, dtype=torch.float32).half()
+    x2 = (torch.randn(N, H, W, C2, generator=g, device=d, dtype=torch.float32) * 0.5).half() if C2 else None
+    w = U.f16_randn(Cout, Cin, 3, 3, seed=32, scale=(9 * Cin) ** -0.5)
+    b = U.f16_randn(Cout, seed=33, scale=0.1)
+    temb = U.f16_randn(N, Cout, seed=34)
+    res = torch.randn(N, H, W, Cout, generator=g, device=d, dtype=torch.float32).half()
+    wg, bg = U.pack_conv3(w).to(d), b.to(d)
+    y_plain = U.op_igemm(x1, wg, bg, X2=x2, mode=1)
+    y_temb = U.op_igemm(x1, wg, bg, X2=x2, temb=temb.to(d), mode=1)
+    y_res = U.op_igemm(x1, wg, bg, X2=x2, res=res, mode=1)
+    for n in (0, 77, N - 1):
+        xin = x1[n:n + 1] if x2 is None else torch.cat([x1[n:n + 1], x2[n:n + 1]], 3)
+        ref = F.conv2d(U.to_nchw(xin.cpu().float()), w.float(), b.float(), padding=1)
+        U.assert_close_fp16(U.to_nchw(y_plain[n:n + 1]), ref, f"big conv3x3 n={n}")
+        U.assert_close_fp16(U.to_nchw(y_temb[n:n + 1]), ref.half().float() + temb[n].float()[None, :, None, None],
+                            f"big conv3x3+temb n={n}")
+        U.assert_close_fp16(U.to_nchw(y_res[n:n + 1]), ref.half().float() + U.to_nchw(res[n:n + 1].cpu().float()),
+                            f"big conv3x3+res n={n}")
+    # the 128-row tile on the same operands agrees to fp32 summation order (different k-step grouping)
+    small = U.op_igemm(x1[:8], wg, bg, X2=x2[:8] if C2 else None, mode=1)
+    assert lib.dm_op_igemm_tile(8 * H * W, Cin, Cout, 1) == 0
+    diff = (small.float() - y_plain[:8].float()).abs()
+    assert diff.max().item() <= 2e-3 * y_plain[:8].float().abs().max().item()

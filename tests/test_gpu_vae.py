@@ -237,7 +237,7 @@ def test_image_to_typicality_grid(vae_engine, vae_sd, sd15_weights_f16):
     usd = {k: torch.from_numpy(v).float() for k, v in sd15_weights_f16.items()}
     x_ref, _ = vae_ref.vae_encode(vsd, img.float(), vnoise.float(), autocast=True)
     noises, ts = sc.draw((1, 4, 8, 8))
-    ref = R.compute_losses(usd, x_ref.half(), c.float(), noises, ts, B=2)
+    ref = R.compute_losses(usd, x_ref, c.float(), noises, ts, B=2)        # fp32 latent, fp32 draws: the reference's flow
     assert U.rel_l2(grid, ref) < 8e-3
     # uint8 image path: load_image reproduces to_tensor(x) * 2 - 1
     u8 = ((img[0].permute(1, 2, 0).float().numpy() + 1) * 127.5).round().clip(0, 255).astype(np.uint8)
