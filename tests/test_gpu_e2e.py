@@ -27,12 +27,14 @@ from tests import gpu_util as U  # noqa: E402
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 FLOW = {"f32": (np.float32, torch.float32), "f16": (np.float16, torch.float16)}
 
-# asserted bounds (<= 2x the r02 measurements on MI355X; see the module docstring)
-TOL_EPS_HAT = 3e-3        # eps_hat rel-L2 vs autocast oracle and vs fp32 oracle
-TOL_LOSS = 3e-3           # loss grid rel-L2 vs autocast oracle
-TOL_T_MEANLOSS = 6e-4     # |dT| / mean loss, few draws
-TOL_T10_MEANLOSS = 3e-4   # |dT| / mean loss at N = 10 draws
-TOL_T10_REL = 1.5e-2      # |dT| / |T| at N = 10 draws
+# asserted bounds: each <= 2x the largest value measured on MI355X in r02 (gpurun_out/r02b/pytest.log)
+TOL_EPS_HAT = 3.0e-3      # eps_hat rel-L2 vs autocast oracle (measured <= 2.03e-3) and vs fp32 oracle (<= 1.61e-3)
+TOL_LOSS = 2.8e-3         # loss / grid rel-L2 vs autocast oracle (measured <= 1.41e-3)
+TOL_T_MEANLOSS = 4.7e-4   # |dT| / mean loss with 1-4 draws (measured <= 2.35e-4)
+TOL_T10_MEANLOSS = 9e-5   # |dT| / mean loss at N = 10 draws (measured <= 4.45e-5)
+TOL_T10_REL = 5.8e-3      # |dT| / |T| at N = 10 draws (measured <= 2.86e-3)
+TOL_C1_MEANLOSS = 1.2e-4  # config-1 substitute, 16 images x N = 2: max |dT| / mean loss (measured 5.9e-5)
+TOL_DIFT = 3.2e-3         # DIFT feature rel-L2 vs the fp32 oracle (measured <= 1.62e-3)
 
 
 @pytest.fixture(scope="module")
@@ -101,8 +103,8 @@ def test_unet_and_loss_vs_oracle(engine, sd15_weights_torch, h, w, n_draws, flow
 
 def test_dtype_flows_differ_as_the_oracle_says(engine, sd15_weights_torch):
     """The two flows are different computations (fp16-rounded sqrt(1 - acp) differs by up to 7 % at small t): the
-    engine's f32-vs-f16 difference must match the oracle's f32-vs-f16 difference, and at t = 0 the coefficient gap
-    (0.029155 vs 0.03125) must show."""
+    engine's f32-vs-f16 difference must match the oracle's f32-vs-f16 difference at small t, where the coefficient gap
+    (sqrt(1 - acp[0]) = 0.029155 vs 0.03125) is largest."""
     x, eps, t, c = _inputs(8, 8, 2, flow="f32")
     t = torch.tensor([0, 5])
     nb, tb, cc, slots = _tile(eps, t, c)
@@ -114,7 +116,8 @@ def test_dtype_flows_differ_as_the_oracle_says(engine, sd15_weights_torch):
     d_eng, d_ref = U.rel_l2(l32, l16), U.rel_l2(r32, r16)
     print(f"t in (0, 5): flow difference engine {d_eng:.2e} oracle {d_ref:.2e}; engine-vs-oracle f32 {U.rel_l2(l32, r32):.2e} "
           f"f16 {U.rel_l2(l16, r16):.2e}")
-    assert d_eng > 5e-3 and abs(d_eng - d_ref) < 0.25 * d_ref
+    # (measured r02: 2.1e-3 both — larger than the engine-vs-oracle distance of either flow, 1.3e-3)
+    assert d_eng > 1e-3 and abs(d_eng - d_ref) < 0.25 * d_ref
     assert U.rel_l2(l32, r32) < TOL_LOSS and U.rel_l2(l16, r16) < TOL_LOSS
 
 
@@ -203,7 +206,7 @@ def test_config1_substitute_cars_geometry(engine, sd15_weights_torch):
     print("                     T oracle", [round(v, 5) for v in T_ref.tolist()])
     print(f"                     max |dT|/mean-loss {dm.max():.2e}, rank agreement "
           f"{(T.argsort() == T_ref.argsort()).float().mean():.2f}")
-    assert dm.max().item() <= TOL_T_MEANLOSS
+    assert dm.max().item() <= TOL_C1_MEANLOSS
 
 
 def test_golden_grid_fixture(engine):
@@ -265,7 +268,7 @@ def test_golden_fixture(engine):
     rf = U.rel_l2(feat.float().cpu(), ref_ft)
     rm = U.rel_l2(mean.cpu(), ref_ft.mean(0, keepdim=True))
     print(f"golden dift feat rel-L2 {rf:.2e} mean rel-L2 {rm:.2e}")
-    assert feat.shape == ref_ft.shape and rf < 4e-3 and rm < 4e-3
+    assert feat.shape == ref_ft.shape and rf < TOL_DIFT and rm < TOL_DIFT
 
 
 def test_dift_vs_oracle(engine, sd15_weights_torch):
@@ -281,7 +284,7 @@ def test_dift_vs_oracle(engine, sd15_weights_torch):
     assert feat.shape == (ens, 1280, h // 2, w // 2) and mean.shape == (1, 1280, h // 2, w // 2)
     rf, rm = U.rel_l2(feat.float().cpu(), ft_ref), U.rel_l2(mean.cpu(), mean_ref)
     print(f"dift rel-L2 vs fp32 oracle: features {rf:.2e}, ensemble mean {rm:.2e}")
-    assert rf < 4e-3 and rm < 4e-3
+    assert rf < TOL_DIFT and rm < TOL_DIFT
     # up_ft_index 0 and 2 shapes
     f0, _ = engine.dift(noisy, torch.tensor(161), slots, 0)
     f2, _ = engine.dift(noisy, torch.tensor(161), slots, 2)
@@ -507,8 +510,8 @@ def test_dift_descriptor_deviation_vs_fp32_oracle(engine, sd15_weights_torch):
     rf = U.rel_l2(mean.cpu(), mean_ref)
     print(f"DIFT fp16 engine vs fp32 oracle @32x32: feature-map rel-L2 {rf:.2e}; descriptor cosine min {cos.min():.7f} "
           f"mean {cos.mean():.7f}; max |d_eng - d_ref| {(d_eng - d_ref).abs().max():.2e}")
-    assert rf < 4e-3
-    assert cos.min().item() > 1 - 2e-5
+    assert rf < TOL_DIFT                                   # measured 1.21e-3
+    assert cos.min().item() > 1 - 1e-6                     # measured 1 - 5e-7
     json.dump({"dift_descriptor_cos_min": cos.min().item(), "dift_feature_rel_l2": rf},
               open(os.path.join(os.environ.get("GRAFT_OUT", "/tmp"), "dift_dev.json"), "w"))
 

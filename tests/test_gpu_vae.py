@@ -136,7 +136,8 @@ def test_vae_encode_matches_oracle(vae_engine, vae_sd, B, H, W):
     r_ac, r_32 = U.rel_l2(mom, ref_mom), U.rel_l2(mom, ref32_mom)
     base = U.rel_l2(ref_mom, ref32_mom)
     print(f"vae {B}x{H}x{W}: moments rel-L2 vs autocast-oracle {r_ac:.2e}, vs fp32 {r_32:.2e}; oracle ac-vs-fp32 {base:.2e}")
-    assert r_ac < 4e-3 and r_32 < 4e-3
+    assert r_ac < 3e-3 and r_32 < 2.7e-3            # measured (r02) <= 1.53e-3 / 1.36e-3
+    print(f"vae latents rel-L2 {U.rel_l2(lat, ref_lat):.2e}")
     assert U.rel_l2(lat, ref_lat) < 4e-3
     # posterior mode = mean * scaling
     mode = vae_engine.vae_encode(img, None, out_dtype=torch.float32)
@@ -150,6 +151,7 @@ def test_vae_golden(vae_engine):
     g = np.load(os.path.join(GOLDEN, "vae_64x64.npz"))
     img, noise = torch.from_numpy(g["image"]), torch.from_numpy(g["noise"])
     lat, mom = vae_engine.vae_encode(img, noise, return_moments=True, out_dtype=torch.float32)
+    print(f"vae golden: moments {U.rel_l2(mom, torch.from_numpy(g['moments'])):.2e} latents {U.rel_l2(lat, torch.from_numpy(g['latents'])):.2e}")
     assert U.rel_l2(mom, torch.from_numpy(g["moments"])) < 4e-3
     assert U.rel_l2(lat, torch.from_numpy(g["latents"])) < 4e-3
 
@@ -238,6 +240,7 @@ def test_image_to_typicality_grid(vae_engine, vae_sd, sd15_weights_f16):
     x_ref, _ = vae_ref.vae_encode(vsd, img.float(), vnoise.float(), autocast=True)
     noises, ts = sc.draw((1, 4, 8, 8))
     ref = R.compute_losses(usd, x_ref, c.float(), noises, ts, B=2)        # fp32 latent, fp32 draws: the reference's flow
+    print(f"image -> grid rel-L2 {U.rel_l2(grid, ref):.2e}")
     assert U.rel_l2(grid, ref) < 8e-3
     # uint8 image path: load_image reproduces to_tensor(x) * 2 - 1
     u8 = ((img[0].permute(1, 2, 0).float().numpy() + 1) * 127.5).round().clip(0, 255).astype(np.uint8)
@@ -284,4 +287,5 @@ def test_dift_from_pixels(vae_engine, vae_sd, sd15_weights_f16):
     noisy = R.add_noise(lat, noise, torch.tensor(161))
     ft, _ = R.dift_features(usd, noisy.half().float(), 161, prompt.float().expand(ens, -1, -1), 1)
     ref = ft.mean(0, keepdim=True)
+    print(f"dift from pixels rel-L2 {U.rel_l2(got, ref):.2e}")
     assert U.rel_l2(got, ref) < 6e-3, U.rel_l2(got, ref)
