@@ -354,8 +354,7 @@ bool attention_pipe_supports(const AttnParams& p);
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.Tq <= 0 || p.Tk <= 0 || p.B <= 0) return hipErrorInvalidValue;
     // long head_dim-40 self-attention: software-pipelined variant (DM_ATTN_PIPE=0 disables)
-    static int pipe = -1;
-    if (pipe < 0) { const char* e = getenv("DM_ATTN_PIPE"); pipe = e ? atoi(e) : 1; }
+    const int pipe = option(OPT_ATTN_PIPE);
     if (pipe && attention_pipe_supports(p)) return launch_attention_pipe(p, s);
     switch (p.D) {
         case 40: return launch_t<40, 2>(p, s);

@@ -19,6 +19,12 @@ inline bool first_use_on_device(std::atomic<uint64_t>& seen) {
     return (seen.fetch_or(bit) & bit) == 0;
 }
 
+// Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of
+// the same name in upper case with a DM_ prefix (DM_IGEMM_PERSIST=0 ...), changeable through dm_set_option().
+enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_PERSIST, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_COUNT };
+int option(Option o);                       // engine.hip
+int set_option(const char* name, int value);   // 0 on success
+
 // ---- K1/K2/K3: implicit-GEMM on MFMA (conv3x3 s1/s2/upsampled, 1x1 conv, linear) -------------
 enum IGemmMode { IG_DENSE = 0, IG_CONV3 = 1, IG_CONV3_S2 = 2, IG_CONV3_UP = 3, IG_CONV3_S2P0 = 4 };
 enum IGemmEpi { EPI_PLAIN = 0, EPI_GEGLU = 1 };
@@ -53,6 +59,18 @@ hipError_t launch_igemm(const IGemmParams& p, hipStream_t s);
 // the caller provides the workspace
 int igemm_splitk_parts(const IGemmParams& p, int spatial);
 int igemm_tile_choice(const IGemmParams& p);     // 0 = 128-row tile, 1 = 256 x 320 tile
+// shapes the persistent form of the 256 x 320 tile (igemm_pers_tile.h) takes; otherwise the one-tile-per-block kernel
+// of igemm_big_tile.h runs (bit-identical results): >= 4 k steps, a time embedding only when every 256-row tile lies
+// inside one sample, never a time embedding and a residual together
+inline bool igemm_pers_ok(const IGemmParams& p) {
+    const int nk = ((p.mode == IG_DENSE) ? 1 : 9) * (p.Cin / 64);
+    if (nk < 4 || p.Cout % 320 != 0 || p.M < 2) return false;
+    if (p.mode != IG_DENSE && (p.OH > 511 || p.OW > 511 || p.M / (p.OH * p.OW) > 8191)) return false;      // packed row coordinates
+    if (p.temb && (p.res || p.epi == EPI_GEGLU || p.ln_stats || (p.OH * p.OW) % 256 != 0)) return false;
+    if (p.res && (p.epi == EPI_GEGLU || p.ln_stats)) return false;
+    if (p.ln_stats && (p.M & 1)) return false;
+    return true;
+}
 
 // ---- K4/K5: flash attention (self and cross), head_dim 40/80/160 ------------------------------
 struct AttnParams {

@@ -545,9 +545,7 @@ struct Fwd {
         return rc;
     }
     static bool ln_fold_enabled() {
-        static int on = -1;
-        if (on < 0) { const char* ev = getenv("DM_LN_FOLD"); on = ev ? atoi(ev) : 1; }
-        return on != 0;
+        return option(OPT_LN_FOLD) != 0;
     }
     int layernorm(const NormW& nw, const Tensor& x, Tensor* y) {
         DM_TRY(alloc(y, x.N, x.H, x.W, x.C));
@@ -971,6 +969,36 @@ int max_chunk(int h, int w) {
 }
 
 }  // namespace
+
+namespace dm {
+
+namespace {
+struct OptDef { const char* name; const char* env; int def; };
+const OptDef kOpts[OPT_COUNT] = {
+    {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_persist", "DM_IGEMM_PERSIST", 1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
+    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1},
+};
+std::atomic<int> g_opt[OPT_COUNT];
+std::atomic<int> g_opt_init{0};
+void opts_init() {
+    if (g_opt_init.load() == 2) return;
+    int expect = 0;
+    if (g_opt_init.compare_exchange_strong(expect, 1)) {
+        for (int i = 0; i < OPT_COUNT; ++i) { const char* e = getenv(kOpts[i].env); g_opt[i] = e ? atoi(e) : kOpts[i].def; }
+        g_opt_init = 2;
+    } else while (g_opt_init.load() != 2) {}
+}
+}  // namespace
+
+int option(Option o) { opts_init(); return g_opt[o].load(std::memory_order_relaxed); }
+int set_option(const char* name, int value) {
+    opts_init();
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (name && !strcmp(name, kOpts[i].name)) { g_opt[i] = value; return 0; }
+    return 1;
+}
+
+}  // namespace dm
 
 // ================================================================================================
 // C ABI
@@ -1672,6 +1700,8 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
     else { p.M = N * OH * OW; p.H = H; p.W = W; p.OH = OH; p.OW = OW; }
     return launch_igemm(p, (hipStream_t)stream) == hipSuccess ? 0 : 1;
 }
+
+int dm_set_option(const char* name, int value) { return dm::set_option(name, value); }
 
 int dm_op_igemm_tile(int M, int Cin, int Cout, int mode) {
     IGemmParams p{};

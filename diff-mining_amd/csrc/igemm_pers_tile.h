@@ -1,20 +1,19 @@
 // igemm_pers_tile.h — persistent form of the 256 px x 320 ch implicit-GEMM tile (formulation, operand layout and
 // swizzle: igemm.hip).  One block per CU walks a strided list of tiles; the k loop is continuous across tiles:
 //
-//   * while the last k step of tile i runs, the LDS-DMA of tile i+1's first k step goes into the other stage, and
-//     right after it (one barrier) the second k step goes into the stage just consumed — the epilogue below needs
-//     no LDS, so both stages prefetch under it: no prologue bubble per tile (≈ 4-5 k cycles of 20-50 k for the
-//     K = 320..1280 linears);
+//   * while the last k step of tile i runs, the LDS-DMA of tile i+1's first k step goes into the other stage (the
+//     stream of "compute stage s, fetch the next k tile into stage s^1" simply continues into the next tile): no
+//     prologue bubble per tile (≈ 4-5 k cycles of 20-50 k for the K = 320..1280 linears), and one loop body;
 //   * the epilogue writes straight from the accumulators.  A lane of the MFMA C layout holds 4 consecutive
 //     channels of one pixel per 16x16 block (8 B after fp16 packing); v_permlane16_swap + v_permlane32_swap
 //     transpose the four lane groups against four channel blocks, after which a lane holds 16 consecutive
 //     channels of its pixel = two 16-byte stores (the store tail is issue-bound per instruction, not per byte).
 //     No staging pass, no epilogue barriers; the residual is read in the same layout, one unit ahead of the
 //     stores (vmcnt retires in order: a load queued behind stores would wait for them);
-//   * the stores are never waited for inside the epilogue: the next tile's first two k steps were fetched BEFORE
-//     them, so `s_waitcnt vmcnt(<stores per wave>)` at the top of the next tile proves the operands landed while
-//     the stores drain under two k steps.  For the count to be exact every wave issues every store: rows beyond M
-//     are redirected to a sink page instead of being predicated off;
+//   * the stores are never waited for inside the epilogue: the next tile's first k step was fetched BEFORE them, so
+//     `s_waitcnt vmcnt(<stores per wave>)` at the top of the next tile proves the operands landed while the stores
+//     drain under that k step.  For the count to be exact every wave issues every store: rows beyond M are
+//     redirected to a sink page instead of being predicated off;
 //   * bias / time-embedding row / folded-LayerNorm vectors of a tile reach LDS by LDS-DMA too (double-buffered
 //     8 KB slots behind the stages), issued with the prefetch of the tile that needs them.
 //
@@ -57,10 +56,25 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page_pers[1024];
-__device__ __attribute__((aligned(256))) unsigned char g_store_sink[8 * 64 * 16];      // one 16-byte slot per (wave, lane)
+__device__ __attribute__((aligned(256))) unsigned char g_store_sink[16 * 64 * 16];     // one 16-byte slot per (wave, lane)
+// Dynamic tile hand-out: one counter per XCD (its blocks share an L2, so an XCD keeps its contiguous tile range) +
+// one completion counter; the last block to finish resets them for the next launch (launches are stream-ordered and
+// an engine is single-stream; __device__ storage is per device).  Static striding lost 3-5 % to the slowest CU.
+__device__ int g_tile_ctr[8 * 32];            // [xcd * 32] (128 bytes apart)
+__device__ int g_tile_done;
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Lane id straight from the hardware.  `asm volatile` on purpose: the k loop runs at 256 registers, and any per-lane
+// constant derived once at kernel entry is either kept live across it or spilled — and a spill reload waits on
+// vmcnt, i.e. behind the LDS-DMA in flight and the previous tile's stores.  Re-deriving the handful of lane
+// constants where they are used costs a few VALU instructions per k step instead.
+__device__ __forceinline__ int hw_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 
 __device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {      // a.row1 <-> b.row0, a.row3 <-> b.row2 (rows of 16 lanes)
     const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
@@ -83,103 +97,131 @@ __device__ __forceinline__ void transpose4(unsigned (&R)[4][NWD]) {
 // LDS slot of a tile's per-channel / per-row vectors (filled by LDS-DMA, 1 KiB pieces)
 constexpr int AUX_BIAS = 0, AUX_TEMB = 1024, AUX_LNS = 2048, AUX_LNT = 4096, AUX_STATS = 6144, AUX_BYTES = 8192;
 
-template <int EPI, bool LN>
-__global__ __launch_bounds__(512, 2)
+// EXTRA: 0 = bias only, 1 = + time-embedding row (every tile inside one sample: OHW % 256 == 0), 2 = + residual.
+// Compile-time, because runtime-optional loads in the epilogue make the compiler place their `s_waitcnt vmcnt` on the
+// common path, where they wait for the prefetched LDS-DMA and the previous stores instead.
+enum { PX_NONE = 0, PX_TEMB = 1, PX_RES = 2 };
+
+// NW = waves per block: 8 (2 per SIMD, wave tile 64 px x 160 ch in two 80-channel halves, <= 256 registers) is what ships.
+// NW = 16 (4 per SIMD, wave tile 64 px x 80 ch, streamed fragments, <= 128 registers; same block tile, LDS image and
+// arithmetic) was built to test whether more issuing waves speed up the L2 -> LDS feed (tools/probes/probe_feed.hip: a CU
+// pulls 33 B/clk with 8 waves issuing and 47 B/clk with 16; the k step needs 29 at the MFMA rate): bit-identical, but
+// 1-5 % SLOWER on 14 of 17 U-Net shapes (r02, tools/ab_igemm.py) — the feed is not what a second pair of waves fixes.
+// The template parameter stays so the experiment can be re-run; only NW = 8 is instantiated.
+template <int EPI, bool LN, int EXTRA, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4)
 void igemm_pers_kernel(IGemmParams p, int ntiles) {
-    constexpr int WC = 2, CH = 2, NW = 8;
+    constexpr int WC = (NW == 16) ? 4 : 2, CH = (NW == 16) ? 1 : 2;
     constexpr int TP = 256, TC = 320;
     constexpr int WBYTES = TC * 128, XBYTES = TP * 128, STAGE = WBYTES + XBYTES;
-    constexpr int WI = TC / 8 / NW, XI = TP / 8 / NW;          // 5 + 4 LDS-DMA pieces per wave per k step
+    // LDS-DMA pieces (8 rows x 128 B) per wave per k step: 40 weight pieces (NW = 16: three slots, the third only on waves
+    // 0..7) + 32 activation pieces
+    constexpr int WI = (TC / 8 + NW - 1) / NW, XI = TP / 8 / NW;
     constexpr int NL = WI + XI;
     // stores per wave per tile (every wave issues all of them: rows beyond M go to the sink page)
-    constexpr int NSTORE = (EPI == EPI_GEGLU) ? 16 : 24;
+    constexpr int NSTORE = ((EPI == EPI_GEGLU) ? 8 : 12) * CH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const aux0 = smem + 2 * STAGE;
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wc = wid % WC;
     const int wp = wid / WC;
 
     // ---- this block's tiles: XCD x (= block % 8) owns a contiguous range; its blocks stride through it ----------
     const int tiles_c = p.Cout / TC;
-    int tile, tend, tstride;
+    // the first tile of a block is static (tstart + its index on the XCD); further ones come from the XCD's counter
+    int tile, tend, tdyn;
+    const int xcd = blockIdx.x & 7;
     {
         const int nblk = gridDim.x;
-        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        const int loc = blockIdx.x >> 3;
         const int q = ntiles >> 3, r = ntiles & 7;
         const int tstart = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
         tend = tstart + q + (xcd < r ? 1 : 0);
-        tstride = (nblk - xcd + 7) >> 3;
+        tdyn = tstart + ((nblk - xcd + 7) >> 3);       // first dynamically handed-out tile of this XCD
         tile = tstart + loc;
     }
-    if (tile >= tend) return;
+    auto finish = [&]() __attribute__((always_inline)) {
+        if (threadIdx.x == 0) {
+            if (atomicAdd(&g_tile_done, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) g_tile_ctr[x * 32] = 0;
+                g_tile_done = 0;
+                __threadfence();
+            }
+        }
+    };
+    if (tile >= tend) { finish(); return; }
 
     const int C1 = p.C1;
     const int C2 = p.Cin - C1;
     const int ntaps = (p.mode == IG_DENSE) ? 1 : 9;
     const int cpt = p.Cin / BK;
-    const int nk = ntaps * cpt;                                  // >= 3 (launcher)
+    const int nk = ntaps * cpt;                                  // >= 4 (igemm_pers_ok)
     const int Ktot = ntaps * p.Cin;
     const int OHW = p.OH * p.OW;
-    const bool temb_lds = p.temb && (OHW % TP == 0);             // a tile lies inside one sample: its temb row goes through LDS
+    constexpr bool temb_lds = (EXTRA == PX_TEMB);                // a tile lies inside one sample: its temb row goes through LDS
 
-    const int lrow = lane >> 3;
-    const int lchunk = ((lane & 7) ^ lrow) * 8;
-    const f16* zero = reinterpret_cast<const f16*>(g_zero_page_pers) + lchunk;
 
     // ---- load-side state of the tile whose operands are being fetched ---------------------------------------------
+    // (kept minimal: the k loop runs at 256 registers; the pixel coordinates of a lane's rows are re-derived from the
+    // row index at every tap change instead of being held)
     int lp0 = 0, lc0 = 0;
-    int xohw[XI], xnb[XI], xoff[XI];
+    // xpk: sample << 18 | oh << 9 | ow of this lane's activation rows, -1 beyond M (n < 8192, oh / ow < 512); held in
+    // registers by the 8-wave form only, re-derived from the row index at every tap change by the 16-wave form (128 registers)
+    constexpr bool KEEP_XPK = (NW == 8);
+    int xpk[KEEP_XPK ? XI : 1], xoff[XI];
     unsigned woff = 0;
     const unsigned wstride = (unsigned)(NW * 8) * (unsigned)Ktot;
     const f16* xbase = p.X;
     int ld_tap = 0, ld_cc = 0;
-    const float sh = (float)p.H / (float)p.OH;
-    const float sw = (float)p.W / (float)p.OW;
 
+    auto pack_row = [&](int m) __attribute__((always_inline)) -> int {
+        if (m >= p.M) return -1;
+        if (p.mode == IG_DENSE) return m;
+        const int n = m / OHW;
+        const int rem = m - n * OHW;
+        const int oh = rem / p.OW;
+        return (n << 18) | (oh << 9) | (rem - oh * p.OW);
+    };
     auto set_tile = [&](int tl) __attribute__((always_inline)) {
         const int pt = tl / tiles_c;
         lp0 = pt * TP;
         lc0 = (tl - pt * tiles_c) * TC;
-#pragma unroll
-        for (int k = 0; k < XI; ++k) {
-            const int m = lp0 + (wid + k * NW) * 8 + lrow;
-            if (m < p.M) {
-                if (p.mode == IG_DENSE) { xohw[k] = 0; xnb[k] = m; }
-                else {
-                    const int n = m / OHW;
-                    const int rem = m - n * OHW;
-                    const int oh = rem / p.OW;
-                    xohw[k] = (oh << 16) | (rem - oh * p.OW);
-                    xnb[k] = n * p.H * p.W;
-                }
-            } else { xohw[k] = -1; xnb[k] = 0; }
-        }
+        const int ln = hw_lane();
+        const int lrow = ln >> 3, lchunk = ((ln & 7) ^ lrow) * 8;
         woff = (unsigned)((size_t)(lc0 + wid * 8 + lrow) * Ktot + lchunk);
         ld_tap = 0; ld_cc = 0;
+        if (KEEP_XPK) {
+#pragma unroll
+            for (int k = 0; k < XI; ++k) xpk[k] = pack_row(lp0 + (wid + k * NW) * 8 + lrow);
+        }
     };
-    auto src_pixel = [&](int k, int dy, int dx) __attribute__((always_inline)) -> int {
-        if (xohw[k] < 0) return -1;
-        const int oh = xohw[k] >> 16, ow = xohw[k] & 0xffff;
-        if (p.mode == IG_DENSE) return xnb[k];
+    auto src_pixel = [&](int k, int dy, int dx, int lrow) __attribute__((always_inline)) -> int {
+        const int pk = KEEP_XPK ? xpk[KEEP_XPK ? k : 0] : pack_row(lp0 + (wid + k * NW) * 8 + lrow);
+        if (pk < 0) return -1;
+        if (p.mode == IG_DENSE) return pk;
+        const int oh = (pk >> 9) & 511, ow = pk & 511;
+        const int xnb = (pk >> 18) * (p.H * p.W);
         if (p.mode == IG_CONV3 || p.mode == IG_CONV3_S2) {
             const int st = (p.mode == IG_CONV3_S2) ? 2 : 1;
             const int ih = oh * st + dy - 1, iw = ow * st + dx - 1;
-            return (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) ? xnb[k] + ih * p.W + iw : -1;
+            return (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) ? xnb + ih * p.W + iw : -1;
         }
         const int uh = oh + dy - 1, uw = ow + dx - 1;              // conv on the nearest-upsampled image
         if (uh < 0 || uh >= p.OH || uw < 0 || uw >= p.OW) return -1;
+        const float sh = (float)p.H / (float)p.OH, sw = (float)p.W / (float)p.OW;
         int ih = (int)floorf((float)uh * sh); ih = ih < p.H - 1 ? ih : p.H - 1;
         int iw = (int)floorf((float)uw * sw); iw = iw < p.W - 1 ? iw : p.W - 1;
-        return xnb[k] + ih * p.W + iw;
+        return xnb + ih * p.W + iw;
     };
     auto set_src = [&](int tap, int cs) __attribute__((always_inline)) {
         const int dy = tap / 3, dx = tap - dy * 3;
+        const int ln = hw_lane();
+        const int lrow = ln >> 3, lchunk = ((ln & 7) ^ lrow) * 8;
 #pragma unroll
         for (int k = 0; k < XI; ++k) {
-            const int pix = src_pixel(k, dy, dx);
+            const int pix = src_pixel(k, dy, dx, lrow);
             xoff[k] = (pix >= 0) ? (pix * cs + lchunk) : -1;
         }
     };
@@ -188,16 +230,18 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
         else if (ld_cc * BK == C1) { xbase = p.X2; set_src(ld_tap, C2); }
         if (++ld_cc == cpt) { ld_cc = 0; ++ld_tap; }
     };
-    auto load_piece = [&](int buf, int idx) __attribute__((always_inline)) {   // idx in [0, NL): W pieces, then X
+    auto load_piece = [&](int buf, int idx, int lchunk) __attribute__((always_inline)) {   // idx in [0, NL): W pieces, then X
         char* wt = smem + buf * STAGE;
         if (idx < WI) {
-            lptr_t dst = (lptr_t)(wt + (wid + idx * NW) * 1024);
-            __builtin_amdgcn_global_load_lds((gptr_t)(p.Wp + (size_t)(woff + (unsigned)idx * wstride)), dst, 16, 0, 0);
+            if (TC / 8 % NW == 0 || wid + idx * NW < TC / 8) {
+                lptr_t dst = (lptr_t)(wt + (wid + idx * NW) * 1024);
+                __builtin_amdgcn_global_load_lds((gptr_t)(p.Wp + (size_t)(woff + (unsigned)idx * wstride)), dst, 16, 0, 0);
+            }
             if (idx == WI - 1) woff += BK;
         } else {
             const int k = idx - WI;
             lptr_t dst = (lptr_t)(wt + WBYTES + (wid + k * NW) * 1024);
-            const f16* a = (xoff[k] >= 0) ? (xbase + (size_t)(unsigned)xoff[k]) : zero;
+            const f16* a = (xoff[k] >= 0) ? (xbase + (size_t)(unsigned)xoff[k]) : reinterpret_cast<const f16*>(g_zero_page_pers) + lchunk;
             __builtin_amdgcn_global_load_lds((gptr_t)a, dst, 16, 0, 0);
             if (xoff[k] >= 0) xoff[k] += BK;
         }
@@ -205,6 +249,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
     // per-tile vectors -> LDS slot by LDS-DMA (lane-linear 1 KiB pieces; lanes past the vector read the zero page)
     auto load_aux = [&](int slot) __attribute__((always_inline)) {
         char* ax = aux0 + slot * AUX_BYTES;
+        const int lane = hw_lane();
         const char* zp = reinterpret_cast<const char*>(g_zero_page_pers) + lane * 16;
         if (wid == 0) {
             const char* s = (p.bias && lane < TC / 8) ? reinterpret_cast<const char*>(p.bias + lc0) + lane * 16 : zp;
@@ -233,22 +278,48 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
     };
 
     floatx4 acc[CH][5][4];
-    const int l15 = lane & 15;
-    const int lg = lane >> 4;
-    const int a_row_off = (wc * 80 * CH + l15) * 128;
-    const int b_row_off = (wp * 64 + l15) * 128;
-    const int koff0 = ((lg ^ (l15 & 7)) << 4), koff1 = (((4 + lg) ^ (l15 & 7)) << 4);
 
-    // one k step on stage `cur`; issue == 1: LDS-DMA of the following k tile into the other stage, interleaved
-    auto step = [&](int cur, bool issue) __attribute__((always_inline)) {
+    // one k step on stage `cur`, with the LDS-DMA of the following k tile of the stream into the other stage interleaved
+    // (its sources were prepared after the previous step's MFMAs, when no fragment registers are live: the address
+    // arithmetic of a tap change needs ~20 temporaries)
+    auto step = [&](int cur) __attribute__((always_inline)) {
         const char* wt = smem + cur * STAGE;
         const char* xt = wt + WBYTES;
+        const int ln = hw_lane();
+        const int l15 = ln & 15, lg = ln >> 4;
+        const int a_row_off = (wc * 80 * CH + l15) * 128;
+        const int b_row_off = (wp * 64 + l15) * 128;
+        const int koff0 = ((lg ^ (l15 & 7)) << 4), koff1 = (((4 + lg) ^ (l15 & 7)) << 4);
+        const int lchunk = ((ln & 7) ^ (ln >> 3)) * 8;
+        if constexpr (CH == 1) {
+            // 16 waves x (64 px x 80 ch) at <= 128 registers: the five channel fragments of a k half stay resident, the
+            // four pixel fragments stream through two registers sets (pixel block j outer, channel block i inner); the
+            // other three waves of the SIMD cover the LDS latency.  Each accumulator still sees k half 0, then k half 1 of
+            // every k step: the same update sequence as the 8-wave form (bit-identical results).
+            half8 a[5], bj[2];
+            int piece = 0;
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                const int ko = sidx ? koff1 : koff0;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) a[i] = *reinterpret_cast<const half8*>(wt + a_row_off + i * 2048 + ko);
+                bj[0] = *reinterpret_cast<const half8*>(xt + b_row_off + ko);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j + 1 < 4) bj[(j + 1) & 1] = *reinterpret_cast<const half8*>(xt + b_row_off + (j + 1) * 2048 + ko);
+#pragma unroll
+                    for (int i = 0; i < 5; ++i)
+                        acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bj[j & 1], acc[0][i][j], 0, 0, 0);
+                    if (piece < NL) { load_piece(cur ^ 1, piece, lchunk); ++piece; }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
         half8 b0[4], b1[4], a[5];
 #pragma unroll
         for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const half8*>(xt + b_row_off + j * 2048 + koff0);
 #pragma unroll
         for (int i = 0; i < 5; ++i) a[i] = *reinterpret_cast<const half8*>(wt + a_row_off + i * 2048 + koff0);
-        if (issue) prepare();
         int piece = 0;
 #pragma unroll
         for (int q = 0; q < 2 * CH; ++q) {
@@ -266,10 +337,13 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
                     const int nq = q + 1, ns = nq / CH, nh = nq % CH;
                     a[i] = *reinterpret_cast<const half8*>(wt + a_row_off + nh * (80 * 128) + i * 2048 + (ns ? koff1 : koff0));
                 }
-                const int g = q * 5 + i;
-                if (issue && (g & 1) == 0 && piece < NL) { load_piece(cur ^ 1, piece); ++piece; }
+                // two LDS-DMA pieces per group: all nine out within the first quarter of the step (measured against one
+                // piece per group / per other group: best by 0-7 % per shape; the later the last piece, the longer the wait)
+                if (piece < NL) { load_piece(cur ^ 1, piece, lchunk); ++piece; }
+                if (piece < NL) { load_piece(cur ^ 1, piece, lchunk); ++piece; }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
         }
     };
 
@@ -277,62 +351,54 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
     auto epilogue = [&](int p0, int c0out, int slot) __attribute__((always_inline)) {
         const char* ax = aux0 + slot * AUX_BYTES;
         constexpr int OCH = (EPI == EPI_GEGLU) ? 40 : 80;          // output channels of one (wave, h) sub-tile
+        constexpr bool RES = (EXTRA == PX_RES);
         const int c0o = (EPI == EPI_GEGLU) ? c0out / 2 : c0out;
-        f16* const sink = reinterpret_cast<f16*>(g_store_sink) + (wid * 64 + lane) * 8;
-        // residual of unit u = (h, j), in the layout of the stores: 16 channels of block lg (two half8) + block 4's quarter
+        // the lane id is re-read from the hardware inside every epilogue: anything derived from the kernel-wide `lane`
+        // is hoisted out of the tile loop by the compiler and then lives (or spills) across the k loop, which runs
+        // at 256 registers; a spill reload here would also sit behind the LDS-DMA just issued (vmcnt is in-order)
+        const int eln = hw_lane();
+        const int e15 = eln & 15, eg = eln >> 4;
+        f16* const sink = reinterpret_cast<f16*>(g_store_sink) + (wid * 64 + eln) * 8;
+        // residual of unit u = (h, j) in the layout of the stores: 16 channels of block eg (two half8) + block 4's quarter
         half8 rlo, rhi; half4 r4;
-        auto load_res = [&](int h, int j) __attribute__((always_inline)) {
-            int m = p0 + wp * 64 + 16 * j + l15;
+        auto load_res = [&](int u) __attribute__((always_inline)) {
+            const int h = u >> 2, j = u & 3;
+            int m = p0 + wp * 64 + 16 * j + e15;
             m = m < p.M ? m : p.M - 1;
             const f16* rp = p.res + (size_t)m * p.ldres + c0o + wc * (OCH * CH) + h * OCH;
-            rlo = *reinterpret_cast<const half8*>(rp + 16 * lg);
-            rhi = *reinterpret_cast<const half8*>(rp + 16 * lg + 8);
-            r4 = *reinterpret_cast<const half4*>(rp + 64 + 4 * lg);
+            rlo = *reinterpret_cast<const half8*>(rp + 16 * eg);
+            rhi = *reinterpret_cast<const half8*>(rp + 16 * eg + 8);
+            r4 = *reinterpret_cast<const half4*>(rp + 64 + 4 * eg);
         };
-        const bool has_res = (EPI != EPI_GEGLU) && p.res;
-        if (has_res) load_res(0, 0);
+        if (RES) load_res(0);
 #pragma unroll
         for (int h = 0; h < CH; ++h) {
-            float bz[5][4], sz[LN ? 5 : 1][4];
-            half4 tv[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int ct = wc * 80 * CH + h * 80 + 16 * i + 4 * lg;          // tile-local GEMM channel
-                if (LN) {
-                    const floatx4 t4 = *reinterpret_cast<const floatx4*>(ax + AUX_LNT + ct * 4);
-                    const floatx4 s4 = *reinterpret_cast<const floatx4*>(ax + AUX_LNS + ct * 4);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { bz[i][r] = t4[r]; sz[i][r] = s4[r]; }
-                } else {
-                    const half4 bv = *reinterpret_cast<const half4*>(ax + AUX_BIAS + ct * 2);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bz[i][r] = (float)bv[r];
-                }
-                if (EPI != EPI_GEGLU && temb_lds) tv[i] = *reinterpret_cast<const half4*>(ax + AUX_TEMB + ct * 2);
-            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int pr = wp * 64 + 16 * j + l15;
+                const int u = h * 4 + j;
+                const int pr = wp * 64 + 16 * j + e15;
                 const int m = p0 + pr;
                 float mu = 0.f, rs = 1.f;
                 if (LN) {
                     const float2 st = *reinterpret_cast<const float2*>(ax + AUX_STATS + pr * 8);
                     mu = st.x; rs = st.y;
                 }
-                if (EPI != EPI_GEGLU && p.temb && !temb_lds) {          // tile straddles samples: per-row time-embedding loads
-                    const int n = (m < p.M) ? (m / OHW) : 0;
-                    const f16* tp = p.temb + (size_t)n * p.temb_ld + c0out + wc * 80 * CH + h * 80 + 4 * lg;
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) tv[i] = *reinterpret_cast<const half4*>(tp + 16 * i);
-                }
                 constexpr int NWD = (EPI == EPI_GEGLU) ? 1 : 2;
                 unsigned R[4][NWD], R4[NWD];
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
+                    const int ct = wc * 80 * CH + h * 80 + 16 * i + 4 * eg;          // tile-local GEMM channel
                     float v[4];
+                    if (LN) {
+                        const floatx4 t4 = *reinterpret_cast<const floatx4*>(ax + AUX_LNT + ct * 4);
+                        const floatx4 s4 = *reinterpret_cast<const floatx4*>(ax + AUX_LNS + ct * 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        v[r] = LN ? rs * (acc[h][i][j][r] - mu * sz[i][r]) + bz[i][r] : acc[h][i][j][r] + bz[i][r];
+                        for (int r = 0; r < 4; ++r) v[r] = rs * (acc[h][i][j][r] - mu * s4[r]) + t4[r];
+                    } else {
+                        const half4 bv = *reinterpret_cast<const half4*>(ax + AUX_BIAS + ct * 2);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[h][i][j][r] + (float)bv[r];
+                    }
                     unsigned w0, w1 = 0;
                     if (EPI == EPI_GEGLU) {
                         const f16 h0 = (f16)v[0], h1 = (f16)v[1], g0 = (f16)v[2], g1 = (f16)v[3];
@@ -341,61 +407,65 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
                         w0 = __builtin_bit_cast(unsigned, o);
                     } else {
                         half4 o = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                        if (p.temb) {
+                        if (temb_lds) {
+                            const half4 tv = *reinterpret_cast<const half4*>(ax + AUX_TEMB + ct * 2);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) o[r] = (f16)((float)o[r] + (float)tv[i][r]);
+                            for (int r = 0; r < 4; ++r) o[r] = (f16)((float)o[r] + (float)tv[r]);
                         }
-                        const uintx2 u = __builtin_bit_cast(uintx2, o);
-                        w0 = u[0]; w1 = u[1];
+                        const uintx2 uu = __builtin_bit_cast(uintx2, o);
+                        w0 = uu[0]; w1 = uu[1];
                     }
                     if (i < 4) { R[i][0] = w0; if (NWD == 2) R[i][NWD - 1] = w1; }
                     else { R4[0] = w0; if (NWD == 2) R4[NWD - 1] = w1; }
                 }
-                transpose4<NWD>(R);            // lane group lg now holds quarters 0..3 of channel block lg
+                transpose4<NWD>(R);            // lane group eg now holds quarters 0..3 of channel block eg
                 f16* yp = (m < p.M) ? p.Y + (size_t)m * p.ldy + c0o + wc * (OCH * CH) + h * OCH : nullptr;
                 if (EPI == EPI_GEGLU) {
-                    const uintx4 o8 = uintx4{R[0][0], R[1][0], R[2][0], R[3][0]};           // 8 output channels of block lg
-                    *reinterpret_cast<uintx4*>(yp ? yp + 8 * lg : sink) = o8;
-                    *reinterpret_cast<unsigned*>(yp ? yp + 32 + 2 * lg : sink) = R4[0];
+                    const uintx4 o8 = uintx4{R[0][0], R[1][0], R[2][0], R[3][0]};           // 8 output channels of block eg
+                    *reinterpret_cast<uintx4*>(yp ? yp + 8 * eg : sink) = o8;
+                    *reinterpret_cast<unsigned*>(yp ? yp + 32 + 2 * eg : sink) = R4[0];
                 } else {
                     half8 lo = __builtin_bit_cast(half8, uintx4{R[0][0], R[0][NWD - 1], R[1][0], R[1][NWD - 1]});
                     half8 hi = __builtin_bit_cast(half8, uintx4{R[2][0], R[2][NWD - 1], R[3][0], R[3][NWD - 1]});
                     half4 o4 = __builtin_bit_cast(half4, uintx2{R4[0], R4[NWD - 1]});
-                    if (has_res) {
-                        const half8 clo = rlo, chi = rhi; const half4 c4 = r4;
-                        // the next unit's residual is requested BEFORE this unit's stores (in-order vmcnt)
-                        if (j + 1 < 4) load_res(h, j + 1); else if (h + 1 < CH) load_res(h + 1, 0);
+                    if (RES) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) { lo[r] = (f16)((float)lo[r] + (float)clo[r]); hi[r] = (f16)((float)hi[r] + (float)chi[r]); }
+                        for (int r = 0; r < 8; ++r) {
+                            lo[r] = (f16)((float)lo[r] + (float)rlo[r]);
+                            hi[r] = (f16)((float)hi[r] + (float)rhi[r]);
+                        }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o4[r] = (f16)((float)o4[r] + (float)c4[r]);
+                        for (int r = 0; r < 4; ++r) o4[r] = (f16)((float)o4[r] + (float)r4[r]);
+                        // the next unit's residual is requested BEFORE this unit's stores (vmcnt retires in order: a
+                        // load queued behind stores would wait for them), into the registers just consumed
+                        if (u + 1 < 4 * CH) load_res(u + 1);
                     }
-                    *reinterpret_cast<half8*>(yp ? yp + 16 * lg : sink) = lo;
-                    *reinterpret_cast<half8*>(yp ? yp + 16 * lg + 8 : sink) = hi;
-                    *reinterpret_cast<half4*>(yp ? yp + 64 + 4 * lg : sink) = o4;
+                    *reinterpret_cast<half8*>(yp ? yp + 16 * eg : sink) = lo;
+                    *reinterpret_cast<half8*>(yp ? yp + 16 * eg + 8 : sink) = hi;
+                    *reinterpret_cast<half4*>(yp ? yp + 64 + 4 * eg : sink) = o4;
                 }
             }
         }
     };
 
-    // ---- prologue: first tile's k steps 0 and 1 into stages 0 and 1, its vectors into slot 0 ----------------------
+    // ---- prologue: the first tile's k step 0 into stage 0, its vectors into slot 0; sources of k step 1 prepared ----
     set_tile(tile);
     load_aux(0);
     prepare();
+    {
+        const int ln = hw_lane();
+        const int lchunk = ((ln & 7) ^ (ln >> 3)) * 8;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) load_piece(0, i);
+        for (int i = 0; i < NL; ++i) load_piece(0, i, lchunk);
+    }
     prepare();
-#pragma unroll
-    for (int i = 0; i < NL; ++i) load_piece(1, i);
 
-    int base = 0;                     // stage of the current tile's k step 0
+    int g = 0;                        // global k step of the stream: stage = g & 1
     int slot = 0;
     bool first = true;
     while (true) {
         const int pt = tile / tiles_c;
         const int p0 = pt * TP, c0out = (tile - pt * tiles_c) * TC;
-        const int next = tile + tstride;
-        const bool has_next = next < tend;
 #pragma unroll
         for (int h = 0; h < CH; ++h)
 #pragma unroll
@@ -403,43 +473,49 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[h][i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-        // One copy of the k step for the whole stream (instruction-cache footprint); per k step kt of this tile:
-        //   kt = 0      both of the tile's first stages were requested BEFORE the previous epilogue's stores, so "at most
-        //               NSTORE outstanding" proves that they (and the tile's vectors) have landed; nothing to issue;
-        //   kt = 1      operands landed with step 0's; every wave is done with stage `base`: refill it with k step 2;
-        //   kt >= 2     wait for everything (this is where the previous tile's stores must have drained);
-        //   last        the stream continues with the next tile's k step 0 into the other stage, then (one barrier later)
-        //               its k step 1 into the stage just consumed.
-        for (int kt = 0; kt < nk; ++kt) {
-            const bool lastk = (kt == nk - 1);
-            if (kt == 0 && !first) {
-                if (NSTORE == 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-            } else if (kt == 1) asm volatile("s_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            if (lastk && has_next) { set_tile(next); load_aux(slot ^ 1); }
-            step((base + kt) & 1, kt >= 1 && (!lastk || has_next));
-        }
+        // The tile's k step 0 (and its vectors) were requested BEFORE the previous epilogue's stores, so "at most
+        // NSTORE outstanding" proves they have landed; every later k step waits for everything, which is where the
+        // previous tile's stores must have drained (they had the epilogue's own run time plus one k step).
+        if (first) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (NSTORE == 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
+        else if (NSTORE == 16) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+        else if (NSTORE == 12) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
         first = false;
-        const int last = (base + nk - 1) & 1;
-        if (has_next) {
-            asm volatile("s_barrier" ::: "memory");            // every wave is done with stage `last`
+        // next tile of this block: asked for now (one returning atomic by thread 0), published through LDS (a spare word
+        // of the current vector slot) after k step 1's top wait, read by everyone after k step nk - 2  (nk >= 4)
+        int ticket = 0;
+        if (threadIdx.x == 0) ticket = atomicAdd(&g_tile_ctr[xcd * 32], 1);
+        int next = 0;
+        bool has_next = false;
+        for (int kt = 0; kt < nk; ++kt) {
+            step(g & 1);                                   // computes stream step g, requests stream step g + 1
+            ++g;
+            // sources of stream step g + 1 (two ahead of the one just computed): from k step nk - 2 on they belong
+            // to the next tile (without one the block re-requests its own first k steps: valid addresses, unused)
+            if (kt == nk - 2) {
+                next = tdyn + *reinterpret_cast<volatile int*>(aux0 + slot * AUX_BYTES + 1020);
+                next = __builtin_amdgcn_readfirstlane(next);
+                has_next = next < tend;
+                set_tile(has_next ? next : tile);
+                if (has_next) load_aux(slot ^ 1);
+            }
             prepare();
-#pragma unroll
-            for (int i = 0; i < NL; ++i) load_piece(last, i);
+            if (kt < nk - 1) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt == 0 && threadIdx.x == 0) *reinterpret_cast<volatile int*>(aux0 + slot * AUX_BYTES + 1020) = ticket;
         }
         epilogue(p0, c0out, slot);
         if (!has_next) break;
         tile = next;
-        base = last ^ 1;
         slot ^= 1;
     }
+    finish();
 }
 
 }  // namespace
 
-template <bool LN>
-static hipError_t launch_igemm_pers_t(const IGemmParams& p, hipStream_t s) {
+template <bool LN, int NW>
+static hipError_t launch_igemm_pers_nw(const IGemmParams& p, hipStream_t s) {
     constexpr int TP = 256, TC = 320;
     constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 2 * AUX_BYTES;           // 160 KiB: two operand stages + two vector slots
     const int ntiles = ((p.M + TP - 1) / TP) * (p.Cout / TC);
@@ -454,11 +530,18 @@ static hipError_t launch_igemm_pers_t(const IGemmParams& p, hipStream_t s) {
     const int grid = ntiles < n_cu[dev & 63] ? ntiles : n_cu[dev & 63];
     static std::atomic<uint64_t> attr_seen{0};      // hipFuncSetAttribute is per DEVICE, not per process
     if (first_use_on_device(attr_seen)) {
-        (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_GEGLU, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, LN, PX_NONE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_GEGLU, LN, PX_NONE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (!LN) {
+            (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, false, PX_TEMB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, false, PX_RES, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
     }
-    if (p.epi == EPI_GEGLU) hipLaunchKernelGGL((igemm_pers_kernel<EPI_GEGLU, LN>), dim3(grid), dim3(512), lds, s, p, ntiles);
-    else hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, LN>), dim3(grid), dim3(512), lds, s, p, ntiles);
+    const dim3 g(grid), b(64 * NW);
+    if (p.epi == EPI_GEGLU) hipLaunchKernelGGL((igemm_pers_kernel<EPI_GEGLU, LN, PX_NONE, NW>), g, b, lds, s, p, ntiles);
+    else if (!LN && p.temb) hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_TEMB, NW>), g, b, lds, s, p, ntiles);
+    else if (!LN && p.res) hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_RES, NW>), g, b, lds, s, p, ntiles);
+    else hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, LN, PX_NONE, NW>), g, b, lds, s, p, ntiles);
     return hipGetLastError();
 }
 

@@ -214,6 +214,12 @@ int dm_engine_memory(dm_engine* e, size_t* weights_bytes, size_t* arena_bytes);
 int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, const void* bias, const void* temb,
                 const void* res, void* Y, int N, int H, int W, int C1, int C2, int Cout, int OH, int OW,
                 int mode, int epi, int temb_ld);
+/* Runtime switches for A/B measurements (process-wide; each defaults to the measured best and is initialised from the
+ * environment variable DM_<NAME>): "igemm_big" (-1 per shape / 0 / 1), "igemm_persist", "igemm_splitk", "ln_fold",
+ * "attn_pipe" (0 / 1).  None of them changes a result bit, except ln_fold (LayerNorm folded into the next GEMM).
+ * Returns nonzero for an unknown name. */
+int dm_set_option(const char* name, int value);
+
 /* which tile geometry dm_op_igemm runs a shape on: 0 = 128-row tile (128x320 / 128x160), 1 = 256x320 tile */
 int dm_op_igemm_tile(int M, int Cin, int Cout, int mode);
 int dm_op_attention(void* stream, const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv,

@@ -318,3 +318,64 @@ def test_igemm_conv3x3_big_tile_vs_conv2d(C1, C2, Cout):
     assert lib.dm_op_igemm_tile(8 * H * W, Cin, Cout, 1) == 0
     diff = (small.float() - y_plain[:8].float()).abs()
     assert diff.max().item() <= 2e-3 * y_plain[:8].float().abs().max().item()
+
+
+@pytest.mark.parametrize("case", ["conv_temb", "conv_cat", "conv_res_ragged", "conv_s2", "conv_up", "dense_res", "geglu", "ln_geglu", "ln_plain"])
+def test_persistent_tile_is_bit_identical(case):
+    """The persistent form of the 256 x 320 tile (continuous k stream across tiles, direct fragment stores through
+    v_permlane16/32_swap, dynamic tile hand-out) against the one-tile-per-block kernel: same arithmetic, same rounding
+    points -> equal bit for bit on every epilogue variant, ragged last row tile included.  `dm_set_option` switches
+    kernels inside one process (igemm_persist: 0 = never, 2 = wherever it can run)."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    g = torch.Generator(device="cuda").manual_seed(11)
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g, device=d, dtype=torch.float32) * scale).half()
+    ln = case.startswith("ln_")
+    N, H, W, C1, C2, Cout, mode, epi, temb, res = {
+        "conv_temb": (160, 32, 32, 640, 0, 640, 1, 0, True, False),
+        "conv_cat": (160, 32, 32, 1280, 640, 640, 1, 0, True, False),
+        "conv_res_ragged": (161, 32, 32, 640, 0, 640, 1, 0, False, True),       # M = 164 864 + ... : last tile partly beyond M
+        "conv_s2": (160, 64, 64, 640, 0, 640, 2, 0, False, False),
+        "conv_up": (160, 16, 16, 1280, 0, 1280, 3, 0, False, False),
+        "dense_res": (1, 1, 66000 + 37, 1280, 0, 1280, 0, 0, False, True),
+        "geglu": (1, 1, 140000, 320, 0, 2560, 0, 1, False, False),
+        "ln_geglu": (1, 1, 131072 + 6, 320, 0, 2560, 0, 1, False, False),
+        "ln_plain": (1, 1, 66000, 1280, 0, 3840, 0, 0, False, False),
+    }[case]
+    taps = 9 if mode else 1
+    OH, OW = (H // 2, W // 2) if mode == 2 else ((2 * H, 2 * W) if mode == 3 else (H, W))
+    M = N * OH * OW
+    assert lib.dm_op_igemm_tile(M, C1 + C2, Cout, mode) == 1
+    x = rnd(N, H, W, C1)
+    x2 = rnd(N, H, W, C2, scale=0.5) if C2 else None
+    w = rnd(Cout, taps * (C1 + C2), scale=(taps * (C1 + C2)) ** -0.5)
+    b = rnd(Cout, scale=0.1)
+    tb = rnd(N, Cout) if temb else None
+    rs = rnd(N, OH, OW, Cout) if res else None
+    if ln:
+        ln_s = w.float().sum(1).contiguous()
+        ln_t = (torch.randn(Cout, generator=g, device=d) * 0.1).contiguous()
+        stats = torch.empty(M, 2, dtype=torch.float32, device=d)
+        assert lib.dm_op_ln_stats(U.stream(), U.ptr(x), M, C1, 1e-5, U.ptr(stats)) == 0
+
+    def run():
+        if ln:
+            y = torch.full((M, Cout // 2 if epi else Cout), float("nan"), dtype=torch.float16, device=d)
+            assert lib.dm_op_igemm_ln(U.stream(), U.ptr(x), U.ptr(w), U.ptr(ln_s), U.ptr(ln_t), U.ptr(stats), U.ptr(y), M, C1, Cout, epi) == 0
+            torch.cuda.synchronize()
+            return y
+        return U.op_igemm(x, w, b, X2=x2, temb=tb, res=rs, mode=mode, epi=epi, OH=OH, OW=OW)
+    try:
+        assert lib.dm_set_option(b"igemm_persist", 0) == 0
+        y0 = run()
+        assert lib.dm_set_option(b"igemm_persist", 2) == 0
+        y1 = run()
+        y2 = run()                      # a second launch: the self-resetting tile counters left a clean state
+    finally:
+        lib.dm_set_option(b"igemm_persist", 1)
+    assert not torch.isnan(y1.float()).any()
+    assert torch.equal(y0, y1) and torch.equal(y1, y2)
+    assert lib.dm_set_option(b"no_such_option", 1) != 0

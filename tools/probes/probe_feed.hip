@@ -1,0 +1,113 @@
+// L2 -> CU operand feed probe for the implicit-GEMM tile: what rate can one block per CU pull the
+// k-step operand stream (320 weight rows + 256 activation rows of 128 B per step, the 256x320x64 tile's 72 KiB) at,
+// with no MFMA and no fragment reads, as a function of the transport and of how many k steps are kept in flight?
+//   V0: LDS-DMA (global_load_lds_dwordx4), wait for everything after every step  (the 2-stage structure, latency-bound?)
+//   V1: LDS-DMA, D steps in flight (counted vmcnt; LDS slots reused without regard to content)
+//   V2: global_load_dwordx4 into VGPRs, D steps in flight
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/probe_feed.hip -o probe_feed && ./probe_feed
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int TP = 256, TC = 320, NW = 8, WI = 5, XI = 4, NL = 9;
+
+template <int MODE, int D>
+__global__ __launch_bounds__(512, 2) void feed_kernel(const _Float16* __restrict__ Wp, const _Float16* __restrict__ X, int K, int C, int nk,
+                                                      int tiles_c, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lrow = lane >> 3, lchunk = ((lane & 7) ^ lrow) * 8;
+    const int b = blockIdx.x;
+    const int pt = b / tiles_c, ct = b % tiles_c;
+    const _Float16* wsrc = Wp + (size_t)(ct * TC + wid * 8 + lrow) * K + lchunk;
+    const _Float16* xsrc = X + (size_t)(pt * TP + wid * 8 + lrow) * C + lchunk;
+    u4 acc = u4{0, 0, 0, 0};
+    for (int kt = 0; kt < nk; ++kt) {
+        char* st = smem + (kt & 1) * (TP + TC) * 128;
+        const int ko = (kt * 64) % C;                       // activation channel slab cycles like a conv's
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const _Float16* src = (i < WI) ? wsrc + (size_t)i * NW * 8 * K + kt * 64 : xsrc + (size_t)(i - WI) * NW * 8 * C + ko;
+            if (MODE < 2) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + (wid + i * NW) * 1024), 16, 0, 0);
+            else { u4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(src)); acc.x ^= v.x; }
+        }
+        if (MODE == 2) { /* the xor above makes the compiler wait for every load: handled by asm-free accounting below */ }
+        if (MODE == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (MODE == 1) {
+            if (D == 2) asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
+            else if (D == 3) asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(27)\n\ts_barrier" ::: "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((acc.x ^ acc.y) == 0x1234567u) sink[0] = acc.x;
+}
+
+// VGPR transport with D steps in flight: the loads of step t + D - 1 are issued before the data of step t is consumed
+template <int D>
+__global__ __launch_bounds__(512, 2) void feed_vgpr_kernel(const _Float16* __restrict__ Wp, const _Float16* __restrict__ X, int K, int C, int nk,
+                                                           int tiles_c, unsigned* sink) {
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lrow = lane >> 3, lchunk = ((lane & 7) ^ lrow) * 8;
+    const int b = blockIdx.x;
+    const int pt = b / tiles_c, ct = b % tiles_c;
+    const _Float16* wsrc = Wp + (size_t)(ct * TC + wid * 8 + lrow) * K + lchunk;
+    const _Float16* xsrc = X + (size_t)(pt * TP + wid * 8 + lrow) * C + lchunk;
+    u4 buf[D][NL];
+    unsigned acc = 0;
+    auto issue = [&](int kt, u4 (&dst)[NL]) {
+        const int ko = (kt * 64) % C;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const _Float16* src = (i < WI) ? wsrc + (size_t)i * NW * 8 * K + kt * 64 : xsrc + (size_t)(i - WI) * NW * 8 * C + ko;
+            dst[i] = *reinterpret_cast<const u4*>(src);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) issue(d, buf[d]);
+    for (int kt0 = 0; kt0 < nk; kt0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int kt = kt0 + d;
+            if (kt + D - 1 < nk) issue(kt + D - 1, buf[(d + D - 1) % D]);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) acc ^= buf[d][i].x;
+            __syncthreads();
+        }
+    }
+    if (acc == 0x1234567u) sink[0] = acc;
+}
+
+int main() {
+    const int K = 5760, C = 640, Cout = 1280, M = 65536, tiles_c = Cout / TC, nblk = (M / TP) * tiles_c;   // 1024 tiles = 4 per CU
+    _Float16 *W, *X; unsigned* sink;
+    hipMalloc(&W, (size_t)Cout * K * 2); hipMalloc(&X, (size_t)M * C * 2); hipMalloc(&sink, 64);
+    hipMemset(W, 0, (size_t)Cout * K * 2); hipMemset(X, 0, (size_t)M * C * 2);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int nk = K / 64;
+    const size_t lds = 2 * (TP + TC) * 128;
+    const double bytes = (double)nblk * nk * (TP + TC) * 128;
+    auto run = [&](const char* name, auto kern, size_t l) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), l, 0, W, X, K, C, nk, tiles_c, sink);
+        hipEventRecord(e0, 0);
+        for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), l, 0, W, X, K, C, nk, tiles_c, sink);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+        const double tbs = bytes / ms / 1e9;
+        printf("%-44s %7.3f ms  %6.2f TB/s  = %5.1f GB/s per CU (%4.1f B/clk at 2.0 GHz); per 72 KiB step: %5.0f ns\n", name, ms, tbs,
+               tbs * 1e3 / 256, tbs * 1e3 / 256 / 2.0, ms * 1e6 / (nblk / 256.0) / nk);
+    };
+    run("LDS-DMA, drain every step (1 block/CU)", feed_kernel<0, 1>, lds);
+    run("LDS-DMA, 2 steps in flight", feed_kernel<1, 2>, lds);
+    run("LDS-DMA, 3 steps in flight", feed_kernel<1, 3>, lds);
+    run("LDS-DMA, 4 steps in flight", feed_kernel<1, 4>, lds);
+    run("LDS-DMA, drain every step, 2 blocks/CU", feed_kernel<0, 1>, lds / 2);
+    run("VGPR loads, 1 step in flight", feed_vgpr_kernel<1>, 0);
+    run("VGPR loads, 2 steps in flight", feed_vgpr_kernel<2>, 0);
+    run("VGPR loads, 3 steps in flight", feed_vgpr_kernel<3>, 0);
+    return 0;
+}
