@@ -5,7 +5,7 @@ container; the resulting .so is git-ignored but travels to the GPU box with the 
 
 A translation unit is recompiled when the sha256 of (its source, every header, the flags, the hipcc
 version) differs from the stamp written next to its object file — content, not mtimes (a snapshot copy
-resets mtimes).  `build()` prints `compiled N/13 TUs` so a build check can see what it exercised;
+resets mtimes).  `build()` prints `compiled N/<TUs> TUs` so a build check can see what it exercised;
 `force=True` (or DM_BUILD_FORCE=1) recompiles everything.
 """
 from __future__ import annotations
@@ -22,8 +22,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdm_engine.so")
-SOURCES = ["igemm.hip", "igemm_big.hip", "igemm_big_ln.hip", "igemm_pers.hip", "igemm_pers_ln.hip", "igemm_ln.hip", "igemm64.hip", "igemm_splitk.hip", "attention.hip", "attention_pipe.hip", "norm.hip", "misc.hip", "vae.hip", "clip.hip", "engine.hip"]
-HEADERS = [os.path.join(CSRC, "dm_kernels.h"), os.path.join(CSRC, "igemm_tile.h"), os.path.join(CSRC, "igemm_big_tile.h"), os.path.join(CSRC, "igemm_pers_tile.h"), os.path.join(os.path.dirname(HERE), "include", "dm_engine.h")]
+SOURCES = ["igemm.hip", "igemm_pers.hip", "igemm_pers_ln.hip", "igemm_ln.hip", "igemm64.hip", "igemm_splitk.hip", "attention.hip", "attention_pipe.hip", "norm.hip", "misc.hip", "vae.hip", "clip.hip", "engine.hip"]
+HEADERS = [os.path.join(CSRC, "dm_kernels.h"), os.path.join(CSRC, "igemm_tile.h"), os.path.join(CSRC, "igemm_pers_tile.h"), os.path.join(os.path.dirname(HERE), "include", "dm_engine.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
          "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 

@@ -21,7 +21,7 @@ inline bool first_use_on_device(std::atomic<uint64_t>& seen) {
 
 // Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of
 // the same name in upper case with a DM_ prefix (DM_IGEMM_PERSIST=0 ...), changeable through dm_set_option().
-enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_PERSIST, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_COUNT };
+enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_COUNT };
 int option(Option o);                       // engine.hip
 int set_option(const char* name, int value);   // 0 on success
 
@@ -59,8 +59,8 @@ hipError_t launch_igemm(const IGemmParams& p, hipStream_t s);
 // the caller provides the workspace
 int igemm_splitk_parts(const IGemmParams& p, int spatial);
 int igemm_tile_choice(const IGemmParams& p);     // 0 = 128-row tile, 1 = 256 x 320 tile
-// shapes the persistent form of the 256 x 320 tile (igemm_pers_tile.h) takes; otherwise the one-tile-per-block kernel
-// of igemm_big_tile.h runs (bit-identical results): >= 4 k steps, a time embedding only when every 256-row tile lies
+// shapes the persistent 256 x 320 tile (igemm_pers_tile.h) takes; the others run on the 128-row tile of igemm_tile.h
+// (bit-identical results): >= 4 k steps, a time embedding only when every 256-row tile lies
 // inside one sample, never a time embedding and a residual together
 inline bool igemm_pers_ok(const IGemmParams& p) {
     const int nk = ((p.mode == IG_DENSE) ? 1 : 9) * (p.Cin / 64);

@@ -975,7 +975,7 @@ namespace dm {
 namespace {
 struct OptDef { const char* name; const char* env; int def; };
 const OptDef kOpts[OPT_COUNT] = {
-    {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_persist", "DM_IGEMM_PERSIST", 1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
+    {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
     {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1},
 };
 std::atomic<int> g_opt[OPT_COUNT];
@@ -1005,7 +1005,7 @@ int set_option(const char* name, int value) {
 // ================================================================================================
 extern "C" {
 
-const char* dm_version(void) { return "dm_engine 0.1 (gfx950; igemm 128x320 / 256x320 x64 mfma_f32_16x16x32_f16, LDS-DMA)"; }
+const char* dm_version(void) { return "dm_engine 0.2 (gfx950; igemm 128x320 / persistent 256x320 x64 mfma_f32_16x16x32_f16, LDS-DMA)"; }
 
 int dm_scheduler_alphas_cumprod(int n, float beta_start, float beta_end, float* out) {
     if (n < 2 || !out) return 1;

@@ -25,25 +25,27 @@
 
 namespace dm {
 
-hipError_t launch_igemm_big(const IGemmParams& p, hipStream_t s);     // igemm_big.hip (256 x 320 tile)
 hipError_t launch_igemm64(const IGemmParams& p, hipStream_t s);      // igemm64.hip (64-channel waves)
 hipError_t launch_igemm_splitk(const IGemmParams& p, hipStream_t s);  // igemm_splitk.hip
 hipError_t launch_igemm_tile_ln(const IGemmParams& p, hipStream_t s);  // igemm_ln.hip
-hipError_t launch_igemm_big_ln(const IGemmParams& p, hipStream_t s);   // igemm_big_ln.hip
 hipError_t launch_igemm_pers(const IGemmParams& p, hipStream_t s);     // igemm_pers.hip (256 x 320 tile, persistent)
 hipError_t launch_igemm_pers_ln(const IGemmParams& p, hipStream_t s);  // igemm_pers_ln.hip
 
-// Shape -> tile choice (measured on MI355X at the bench batch, tools/bench_ops.py): the 256x320 tile
-// pays on the k >= 640 linears, on the >= 640-channel / concat 3x3 convs and on the wide GEGLU
-// projections (+8..25 %) when the launch still has >= 2 tiles per CU; 128x320 wins elsewhere.
+// Shape -> tile choice, measured per shape on one box with both arms interleaved (tools/ab_igemm.py, r02): the
+// persistent 256 x 320 tile (igemm_pers_tile.h: 13.8 instead of 21.9 LDS-DMA bytes per kMAC, no per-tile prologue, stores
+// draining under the next tile) wins or ties on every U-Net shape that gives it >= 2 tiles per CU — -12 % on the
+// 320-channel q/k/v projections, -5..8 % on the 320-channel 3x3 convolutions, -7 % on ff.net.2 at 16x16, -3 % on the
+// 1280-channel projections — except the plain 1280 -> 1280 3x3 convolutions at 16x16 (640 tiles = 2.5 per CU: +2 %).
+// The choice depends on the batch size through the tile count; the two kernels are bit-identical
+// (tests/test_gpu_ops.py::test_persistent_tile_is_bit_identical), so a sample's result does not.
 static bool use_big(const IGemmParams& p) {
-    const int force = option(OPT_IGEMM_BIG);                 // -1: per shape
-    if (p.Cout % 320 != 0) return false;
-    if (force >= 0) return force != 0;                       // DM_IGEMM_BIG=0/1: A/B switch for every eligible shape
+    const int force = option(OPT_IGEMM_BIG);                 // -1: per shape; 0 / 1: A/B switch for every eligible shape
+    if (p.Cout % 320 != 0 || !igemm_pers_ok(p)) return false;
+    if (force >= 0) return force != 0;
     const long long tiles = (long long)((p.M + 255) / 256) * (p.Cout / 320);
-    if (tiles < 1024) return false;
-    if (p.mode == IG_DENSE) return p.Cin >= 640 || p.Cout >= 2560;
-    return p.Cin >= 640;
+    if (tiles < 512) return false;
+    if (p.mode == IG_CONV3 && tiles < 1024 && p.Cin <= 1280) return false;
+    return true;
 }
 
 // Layers at <= 8x8 spatial positions per sample (M = 10 240 rows at the bench batch: 320 tiles for 256 CUs):
@@ -60,18 +62,6 @@ int igemm_splitk_parts(const IGemmParams& p, int spatial) {
     return 1;
 }
 
-// Persistent form of the 256 x 320 tile (bit-identical results).  Measured per shape on one box (tools/ab_igemm.py,
-// r02): -12 / -7 / -1 % on the GEGLU projections (K = 320 / 640 / 1280), -8 % on the LayerNorm-folded q/k/v projections,
-// -4..5 % on the concat convolutions, -1..0 % on the time-embedding convolutions; +1 % on the residual convolutions,
-// +4..5 % on the residual linears (ff.net.2, to_out), +3 % on the nearest-upsample convolutions — those stay on the
-// one-tile-per-block kernel.  igemm_persist = 0: never, = 2: wherever the kernel can run (A/B).
-static bool use_pers(const IGemmParams& p) {
-    const int on = option(OPT_IGEMM_PERSIST);
-    if (on == 0 || !igemm_pers_ok(p)) return false;
-    if (on == 2) return true;
-    return !p.res && p.mode != IG_CONV3_UP;
-}
-
 // which tile geometry launch_igemm picks for a plain (no LN fold, no split-K) shape: 0 = 128-row, 1 = 256 x 320
 int igemm_tile_choice(const IGemmParams& p) {
     if (p.Cout % 160 != 0 || p.mode == IG_CONV3_S2P0) return 0;
@@ -82,12 +72,11 @@ hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
     if (p.ksplit > 1 && p.partial) return launch_igemm_splitk(p, s);
     if (p.ln_stats) {
         if (!p.ln_s || !p.ln_t || p.Cout % 160 != 0) return hipErrorInvalidValue;
-        if (use_big(p)) return use_pers(p) ? launch_igemm_pers_ln(p, s) : launch_igemm_big_ln(p, s);
-        return launch_igemm_tile_ln(p, s);
+        return use_big(p) ? launch_igemm_pers_ln(p, s) : launch_igemm_tile_ln(p, s);
     }
     if (p.Cout % 160 != 0 || p.mode == IG_CONV3_S2P0) return launch_igemm64(p, s);        // VAE channel counts
     if (p.Cout % 160 != 0 || p.Cin % BK != 0 || p.C1 % BK != 0 || p.M <= 0) return hipErrorInvalidValue;
-    if (use_big(p)) return use_pers(p) ? launch_igemm_pers(p, s) : launch_igemm_big(p, s);
+    if (use_big(p)) return launch_igemm_pers(p, s);
     return (p.Cout % 320 == 0) ? launch_t<4, 5>(p, s) : launch_t<2, 5>(p, s);
 }
 

@@ -210,9 +210,13 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
         }
         const int uh = oh + dy - 1, uw = ow + dx - 1;              // conv on the nearest-upsampled image
         if (uh < 0 || uh >= p.OH || uw < 0 || uw >= p.OW) return -1;
-        const float sh = (float)p.H / (float)p.OH, sw = (float)p.W / (float)p.OW;
-        int ih = (int)floorf((float)uh * sh); ih = ih < p.H - 1 ? ih : p.H - 1;
-        int iw = (int)floorf((float)uw * sw); iw = iw < p.W - 1 ? iw : p.W - 1;
+        int ih, iw;
+        if (p.OH == 2 * p.H && p.OW == 2 * p.W) { ih = uh >> 1; iw = uw >> 1; }      // exact 2x: floor(u * 0.5), no float math
+        else {                                                                      // F.interpolate(size=...), odd latent sizes
+            const float sh = (float)p.H / (float)p.OH, sw = (float)p.W / (float)p.OW;
+            ih = (int)floorf((float)uh * sh); ih = ih < p.H - 1 ? ih : p.H - 1;
+            iw = (int)floorf((float)uw * sw); iw = iw < p.W - 1 ? iw : p.W - 1;
+        }
         return xnb + ih * p.W + iw;
     };
     auto set_src = [&](int tap, int cs) __attribute__((always_inline)) {
@@ -360,15 +364,23 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
         const int e15 = eln & 15, eg = eln >> 4;
         f16* const sink = reinterpret_cast<f16*>(g_store_sink) + (wid * 64 + eln) * 8;
         // residual of unit u = (h, j) in the layout of the stores: 16 channels of block eg (two half8) + block 4's quarter
-        half8 rlo, rhi; half4 r4;
+        // Residual variant, two phases: (A) every unit is converted / transposed into packed registers while ALL residual
+        // loads are issued (unit u+1's right after unit u's conversion freed its 20 accumulator registers), (B) add + store.
+        // Every load is older than every store (vmcnt retires in order: a load queued behind stores would wait for them),
+        // and the wait for the first residual — which also sits behind the LDS-DMA of the next tile's first k step —
+        // overlaps the conversion work instead of preceding it.
+        constexpr int NU = 4 * CH;
+        half8 rlo[RES ? NU : 1], rhi[RES ? NU : 1], plo[RES ? NU : 1], phi[RES ? NU : 1];
+        half4 r4[RES ? NU : 1], p4[RES ? NU : 1];
+        f16* ypu[RES ? NU : 1];
         auto load_res = [&](int u) __attribute__((always_inline)) {
             const int h = u >> 2, j = u & 3;
             int m = p0 + wp * 64 + 16 * j + e15;
             m = m < p.M ? m : p.M - 1;
             const f16* rp = p.res + (size_t)m * p.ldres + c0o + wc * (OCH * CH) + h * OCH;
-            rlo = *reinterpret_cast<const half8*>(rp + 16 * eg);
-            rhi = *reinterpret_cast<const half8*>(rp + 16 * eg + 8);
-            r4 = *reinterpret_cast<const half4*>(rp + 64 + 4 * eg);
+            rlo[RES ? u : 0] = *reinterpret_cast<const half8*>(rp + 16 * eg);
+            rhi[RES ? u : 0] = *reinterpret_cast<const half8*>(rp + 16 * eg + 8);
+            r4[RES ? u : 0] = *reinterpret_cast<const half4*>(rp + 64 + 4 * eg);
         };
         if (RES) load_res(0);
 #pragma unroll
@@ -429,21 +441,32 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
                     half8 hi = __builtin_bit_cast(half8, uintx4{R[2][0], R[2][NWD - 1], R[3][0], R[3][NWD - 1]});
                     half4 o4 = __builtin_bit_cast(half4, uintx2{R4[0], R4[NWD - 1]});
                     if (RES) {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            lo[r] = (f16)((float)lo[r] + (float)rlo[r]);
-                            hi[r] = (f16)((float)hi[r] + (float)rhi[r]);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o4[r] = (f16)((float)o4[r] + (float)r4[r]);
-                        // the next unit's residual is requested BEFORE this unit's stores (vmcnt retires in order: a
-                        // load queued behind stores would wait for them), into the registers just consumed
-                        if (u + 1 < 4 * CH) load_res(u + 1);
+                        plo[RES ? u : 0] = lo; phi[RES ? u : 0] = hi; p4[RES ? u : 0] = o4; ypu[RES ? u : 0] = yp;
+                        if (u + 1 < NU) load_res(u + 1);
+                    } else {
+                        *reinterpret_cast<half8*>(yp ? yp + 16 * eg : sink) = lo;
+                        *reinterpret_cast<half8*>(yp ? yp + 16 * eg + 8 : sink) = hi;
+                        *reinterpret_cast<half4*>(yp ? yp + 64 + 4 * eg : sink) = o4;
                     }
-                    *reinterpret_cast<half8*>(yp ? yp + 16 * eg : sink) = lo;
-                    *reinterpret_cast<half8*>(yp ? yp + 16 * eg + 8 : sink) = hi;
-                    *reinterpret_cast<half4*>(yp ? yp + 64 + 4 * eg : sink) = o4;
                 }
+            }
+        }
+        if (RES) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                half8 lo = plo[RES ? u : 0], hi = phi[RES ? u : 0];
+                half4 o4 = p4[RES ? u : 0];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    lo[r] = (f16)((float)lo[r] + (float)rlo[RES ? u : 0][r]);
+                    hi[r] = (f16)((float)hi[r] + (float)rhi[RES ? u : 0][r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o4[r] = (f16)((float)o4[r] + (float)r4[RES ? u : 0][r]);
+                f16* yp = ypu[RES ? u : 0];
+                *reinterpret_cast<half8*>(yp ? yp + 16 * eg : sink) = lo;
+                *reinterpret_cast<half8*>(yp ? yp + 16 * eg + 8 : sink) = hi;
+                *reinterpret_cast<half4*>(yp ? yp + 64 + 4 * eg : sink) = o4;
             }
         }
     };

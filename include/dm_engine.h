@@ -215,12 +215,11 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
                 const void* res, void* Y, int N, int H, int W, int C1, int C2, int Cout, int OH, int OW,
                 int mode, int epi, int temb_ld);
 /* Runtime switches for A/B measurements (process-wide; each defaults to the measured best and is initialised from the
- * environment variable DM_<NAME>): "igemm_big" (-1 per shape / 0 / 1), "igemm_persist", "igemm_splitk", "ln_fold",
- * "attn_pipe" (0 / 1).  None of them changes a result bit, except ln_fold (LayerNorm folded into the next GEMM).
+ * environment variable DM_<NAME>): "igemm_big" (-1 per shape / 0 / 1), "igemm_splitk", "ln_fold", "attn_pipe" (0 / 1).  None of them changes a result bit, except ln_fold (LayerNorm folded into the next GEMM).
  * Returns nonzero for an unknown name. */
 int dm_set_option(const char* name, int value);
 
-/* which tile geometry dm_op_igemm runs a shape on: 0 = 128-row tile (128x320 / 128x160), 1 = 256x320 tile */
+/* which tile geometry dm_op_igemm runs a shape on: 0 = 128-row tile (128x320 / 128x160), 1 = persistent 256x320 tile */
 int dm_op_igemm_tile(int M, int Cin, int Cout, int mode);
 int dm_op_attention(void* stream, const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv,
                     int ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso, const int32_t* kv_slot,

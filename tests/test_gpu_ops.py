@@ -322,10 +322,11 @@ def test_igemm_conv3x3_big_tile_vs_conv2d(C1, C2, Cout):
 
 @pytest.mark.parametrize("case", ["conv_temb", "conv_cat", "conv_res_ragged", "conv_s2", "conv_up", "dense_res", "geglu", "ln_geglu", "ln_plain"])
 def test_persistent_tile_is_bit_identical(case):
-    """The persistent form of the 256 x 320 tile (continuous k stream across tiles, direct fragment stores through
-    v_permlane16/32_swap, dynamic tile hand-out) against the one-tile-per-block kernel: same arithmetic, same rounding
-    points -> equal bit for bit on every epilogue variant, ragged last row tile included.  `dm_set_option` switches
-    kernels inside one process (igemm_persist: 0 = never, 2 = wherever it can run)."""
+    """The persistent 256 x 320 tile (continuous k stream across tiles, direct fragment stores through
+    v_permlane16/32_swap, dynamic tile hand-out) against the one-tile-per-block 128-row kernel with its LDS-staged
+    epilogue: same arithmetic, same rounding points -> equal bit for bit on every epilogue variant, ragged last row tile
+    included (which is what makes a sample's result independent of the batch size that selects the tile).
+    `dm_set_option` switches kernels inside one process (igemm_big: 0 = never, 1 = every eligible shape, -1 = per shape)."""
     from diff_mining_amd import engine as E
     lib = E.load_library()
     d = U.dev()
@@ -369,13 +370,15 @@ def test_persistent_tile_is_bit_identical(case):
             return y
         return U.op_igemm(x, w, b, X2=x2, temb=tb, res=rs, mode=mode, epi=epi, OH=OH, OW=OW)
     try:
-        assert lib.dm_set_option(b"igemm_persist", 0) == 0
+        assert lib.dm_set_option(b"igemm_big", 0) == 0
+        assert lib.dm_op_igemm_tile(M, C1 + C2, Cout, mode) == 0
         y0 = run()
-        assert lib.dm_set_option(b"igemm_persist", 2) == 0
+        assert lib.dm_set_option(b"igemm_big", 1) == 0
+        assert lib.dm_op_igemm_tile(M, C1 + C2, Cout, mode) == 1
         y1 = run()
         y2 = run()                      # a second launch: the self-resetting tile counters left a clean state
     finally:
-        lib.dm_set_option(b"igemm_persist", 1)
+        lib.dm_set_option(b"igemm_big", -1)
     assert not torch.isnan(y1.float()).any()
     assert torch.equal(y0, y1) and torch.equal(y1, y2)
     assert lib.dm_set_option(b"no_such_option", 1) != 0

@@ -2,7 +2,7 @@
 """A/B of a runtime switch (dm_set_option) on the U-Net's igemm shapes at the bench batch, both arms in ONE process on ONE
 box, interleaved (box-to-box and run-to-run spread is +-2-3 %, more than most kernel changes):
 
-    python tools/ab_igemm.py igemm_persist 0 1            # option, value A, value B
+    python tools/ab_igemm.py igemm_big 0 1                # option, value A, value B (here: 128-row tile vs persistent 256 x 320)
 Shapes: every (mode, M, N, K, epilogue) of a bench step that takes the 256 x 320 tile, with its launches per step."""
 import os
 import sys
@@ -33,6 +33,15 @@ SHAPES = [
     ("ff2 2560->640 @32 res", 5, 0, 32, 32, 2560, 0, 640, 0, "res"),
     ("qkv 640->1920 @32 ln", 5, 0, 32, 32, 640, 0, 1920, 0, "ln"),
     ("shortcut 1x1 cat 640+320->320 @64", 1, 0, 64, 64, 640, 320, 320, 0, ""),
+    # shapes the per-shape rule keeps on the 128-row tile (Cin < 640, or < 1024 big tiles)
+    ("conv1 3x3 320->320 @64 temb", 3, 1, 64, 64, 320, 0, 320, 0, "temb"),
+    ("conv2 3x3 320->320 @64 res", 3, 1, 64, 64, 320, 0, 320, 0, "res"),
+    ("proj 320->320 @64 res", 15, 0, 64, 64, 320, 0, 320, 0, "res"),
+    ("qkv 320->960 @64 ln", 5, 0, 64, 64, 320, 0, 960, 0, "ln"),
+    ("proj 640->640 @32 res", 20, 0, 32, 32, 640, 0, 640, 0, "res"),
+    ("proj 1280->1280 @16 res", 20, 0, 16, 16, 1280, 0, 1280, 0, "res"),
+    ("ff2 5120->1280 @16 res", 5, 0, 16, 16, 5120, 0, 1280, 0, "res"),
+    ("down 3x3 s2 320->320 @64->32", 1, 2, 64, 64, 320, 0, 320, 0, ""),
 ]
 
 

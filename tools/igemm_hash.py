@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Prints a sha256 per output of dm_op_igemm / dm_op_igemm_ln on shapes that take the 256 x 320 tile, so that two
-builds / runtime switches (e.g. DM_IGEMM_PERSIST=0 vs 1) can be compared bit for bit from separate processes:
+builds / runtime switches (e.g. DM_IGEMM_BIG=0 vs 1) can be compared bit for bit from separate processes:
 
-    DM_IGEMM_PERSIST=0 python tools/igemm_hash.py > a.txt; DM_IGEMM_PERSIST=1 python tools/igemm_hash.py > b.txt; diff a.txt b.txt
+    DM_IGEMM_BIG=0 python tools/igemm_hash.py > a.txt; DM_IGEMM_BIG=1 python tools/igemm_hash.py > b.txt; diff a.txt b.txt
 """
 import hashlib
 import os

@@ -81,6 +81,57 @@ __global__ __launch_bounds__(512, 2) void feed_vgpr_kernel(const _Float16* __res
     if (acc == 0x1234567u) sink[0] = acc;
 }
 
+// The real k step's three activities, separately switchable: LDS-DMA of the next stage (9 pieces per wave, spread over
+// the step), the fragment reads of the current stage (28 ds_read_b128 per wave = 229 KB per block) and the 80 MFMAs per
+// wave.  RD / MF = 0 removes that activity (operands then come from registers).
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <int DMA, int RD, int MF>
+__global__ __launch_bounds__(512, 2) void mix_kernel(const _Float16* __restrict__ Wp, const _Float16* __restrict__ X, int K, int C, int nk,
+                                                     int tiles_c, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lrow = lane >> 3, lchunk = ((lane & 7) ^ lrow) * 8;
+    const int b = blockIdx.x;
+    const int pt = b / tiles_c, ct = b % tiles_c;
+    const _Float16* wsrc = Wp + (size_t)(ct * TC + wid * 8 + lrow) * K + lchunk;
+    const _Float16* xsrc = X + (size_t)(pt * TP + wid * 8 + lrow) * C + lchunk;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int roff = ((wid & 3) * 64 + l15) * 128 + ((lg ^ (l15 & 7)) << 4);
+    f4 acc[20];
+    for (int i = 0; i < 20; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    h8 fa, fb;
+    for (int k = 0; k < 8; ++k) { fa[k] = (_Float16)(0.01f * (lane + k)); fb[k] = (_Float16)(0.02f * (lane - k)); }
+    for (int kt = 0; kt < nk; ++kt) {
+        char* st = smem + ((kt + 1) & 1) * (TP + TC) * 128;
+        const char* cur = smem + (kt & 1) * (TP + TC) * 128;
+        const int ko = ((kt + 1) * 64) % C;
+        int piece = 0;
+#pragma unroll
+        for (int g = 0; g < 20; ++g) {
+            if (RD) {          // 28 fragment reads per step: one per group + 8 extra
+                const h8 v = *reinterpret_cast<const h8*>(cur + roff + (g % 5) * 2048 + (g / 5) * 10240);
+                if (MF) fa = v; else { asm volatile("" :: "v"(v)); }
+                if (g < 8) { const h8 u = *reinterpret_cast<const h8*>(cur + 40960 + roff + (g % 4) * 2048); if (MF) fb = u; else { asm volatile("" :: "v"(u)); } }
+            }
+            if (MF) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[(g % 5) * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc[(g % 5) * 4 + j], 0, 0, 0);
+            }
+            if (DMA && piece < NL && (g & 1) == 0) {
+                const int i = piece++;
+                const _Float16* src = (i < WI) ? wsrc + (size_t)i * NW * 8 * K + ((kt + 1) % nk) * 64 : xsrc + (size_t)(i - WI) * NW * 8 * C + ko;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + (wid + i * NW) * 1024), 16, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    float sum = 0.f;
+    for (int i = 0; i < 20; ++i) sum += acc[i][0] + acc[i][3];
+    if (sum == 1.2345f) sink[1] = 1;
+}
+
 int main() {
     const int K = 5760, C = 640, Cout = 1280, M = 65536, tiles_c = Cout / TC, nblk = (M / TP) * tiles_c;   // 1024 tiles = 4 per CU
     _Float16 *W, *X; unsigned* sink;
@@ -109,5 +160,22 @@ int main() {
     run("VGPR loads, 1 step in flight", feed_vgpr_kernel<1>, 0);
     run("VGPR loads, 2 steps in flight", feed_vgpr_kernel<2>, 0);
     run("VGPR loads, 3 steps in flight", feed_vgpr_kernel<3>, 0);
+    printf("--- k step activities, 2 stages, drain + barrier every step (ns per step; 80 MFMAs/wave = 1067 ns at 2.4 GHz peak)\n");
+    auto runm = [&](const char* name, auto kern) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, 0, W, X, K, C, nk, tiles_c, sink);
+        hipEventRecord(e0, 0);
+        for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, 0, W, X, K, C, nk, tiles_c, sink);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+        printf("%-44s %7.3f ms  per step: %5.0f ns\n", name, ms, ms * 1e6 / (nblk / 256.0) / nk);
+    };
+    runm("DMA only (spread over the step)", mix_kernel<1, 0, 0>);
+    runm("fragment reads only", mix_kernel<0, 1, 0>);
+    runm("MFMA only", mix_kernel<0, 0, 1>);
+    runm("MFMA + fragment reads", mix_kernel<0, 1, 1>);
+    runm("MFMA + DMA", mix_kernel<1, 0, 1>);
+    runm("fragment reads + DMA", mix_kernel<1, 1, 0>);
+    runm("MFMA + fragment reads + DMA", mix_kernel<1, 1, 1>);
     return 0;
 }
