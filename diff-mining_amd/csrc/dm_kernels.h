@@ -65,8 +65,8 @@ int igemm_tile_choice(const IGemmParams& p);     // 0 = 128-row tile, 1 = 256 x 
 inline bool igemm_pers_ok(const IGemmParams& p) {
     const int nk = ((p.mode == IG_DENSE) ? 1 : 9) * (p.Cin / 64);
     if (nk < 4 || p.Cout % 320 != 0 || p.M < 2) return false;
-    if (p.mode != IG_DENSE && (p.OH > 511 || p.OW > 511 || p.M / (p.OH * p.OW) > 8191)) return false;      // packed row coordinates
-    if (p.temb && (p.res || p.epi == EPI_GEGLU || p.ln_stats || (p.OH * p.OW) % 256 != 0)) return false;
+    if (p.mode != IG_DENSE && (p.OH < 1 || p.OW < 1 || p.OH > 511 || p.OW > 511 || p.M / (p.OH * p.OW) > 8191)) return false;   // packed row coordinates
+    if (p.temb && (p.res || p.epi == EPI_GEGLU || p.ln_stats || p.OH * p.OW < 1 || (p.OH * p.OW) % 256 != 0)) return false;
     if (p.res && (p.epi == EPI_GEGLU || p.ln_stats)) return false;
     if (p.ln_stats && (p.M & 1)) return false;
     return true;

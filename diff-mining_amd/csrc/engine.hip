@@ -1706,6 +1706,7 @@ int dm_set_option(const char* name, int value) { return dm::set_option(name, val
 int dm_op_igemm_tile(int M, int Cin, int Cout, int mode) {
     IGemmParams p{};
     p.M = M; p.Cin = Cin; p.C1 = Cin; p.Cout = Cout; p.mode = mode; p.epi = EPI_PLAIN;
+    p.OH = 1; p.OW = M > 511 ? 256 : (M > 0 ? M : 1);      // spatial extent unknown here: any value inside the kernel's coordinate range
     return igemm_tile_choice(p);
 }
 

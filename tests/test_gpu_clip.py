@@ -42,7 +42,7 @@ def test_clip_matches_transformers_fixture(clip_engine, clip_sd):
     sd = {k: torch.from_numpy(v).float() for k, v in clip_sd.items()}
     r16 = U.rel_l2(out, clip_ref.clip_text_forward(sd, ids, autocast=True))
     print(f"clip: rel-L2 vs transformers fp32 {r:.2e}, vs fp16-emulating oracle {r16:.2e}")
-    assert r < 3e-3 and r16 < 3e-3
+    assert r < 2.2e-3 and r16 < 2.4e-3          # measured (r02) 1.08e-3 / 1.21e-3
     out16 = clip_engine.clip_encode(ids, out_dtype=torch.float16)
     assert torch.equal(out16.float(), out)
 

@@ -3,7 +3,7 @@ head_dim-512 attention, and `dm_vae_encode` end to end against the CPU oracle (`
 parity unpinned — see its header) and the committed golden fixture.
 
 Tolerances as for the U-Net: per-op rel-L2 <= 2e-3 vs torch fp32 on the same fp16
-inputs; end-to-end moments rel-L2 <= 4e-3 against the fp16-autocast emulation of the oracle."""
+inputs; end-to-end moments rel-L2 <= 3e-3 (2x the measured value) against the fp16-autocast emulation of the oracle."""
 import ctypes as C
 import os
 
@@ -138,7 +138,7 @@ def test_vae_encode_matches_oracle(vae_engine, vae_sd, B, H, W):
     print(f"vae {B}x{H}x{W}: moments rel-L2 vs autocast-oracle {r_ac:.2e}, vs fp32 {r_32:.2e}; oracle ac-vs-fp32 {base:.2e}")
     assert r_ac < 3e-3 and r_32 < 2.7e-3            # measured (r02) <= 1.53e-3 / 1.36e-3
     print(f"vae latents rel-L2 {U.rel_l2(lat, ref_lat):.2e}")
-    assert U.rel_l2(lat, ref_lat) < 4e-3
+    assert U.rel_l2(lat, ref_lat) < 1.8e-3           # measured (r02) <= 9.0e-4
     # posterior mode = mean * scaling
     mode = vae_engine.vae_encode(img, None, out_dtype=torch.float32)
     assert torch.equal(mode, mom[:, :4] * np.float32(0.18215))
@@ -152,8 +152,8 @@ def test_vae_golden(vae_engine):
     img, noise = torch.from_numpy(g["image"]), torch.from_numpy(g["noise"])
     lat, mom = vae_engine.vae_encode(img, noise, return_moments=True, out_dtype=torch.float32)
     print(f"vae golden: moments {U.rel_l2(mom, torch.from_numpy(g['moments'])):.2e} latents {U.rel_l2(lat, torch.from_numpy(g['latents'])):.2e}")
-    assert U.rel_l2(mom, torch.from_numpy(g["moments"])) < 4e-3
-    assert U.rel_l2(lat, torch.from_numpy(g["latents"])) < 4e-3
+    assert U.rel_l2(mom, torch.from_numpy(g["moments"])) < 3e-3           # measured (r02) 1.50e-3
+    assert U.rel_l2(lat, torch.from_numpy(g["latents"])) < 1.7e-3         # measured (r02) 8.5e-4
 
 
 def test_vae_full_size_properties(vae_engine):
@@ -241,7 +241,7 @@ def test_image_to_typicality_grid(vae_engine, vae_sd, sd15_weights_f16):
     noises, ts = sc.draw((1, 4, 8, 8))
     ref = R.compute_losses(usd, x_ref, c.float(), noises, ts, B=2)        # fp32 latent, fp32 draws: the reference's flow
     print(f"image -> grid rel-L2 {U.rel_l2(grid, ref):.2e}")
-    assert U.rel_l2(grid, ref) < 8e-3
+    assert U.rel_l2(grid, ref) < 3.2e-3              # measured (r02) 1.62e-3
     # uint8 image path: load_image reproduces to_tensor(x) * 2 - 1
     u8 = ((img[0].permute(1, 2, 0).float().numpy() + 1) * 127.5).round().clip(0, 255).astype(np.uint8)
     t = sc.load_image(u8)
@@ -288,4 +288,4 @@ def test_dift_from_pixels(vae_engine, vae_sd, sd15_weights_f16):
     ft, _ = R.dift_features(usd, noisy.half().float(), 161, prompt.float().expand(ens, -1, -1), 1)
     ref = ft.mean(0, keepdim=True)
     print(f"dift from pixels rel-L2 {U.rel_l2(got, ref):.2e}")
-    assert U.rel_l2(got, ref) < 6e-3, U.rel_l2(got, ref)
+    assert U.rel_l2(got, ref) < 3e-3, U.rel_l2(got, ref)      # measured (r02) 1.48e-3
