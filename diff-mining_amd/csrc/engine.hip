@@ -1315,7 +1315,9 @@ int dm_vae_encode(dm_engine* e, const void* image_dev, const void* noise_dev, in
     if (!e) return 1;
     if (!e->vae_ready) DM_FAIL(e, "dm_vae_encode: VAE weights not loaded (dm_engine_finalize_vae)");
     if (!image_dev || (!latent_f16_dev && !latent_f32_dev && !moments_f32_dev)) DM_FAIL(e, "dm_vae_encode: null argument");
-    if (batch <= 0 || H < 8 || W < 8 || (H % 8) || (W % 8)) DM_FAIL(e, "dm_vae_encode: H and W must be positive multiples of 8");
+    // any size >= 8: like diffusers' three Downsample2D(padding=0) stages (pad right/bottom by one, 3x3 stride 2), each stage
+    // floors odd sizes, so the latent is floor(H / 8) x floor(W / 8) (cars rescaled to 256 x 341 px -> 32 x 42)
+    if (batch <= 0 || H < 8 || W < 8) DM_FAIL(e, "dm_vae_encode: H and W must be >= 8");
     if (draws_per_image < 1 || (draws_per_image > 1 && !noise_dev)) DM_FAIL(e, "dm_vae_encode: draws_per_image > 1 needs the noise draws");
     const int D = draws_per_image;
     DM_HIP(e, hipSetDevice(e->device));

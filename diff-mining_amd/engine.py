@@ -222,7 +222,7 @@ class UNetEngine:
         out_dtype = out_dtype or torch.float16
         image = image.to(self.device, torch.float16).contiguous()
         B, c, H, W = image.shape
-        assert c == 3 and H % 8 == 0 and W % 8 == 0, image.shape
+        assert c == 3 and H >= 8 and W >= 8, image.shape
         h, w = H // 8, W // 8
         if noise is not None:
             noise = noise.to(self.device, torch.float16).contiguous()

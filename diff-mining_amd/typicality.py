@@ -245,8 +245,8 @@ class TypicalityScorer:
     def compute(self, country: str, path: str, vae_noise=None):
         """`D.compute(country, path)`: open + rescale the image, score it under [country, ""] and write the
         `[N,2,4,h,w]` float16 grid to `<typicality_path>/<image stem>.npy`.  Needs VAE weights on the engine
-        and `country_embeds`.  The image is cropped to a multiple of 8 pixels for the VAE (the reference's
-        `F.conv2d` chain floors odd sizes implicitly at each stride-2 stage)."""
+        and `country_embeds`.  Image sizes that are not multiples of 8 (cars: 256 x 341) are encoded as they are:
+        every stride-2 stage of the VAE floors, as in the reference."""
         import PIL.Image
         assert self.typicality_path is not None and self.country_embeds is not None, "scorer built without D's arguments"
         img = self.rescale(PIL.Image.open(path))
@@ -254,9 +254,7 @@ class TypicalityScorer:
         out = os.path.join(self.typicality_path, seed.replace(".jpg", ".npy").replace(".png", ".npy"))
         embeds = torch.stack([self.country_embeds[country], self.country_embeds[""]], dim=0)       # 0 = c, 1 = null
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        x = self.load_image(img)
-        H, W = x.shape[-2] // 8 * 8, x.shape[-1] // 8 * 8
-        losses = self.compute_losses_from_image(x[..., :H, :W], embeds, vae_noise=vae_noise)
+        losses = self.compute_losses_from_image(self.load_image(img), embeds, vae_noise=vae_noise)
         out = self.get_path(self.typicality_path, out)
         with open(out, "wb") as f:
             np.save(f, losses.numpy())

@@ -154,7 +154,8 @@ int dm_prof_read(dm_engine* e, double* igemm_ms, double* igemm_flops, int64_t* i
  *   `post_quant_conv.*` are accepted and ignored; the pre-0.15 attention names query/key/value/proj_attn
  *   and their [C,C,1,1] shapes are mapped to to_q/to_k/to_v/to_out.0).  Host memory, DM_F16 or DM_F32.
  * dm_engine_finalize_vae: checks the 108 encoder tensors (34,163,664 parameters), packs, uploads.
- * dm_vae_encode: image [batch,3,H,W] fp16 NCHW in [-1,1] (H, W multiples of 8); `draws_per_image` D
+ * dm_vae_encode: image [batch,3,H,W] fp16 NCHW in [-1,1] (H, W >= 8; sizes that are not multiples of 8 floor at each of
+ *   the three stride-2 stages like diffusers' Downsample2D(padding=0): the latent is floor(H/8) x floor(W/8)); `draws_per_image` D
  *   posterior samples per image from noise [batch*D,4,H/8,W/8] fp16 = the injected N(0,1) draws of
  *   `latent_dist.sample()` (NULL with D = 1 -> posterior mode, mean only).  D = 8 is the DIFT ensemble
  *   (dift.py:187,220 encode the same image 8 times; here the encoder runs once per image).

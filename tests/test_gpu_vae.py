@@ -125,12 +125,15 @@ def _oracle(vae_sd, img, noise, autocast=True):
     return vae_ref.vae_encode(sd, img.float(), noise, autocast)
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 64, 96), (1, 128, 128)])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 64, 96), (1, 128, 128), (1, 100, 68), (1, 85, 131)])
 def test_vae_encode_matches_oracle(vae_engine, vae_sd, B, H, W):
     from diff_mining_amd import synth
+    # sizes that are not multiples of 8 floor at every stride-2 stage (100 -> 50 -> 25 -> 12; 85 -> 42 -> 21 -> 10), like
+    # diffusers' Downsample2D(padding=0): what D.rescale hands the VAE for cars (256 x 341, compute.py:165-173)
     img = torch.from_numpy(synth.synth_image(B, H, W))
     noise = U.f16_randn(B, 4, H // 8, W // 8, seed=41)
     lat, mom = vae_engine.vae_encode(img, noise, return_moments=True, out_dtype=torch.float32)
+    assert lat.shape == (B, 4, H // 8, W // 8)
     ref_lat, ref_mom = _oracle(vae_sd, img, noise, autocast=True)
     ref32_lat, ref32_mom = _oracle(vae_sd, img, noise, autocast=False)
     r_ac, r_32 = U.rel_l2(mom, ref_mom), U.rel_l2(mom, ref32_mom)
@@ -289,3 +292,33 @@ def test_dift_from_pixels(vae_engine, vae_sd, sd15_weights_f16):
     ref = ft.mean(0, keepdim=True)
     print(f"dift from pixels rel-L2 {U.rel_l2(got, ref):.2e}")
     assert U.rel_l2(got, ref) < 3e-3, U.rel_l2(got, ref)      # measured (r02) 1.48e-3
+
+
+def test_compute_writes_the_reference_npy(vae_engine, sd15_weights_f16, tmp_path):
+    """`D.compute(country, path)` end to end (compute.py:182-192): image file -> rescale -> VAE -> N x 2 U-Net scorings ->
+    `<typicality_path>/<stem>.npy` ([N,2,4,h,w] float16, cond 0 = country, 1 = ""), then `exists` / `__call__`."""
+    import PIL.Image
+    from diff_mining_amd import synth
+    from diff_mining_amd.typicality import TypicalityScorer
+    eng = vae_engine
+    if not eng._finalized:
+        eng.load_state_dict(sd15_weights_f16)
+    _, _, _, c = synth.synth_inputs(1, 1, 8, 8)
+    embeds = {"1970": torch.from_numpy(c[0]), "": torch.from_numpy(c[1])}
+    out_dir = str(tmp_path / "typ" / "1970")
+    sc = TypicalityScorer(eng, seed=42, N=2, t_min=0.1, t_max=0.7, typicality_path=out_dir, which="cars", country_embeds=embeds)
+    u8 = ((synth.synth_image(1, 50, 67)[0].transpose(1, 2, 0).astype(np.float32) + 1) * 127.5).round().clip(0, 255).astype(np.uint8)
+    path = str(tmp_path / "1970__car_000123.jpg")
+    PIL.Image.fromarray(u8).save(path, quality=95)
+    assert not sc.exists(path)
+    vnoise = U.f16_randn(1, 4, 32, 42, seed=77)            # cars: 67 x 50 px -> (343, 256) -> latent 32 x 42
+    out = sc.compute("1970", path, vae_noise=vnoise)
+    assert out == os.path.join(out_dir, "1970__car_000123.npy") and sc.exists(path)
+    grid = sc(path)
+    assert grid.dtype == np.float16 and grid.shape == (2, 2, 4, 32, 42)
+    # the same image through the pieces
+    img = sc.rescale(PIL.Image.open(path))
+    assert img.size == (343, 256)
+    ref = sc.compute_losses_from_image(sc.load_image(img), torch.stack([embeds["1970"], embeds[""]]), vae_noise=vnoise)
+    assert np.array_equal(grid, ref.numpy())
+    assert np.isfinite(grid.astype(np.float32)).all() and not np.array_equal(grid[:, 0], grid[:, 1])

@@ -132,6 +132,53 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const _Float16* __restrict_
     if (sum == 1.2345f) sink[1] = 1;
 }
 
+// the same three activities with v_mfma_f32_32x32x16_f16 (40 per wave per step = the same FLOPs; half the operand
+// register reads per FLOP): is the MFMA-only floor lower?
+typedef float f16v __attribute__((ext_vector_type(16)));
+template <int DMA, int RD>
+__global__ __launch_bounds__(512, 2) void mix32_kernel(const _Float16* __restrict__ Wp, const _Float16* __restrict__ X, int K, int C, int nk,
+                                                       int tiles_c, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lrow = lane >> 3, lchunk = ((lane & 7) ^ lrow) * 8;
+    const int b = blockIdx.x;
+    const int pt = b / tiles_c, ct = b % tiles_c;
+    const _Float16* wsrc = Wp + (size_t)(ct * TC + wid * 8 + lrow) * K + lchunk;
+    const _Float16* xsrc = X + (size_t)(pt * TP + wid * 8 + lrow) * C + lchunk;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int roff = ((wid & 3) * 64 + l15) * 128 + ((lg ^ (l15 & 7)) << 4);
+    f16v acc[10];
+    for (int i = 0; i < 10; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    h8 fa, fb;
+    for (int k = 0; k < 8; ++k) { fa[k] = (_Float16)(0.01f * (lane + k)); fb[k] = (_Float16)(0.02f * (lane - k)); }
+    for (int kt = 0; kt < nk; ++kt) {
+        char* st = smem + ((kt + 1) & 1) * (TP + TC) * 128;
+        const char* cur = smem + (kt & 1) * (TP + TC) * 128;
+        const int ko = ((kt + 1) * 64) % C;
+        int piece = 0;
+#pragma unroll
+        for (int g = 0; g < 20; ++g) {
+            if (RD) {
+                const h8 v = *reinterpret_cast<const h8*>(cur + roff + (g % 5) * 2048 + (g / 5) * 10240);
+                fa = v;
+                if (g < 8) { const h8 u = *reinterpret_cast<const h8*>(cur + 40960 + roff + (g % 4) * 2048); fb = u; }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[(g % 5) * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[(g % 5) * 2 + j], 0, 0, 0);
+            if (DMA && piece < NL && (g & 1) == 0) {
+                const int i = piece++;
+                const _Float16* src = (i < WI) ? wsrc + (size_t)i * NW * 8 * K + ((kt + 1) % nk) * 64 : xsrc + (size_t)(i - WI) * NW * 8 * C + ko;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + (wid + i * NW) * 1024), 16, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    float sum = 0.f;
+    for (int i = 0; i < 10; ++i) sum += acc[i][0] + acc[i][15];
+    if (sum == 1.2345f) sink[1] = 1;
+}
+
 int main() {
     const int K = 5760, C = 640, Cout = 1280, M = 65536, tiles_c = Cout / TC, nblk = (M / TP) * tiles_c;   // 1024 tiles = 4 per CU
     _Float16 *W, *X; unsigned* sink;
@@ -177,5 +224,9 @@ int main() {
     runm("MFMA + DMA", mix_kernel<1, 0, 1>);
     runm("fragment reads + DMA", mix_kernel<1, 1, 0>);
     runm("MFMA + fragment reads + DMA", mix_kernel<1, 1, 1>);
+    runm("32x32x16: MFMA only", mix32_kernel<0, 0>);
+    runm("32x32x16: MFMA + fragment reads", mix32_kernel<0, 1>);
+    runm("32x32x16: MFMA + DMA", mix32_kernel<1, 0>);
+    runm("32x32x16: MFMA + fragment reads + DMA", mix32_kernel<1, 1>);
     return 0;
 }
