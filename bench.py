@@ -16,7 +16,7 @@ it uses the ranks it was given and refuses a WORLD_SIZE that contradicts --gpus.
 sharding `r::N` as the reference's `subs[i::sub_split]` (diffmining/typicality/compute.py:337-341).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     — dominant kernel = the implicit-GEMM MFMA kernel family (84 % of the FLOPs):
+  roofline     — dominant kernel = the implicit-GEMM MFMA kernel family (84 % of the FLOPs; igemm_pers_kernel + igemm_kernel):
                  achieved = its algorithmic FLOPs / its summed launch time, measured with HIP events
                  on the launch stream over the timed steps (dm_prof_*); peak = 2.5 PFLOP/s dense fp16.
   cpu_baseline — the oracle (fp32 PyTorch-CPU restatement; kind "port") timed on this host's cores on
@@ -200,7 +200,7 @@ def main():
                        "images_per_gpu_per_step": n_img, "unet_forwards_per_image": per_img,
                        "latent_dtype_flow": args.latent_dtype,
                        "parallelism": f"image-sharded x{world}, one all-gather of T(x|c)"},
-            "roofline": {"bound": "mfma", "kernel": "igemm family: igemm_kernel + igemm_big_kernel incl. their LayerNorm-folded and split-K instantiations (implicit-GEMM conv3x3/1x1/linear, 128x320 and 256x320 tiles)",
+            "roofline": {"bound": "mfma", "kernel": "igemm family: igemm_pers_kernel (persistent 256x320 tile) + igemm_kernel (128x320 / 128x160 tile) incl. their LayerNorm-folded and split-K instantiations (implicit-GEMM conv3x3/1x1/linear)",
                          "achieved": round(ig_tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ig_tf / PEAK_TFLOPS, 4), "traffic": hbm_traffic_per_launch(),
                          "launches": prof["igemm_launches"], "kernel_ms_total": round(prof["igemm_ms"], 3),
@@ -233,7 +233,8 @@ def hbm_traffic_per_launch():
     for name in ("r02_final_pmc.json", "r01_final_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                return round(json.load(f)["kernels"]["igemm_kernel+igemm_big_kernel"]["hbm_bytes_per_launch"])
+                k = json.load(f)["kernels"]
+                return round((k.get("igemm_family") or k["igemm_kernel+igemm_big_kernel"])["hbm_bytes_per_launch"])
         except Exception:
             continue
     return None

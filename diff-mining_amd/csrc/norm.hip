@@ -21,7 +21,8 @@ constexpr int GN_PIX_MAX = 256;     // pixels per stats block (fewer when the im
 // The channel concat cat([X, X2]) of the up blocks is read in place (never materialised).
 __global__ void gn_stats_partial(const f16* __restrict__ X, const f16* __restrict__ X2, int HW, int C, int C1,
                                  int G, int R, int GN_PIX, double* __restrict__ partial) {
-    extern __shared__ float sh[];   // [R][C][2]
+    extern __shared__ float sh[];   // [R][2][C]: sums and sums of squares planar (a thread's 8 channels = two 16-byte stores;
+                                    // interleaved (sum, sq) pairs put 64 B between threads: a 16-way bank conflict per store)
     const int cols = C >> 3;
     const int n = blockIdx.y;
     const int chunk = blockIdx.x;
@@ -56,8 +57,8 @@ __global__ void gn_stats_partial(const f16* __restrict__ X, const f16* __restric
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            sh[((size_t)rg * C + c + k) * 2 + 0] = s[k];
-            sh[((size_t)rg * C + c + k) * 2 + 1] = q[k];
+            sh[((size_t)rg * 2 + 0) * C + c + k] = s[k];
+            sh[((size_t)rg * 2 + 1) * C + c + k] = q[k];
         }
     }
     __syncthreads();
@@ -66,8 +67,8 @@ __global__ void gn_stats_partial(const f16* __restrict__ X, const f16* __restric
         double ds = 0.0, dq = 0.0;
         for (int r = 0; r < R; ++r)
             for (int k = 0; k < cpg; ++k) {
-                ds += (double)sh[((size_t)r * C + t * cpg + k) * 2 + 0];
-                dq += (double)sh[((size_t)r * C + t * cpg + k) * 2 + 1];
+                ds += (double)sh[((size_t)r * 2 + 0) * C + t * cpg + k];
+                dq += (double)sh[((size_t)r * 2 + 1) * C + t * cpg + k];
             }
         double* out = partial + (((size_t)n * gridDim.x + chunk) * G + t) * 2;
         out[0] = ds; out[1] = dq;

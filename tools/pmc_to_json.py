@@ -17,7 +17,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 
 def family(name):
     if "igemm" in name:
-        return "igemm_kernel+igemm_big_kernel"
+        return "igemm_family"
     if "attn_" in name:
         return "attention"
     if "gn_" in name:

@@ -2,11 +2,13 @@
 # Regenerate the judged artifacts of a round on the GPU box:  bash tools/profile_round.sh <tag>
 # (run through gpurun; outputs land in gpurun_out/<tag>/, copy the summaries into profiles/).
 set -u
-TAG=${1:-r01_final}
+TAG=${1:-r02_final}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+DM_PROF_DUMP=$OUT/shapes_raw.txt python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python tools/prof_shapes.py $OUT/shapes_raw.txt 3 > $OUT/shapes.txt; rm -f $OUT/shapes_raw.txt
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline \
     > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
 i=0
