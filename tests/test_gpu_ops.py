@@ -382,3 +382,54 @@ def test_persistent_tile_is_bit_identical(case):
     assert not torch.isnan(y1.float()).any()
     assert torch.equal(y0, y1) and torch.equal(y1, y2)
     assert lib.dm_set_option(b"no_such_option", 1) != 0
+
+
+def test_persistent_tile_fuzz_against_128_row_tile():
+    """Randomised shapes (every mode, concat splits, ragged M, odd spatial sizes, K from 4 k steps up, optional bias /
+    time embedding / residual) through both tile kernels: bit-identical wherever the persistent kernel accepts the shape
+    (igemm_big = 1 falls back to the 128-row tile where it does not, e.g. a time embedding with HW % 256 != 0)."""
+    import random
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    rng = random.Random(1234)
+    g = torch.Generator(device="cuda").manual_seed(99)
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g, device=d, dtype=torch.float32) * scale).half()
+    n_pers = 0
+    try:
+        for it in range(36):
+            mode = rng.choice([0, 0, 1, 1, 1, 2, 3])
+            Cout = rng.choice([320, 640, 960, 1280])
+            c_tot = rng.choice([256, 320, 384, 640, 960])
+            C2 = rng.choice([0, 0, 64, 128, 320]) if c_tot > 320 else 0
+            C1 = c_tot - C2
+            if mode == 0:
+                N, H, W = 1, 1, rng.choice([256, 300, 1000, 1025, 2048, 4097])
+            else:
+                N = rng.choice([1, 2, 3, 5])
+                H, W = rng.choice([(16, 16), (16, 32), (9, 7), (12, 10), (32, 32), (24, 16)])
+            OH, OW = (H, W) if mode in (0, 1) else (((H + 1) // 2, (W + 1) // 2) if mode == 2 else
+                                                    rng.choice([(2 * H, 2 * W), (2 * H - 1, 2 * W - 1)]))
+            epi = 1 if (mode == 0 and rng.random() < 0.25) else 0
+            extra = rng.choice(["", "", "temb", "res"]) if not epi else ""
+            if extra == "temb" and mode == 0:
+                extra = ""
+            taps = 9 if mode else 1
+            x = rnd(N, H, W, C1)
+            x2 = rnd(N, H, W, C2, scale=0.5) if C2 else None
+            w = rnd(Cout, taps * c_tot, scale=(taps * c_tot) ** -0.5)
+            b = rnd(Cout, scale=0.1) if rng.random() < 0.8 else None
+            tb = rnd(N, Cout) if extra == "temb" else None
+            rs = rnd(N, OH, OW, Cout) if extra == "res" else None
+            outs = []
+            for big in (0, 1):
+                assert lib.dm_set_option(b"igemm_big", big) == 0
+                outs.append(U.op_igemm(x, w, b, X2=x2, temb=tb, res=rs, mode=mode, epi=epi, OH=OH, OW=OW))
+            n_pers += lib.dm_op_igemm_tile(N * OH * OW, c_tot, Cout, mode)
+            assert not torch.isnan(outs[1].float()).any(), (it, mode, N, H, W, C1, C2, Cout, epi, extra)
+            assert torch.equal(outs[0], outs[1]), (it, mode, N, H, W, C1, C2, Cout, epi, extra)
+    finally:
+        lib.dm_set_option(b"igemm_big", -1)
+    assert n_pers >= 20
