@@ -180,9 +180,9 @@ def test_vae_rejects_bad_input(vae_engine, vae_sd):
     from diff_mining_amd.engine import EngineError, UNetEngine
     with pytest.raises(EngineError):
         vae_engine.lib.dm_vae_encode.restype  # noqa: B018  (attribute exists)
-        bad = torch.zeros(1, 3, 60, 64, dtype=torch.float16, device=U.dev())
-        out = torch.empty(1, 4, 7, 8, dtype=torch.float16, device=U.dev())
-        vae_engine._check(vae_engine.lib.dm_vae_encode(vae_engine._h, U.ptr(bad), None, 1, 1, 60, 64, 0.18215, U.ptr(out), None,
+        bad = torch.zeros(1, 3, 4, 64, dtype=torch.float16, device=U.dev())       # smaller than one latent pixel
+        out = torch.empty(1, 4, 1, 8, dtype=torch.float16, device=U.dev())
+        vae_engine._check(vae_engine.lib.dm_vae_encode(vae_engine._h, U.ptr(bad), None, 1, 1, 4, 64, 0.18215, U.ptr(out), None,
                                                        None, U.stream()), "dm_vae_encode")
     eng = UNetEngine(0)
     try:
