@@ -1,9 +1,9 @@
-// igemm_pers.hip — plain instantiations of the persistent 256 px x 320 ch implicit-GEMM tile (igemm_pers_tile.h), 8 waves.
+// igemm_pers.hip — plain instantiations of the persistent 256 px x 320 ch implicit-GEMM tile (igemm_pers_tile.h).
 // Own translation unit like the other tile kernels (co-compiling large kernels perturbs their register allocation).
 #include "igemm_pers_tile.h"
 
 namespace dm {
 
-hipError_t launch_igemm_pers(const IGemmParams& p, hipStream_t s) { return launch_igemm_pers_nw<false, 8>(p, s); }
+hipError_t launch_igemm_pers(const IGemmParams& p, hipStream_t s) { return launch_igemm_pers_t<false>(p, s); }
 
 }  // namespace dm

@@ -1,8 +1,8 @@
-// igemm_pers_ln.hip — LayerNorm-folded instantiations of the persistent 256 x 320 tile, 8 waves (igemm_pers_tile.h).
+// igemm_pers_ln.hip — LayerNorm-folded instantiations of the persistent 256 x 320 tile (igemm_pers_tile.h).
 #include "igemm_pers_tile.h"
 
 namespace dm {
 
-hipError_t launch_igemm_pers_ln(const IGemmParams& p, hipStream_t s) { return launch_igemm_pers_nw<true, 8>(p, s); }
+hipError_t launch_igemm_pers_ln(const IGemmParams& p, hipStream_t s) { return launch_igemm_pers_t<true>(p, s); }
 
 }  // namespace dm

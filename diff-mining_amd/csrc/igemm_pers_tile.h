@@ -56,7 +56,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page_pers[1024];
-__device__ __attribute__((aligned(256))) unsigned char g_store_sink[16 * 64 * 16];     // one 16-byte slot per (wave, lane)
+__device__ __attribute__((aligned(256))) unsigned char g_store_sink[8 * 64 * 16];      // one 16-byte slot per (wave, lane)
 // Dynamic tile hand-out: one counter per XCD (its blocks share an L2, so an XCD keeps its contiguous tile range) +
 // one completion counter; the last block to finish resets them for the next launch (launches are stream-ordered and
 // an engine is single-stream; __device__ storage is per device).  Static striding lost 3-5 % to the slowest CU.
@@ -102,24 +102,18 @@ constexpr int AUX_BIAS = 0, AUX_TEMB = 1024, AUX_LNS = 2048, AUX_LNT = 4096, AUX
 // common path, where they wait for the prefetched LDS-DMA and the previous stores instead.
 enum { PX_NONE = 0, PX_TEMB = 1, PX_RES = 2 };
 
-// NW = waves per block: 8 (2 per SIMD, wave tile 64 px x 160 ch in two 80-channel halves, <= 256 registers) is what ships.
-// NW = 16 (4 per SIMD, wave tile 64 px x 80 ch, streamed fragments, <= 128 registers; same block tile, LDS image and
-// arithmetic) was built to test whether more issuing waves speed up the L2 -> LDS feed (tools/probes/probe_feed.hip: a CU
-// pulls 33 B/clk with 8 waves issuing and 47 B/clk with 16; the k step needs 29 at the MFMA rate): bit-identical, but
-// 1-5 % SLOWER on 14 of 17 U-Net shapes (r02, tools/ab_igemm.py) — the feed is not what a second pair of waves fixes.
-// The template parameter stays so the experiment can be re-run; only NW = 8 is instantiated.
-template <int EPI, bool LN, int EXTRA, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 4)
+// 8 waves (2 per SIMD), wave tile 64 px x 160 ch in two 80-channel halves, <= 256 registers.  (A 16-wave form of the
+// same block tile — 64 x 80 wave tiles, <= 128 registers — was measured 1-5 % slower in r02: DESIGN.md §4b.)
+template <int EPI, bool LN, int EXTRA>
+__global__ __launch_bounds__(512, 2)
 void igemm_pers_kernel(IGemmParams p, int ntiles) {
-    constexpr int WC = (NW == 16) ? 4 : 2, CH = (NW == 16) ? 1 : 2;
+    constexpr int WC = 2, CH = 2, NW = 8;
     constexpr int TP = 256, TC = 320;
     constexpr int WBYTES = TC * 128, XBYTES = TP * 128, STAGE = WBYTES + XBYTES;
-    // LDS-DMA pieces (8 rows x 128 B) per wave per k step: 40 weight pieces (NW = 16: three slots, the third only on waves
-    // 0..7) + 32 activation pieces
-    constexpr int WI = (TC / 8 + NW - 1) / NW, XI = TP / 8 / NW;
+    constexpr int WI = TC / 8 / NW, XI = TP / 8 / NW;          // 5 + 4 LDS-DMA pieces (8 rows x 128 B) per wave per k step
     constexpr int NL = WI + XI;
     // stores per wave per tile (every wave issues all of them: rows beyond M go to the sink page)
-    constexpr int NSTORE = ((EPI == EPI_GEGLU) ? 8 : 12) * CH;
+    constexpr int NSTORE = (EPI == EPI_GEGLU) ? 16 : 24;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const aux0 = smem + 2 * STAGE;
 
@@ -167,10 +161,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
     // (kept minimal: the k loop runs at 256 registers; the pixel coordinates of a lane's rows are re-derived from the
     // row index at every tap change instead of being held)
     int lp0 = 0, lc0 = 0;
-    // xpk: sample << 18 | oh << 9 | ow of this lane's activation rows, -1 beyond M (n < 8192, oh / ow < 512); held in
-    // registers by the 8-wave form only, re-derived from the row index at every tap change by the 16-wave form (128 registers)
-    constexpr bool KEEP_XPK = (NW == 8);
-    int xpk[KEEP_XPK ? XI : 1], xoff[XI];
+    int xpk[XI], xoff[XI];            // xpk: sample << 18 | oh << 9 | ow of this lane's activation rows, -1 beyond M (n < 8192, oh / ow < 512)
     unsigned woff = 0;
     const unsigned wstride = (unsigned)(NW * 8) * (unsigned)Ktot;
     const f16* xbase = p.X;
@@ -192,13 +183,11 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
         const int lrow = ln >> 3, lchunk = ((ln & 7) ^ lrow) * 8;
         woff = (unsigned)((size_t)(lc0 + wid * 8 + lrow) * Ktot + lchunk);
         ld_tap = 0; ld_cc = 0;
-        if (KEEP_XPK) {
 #pragma unroll
-            for (int k = 0; k < XI; ++k) xpk[k] = pack_row(lp0 + (wid + k * NW) * 8 + lrow);
-        }
+        for (int k = 0; k < XI; ++k) xpk[k] = pack_row(lp0 + (wid + k * NW) * 8 + lrow);
     };
-    auto src_pixel = [&](int k, int dy, int dx, int lrow) __attribute__((always_inline)) -> int {
-        const int pk = KEEP_XPK ? xpk[KEEP_XPK ? k : 0] : pack_row(lp0 + (wid + k * NW) * 8 + lrow);
+    auto src_pixel = [&](int k, int dy, int dx) __attribute__((always_inline)) -> int {
+        const int pk = xpk[k];
         if (pk < 0) return -1;
         if (p.mode == IG_DENSE) return pk;
         const int oh = (pk >> 9) & 511, ow = pk & 511;
@@ -225,7 +214,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
         const int lrow = ln >> 3, lchunk = ((ln & 7) ^ lrow) * 8;
 #pragma unroll
         for (int k = 0; k < XI; ++k) {
-            const int pix = src_pixel(k, dy, dx, lrow);
+            const int pix = src_pixel(k, dy, dx);
             xoff[k] = (pix >= 0) ? (pix * cs + lchunk) : -1;
         }
     };
@@ -237,10 +226,8 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
     auto load_piece = [&](int buf, int idx, int lchunk) __attribute__((always_inline)) {   // idx in [0, NL): W pieces, then X
         char* wt = smem + buf * STAGE;
         if (idx < WI) {
-            if (TC / 8 % NW == 0 || wid + idx * NW < TC / 8) {
-                lptr_t dst = (lptr_t)(wt + (wid + idx * NW) * 1024);
-                __builtin_amdgcn_global_load_lds((gptr_t)(p.Wp + (size_t)(woff + (unsigned)idx * wstride)), dst, 16, 0, 0);
-            }
+            lptr_t dst = (lptr_t)(wt + (wid + idx * NW) * 1024);
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.Wp + (size_t)(woff + (unsigned)idx * wstride)), dst, 16, 0, 0);
             if (idx == WI - 1) woff += BK;
         } else {
             const int k = idx - WI;
@@ -295,30 +282,6 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
         const int b_row_off = (wp * 64 + l15) * 128;
         const int koff0 = ((lg ^ (l15 & 7)) << 4), koff1 = (((4 + lg) ^ (l15 & 7)) << 4);
         const int lchunk = ((ln & 7) ^ (ln >> 3)) * 8;
-        if constexpr (CH == 1) {
-            // 16 waves x (64 px x 80 ch) at <= 128 registers: the five channel fragments of a k half stay resident, the
-            // four pixel fragments stream through two registers sets (pixel block j outer, channel block i inner); the
-            // other three waves of the SIMD cover the LDS latency.  Each accumulator still sees k half 0, then k half 1 of
-            // every k step: the same update sequence as the 8-wave form (bit-identical results).
-            half8 a[5], bj[2];
-            int piece = 0;
-#pragma unroll
-            for (int sidx = 0; sidx < 2; ++sidx) {
-                const int ko = sidx ? koff1 : koff0;
-#pragma unroll
-                for (int i = 0; i < 5; ++i) a[i] = *reinterpret_cast<const half8*>(wt + a_row_off + i * 2048 + ko);
-                bj[0] = *reinterpret_cast<const half8*>(xt + b_row_off + ko);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j + 1 < 4) bj[(j + 1) & 1] = *reinterpret_cast<const half8*>(xt + b_row_off + (j + 1) * 2048 + ko);
-#pragma unroll
-                    for (int i = 0; i < 5; ++i)
-                        acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bj[j & 1], acc[0][i][j], 0, 0, 0);
-                    if (piece < NL) { load_piece(cur ^ 1, piece, lchunk); ++piece; }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        } else {
         half8 b0[4], b1[4], a[5];
 #pragma unroll
         for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const half8*>(xt + b_row_off + j * 2048 + koff0);
@@ -347,7 +310,6 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
                 if (piece < NL) { load_piece(cur ^ 1, piece, lchunk); ++piece; }
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
         }
     };
 
@@ -501,9 +463,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
         // previous tile's stores must have drained (they had the epilogue's own run time plus one k step).
         if (first) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         else if (NSTORE == 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
-        else if (NSTORE == 16) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-        else if (NSTORE == 12) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
         first = false;
         // next tile of this block: asked for now (one returning atomic by thread 0), published through LDS (a spare word
         // of the current vector slot) after k step 1's top wait, read by everyone after k step nk - 2  (nk >= 4)
@@ -537,8 +497,8 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
 
 }  // namespace
 
-template <bool LN, int NW>
-static hipError_t launch_igemm_pers_nw(const IGemmParams& p, hipStream_t s) {
+template <bool LN>
+static hipError_t launch_igemm_pers_t(const IGemmParams& p, hipStream_t s) {
     constexpr int TP = 256, TC = 320;
     constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 2 * AUX_BYTES;           // 160 KiB: two operand stages + two vector slots
     const int ntiles = ((p.M + TP - 1) / TP) * (p.Cout / TC);
@@ -553,18 +513,20 @@ static hipError_t launch_igemm_pers_nw(const IGemmParams& p, hipStream_t s) {
     const int grid = ntiles < n_cu[dev & 63] ? ntiles : n_cu[dev & 63];
     static std::atomic<uint64_t> attr_seen{0};      // hipFuncSetAttribute is per DEVICE, not per process
     if (first_use_on_device(attr_seen)) {
-        (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, LN, PX_NONE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_GEGLU, LN, PX_NONE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (!LN) {
-            (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, false, PX_TEMB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, false, PX_RES, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, LN, PX_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_GEGLU, LN, PX_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if constexpr (!LN) {
+            (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, false, PX_TEMB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, false, PX_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         }
     }
-    const dim3 g(grid), b(64 * NW);
-    if (p.epi == EPI_GEGLU) hipLaunchKernelGGL((igemm_pers_kernel<EPI_GEGLU, LN, PX_NONE, NW>), g, b, lds, s, p, ntiles);
-    else if (!LN && p.temb) hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_TEMB, NW>), g, b, lds, s, p, ntiles);
-    else if (!LN && p.res) hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_RES, NW>), g, b, lds, s, p, ntiles);
-    else hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, LN, PX_NONE, NW>), g, b, lds, s, p, ntiles);
+    const dim3 g(grid), b(512);
+    if (p.epi == EPI_GEGLU) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_GEGLU, LN, PX_NONE>), g, b, lds, s, p, ntiles); return hipGetLastError(); }
+    if constexpr (!LN) {        // the folded-LayerNorm layers never carry a time embedding or a residual (igemm_pers_ok)
+        if (p.temb) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_TEMB>), g, b, lds, s, p, ntiles); return hipGetLastError(); }
+        if (p.res) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_RES>), g, b, lds, s, p, ntiles); return hipGetLastError(); }
+    }
+    hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, LN, PX_NONE>), g, b, lds, s, p, ntiles);
     return hipGetLastError();
 }
 
