@@ -40,19 +40,23 @@ namespace {
 
 constexpr int BK = 64;
 
-// erf-GELU x * Phi(x): see igemm_big_tile.h (Abramowitz-Stegun 7.1.26, |erf error| < 1.5e-7)
+// erf-GELU  x * Phi(x) = max(x, 0) - |x| * T(|x|),  T(a) = 0.5 * (1 - erf(a / sqrt 2)) by Abramowitz-Stegun 7.1.26
+// (|erf error| < 1.5e-7; measured over all 63 488 finite fp16 inputs: max |error| 3.3e-7, i.e. far below the fp16
+// rounding of the result): 1 rcp + 1 exp2 + 12 plain VALU instead of libm erff (~40 instructions), which dominated the
+// GEGLU epilogue (40 calls per lane per 256 x 320 tile).  The tail T is formed directly (no 1 - 1 cancellation for
+// negative x), the 0.5 lives in the coefficients and 1 / sqrt 2 in the constants, and the max / |x| form needs no
+// compare-and-select (r02: -2..3 % on the GEGLU launches against the x * (x < 0 ? T : 1 - T) form; a fused-multiply-add
+// form and an inline-asm max measured the same).
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float ax = __builtin_fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
-    float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
-    poly = __builtin_fmaf(t, poly, 1.421413741f);
-    poly = __builtin_fmaf(t, poly, -0.284496736f);
-    poly = __builtin_fmaf(t, poly, 0.254829592f);
+    const float ax = __builtin_fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    float poly = __builtin_fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+    poly = __builtin_fmaf(t, poly, 0.5f * 1.421413741f);
+    poly = __builtin_fmaf(t, poly, 0.5f * -0.284496736f);
+    poly = __builtin_fmaf(t, poly, 0.5f * 0.254829592f);
     poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
-    const float half_tail = 0.5f * poly * e;
-    const float phi = (x < 0.f) ? half_tail : 1.0f - half_tail;
-    return x * phi;
+    const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170368f);        // exp(-x^2 / 2)
+    return __builtin_fmaxf(x, 0.f) - ax * (poly * e);
 }
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page_pers[1024];
