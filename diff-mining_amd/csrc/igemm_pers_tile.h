@@ -66,6 +66,14 @@ __device__ __attribute__((aligned(256))) unsigned char g_store_sink[8 * 64 * 16]
 // an engine is single-stream; __device__ storage is per device).  Static striding lost 3-5 % to the slowest CU.
 __device__ int g_tile_ctr[8 * 32];            // [xcd * 32] (128 bytes apart)
 __device__ int g_tile_done;
+#ifdef DM_IGEMM_TIMING
+// phase timers of one block (tools/igemm_timing.py): [0] k-step bodies, [1] waits at the top of k steps, [2] epilogue,
+// [3] tile switch (zeroing, first wait), [4] tiles, in shader cycles of wave 0
+__device__ long long g_pers_dbg[8];
+#define PTICK(i) do { const long long _n = (long long)__builtin_readcyclecounter(); dbg[i] += _n - tlast; tlast = _n; } while (0)
+#else
+#define PTICK(i) do {} while (0)
+#endif
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -449,6 +457,10 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
     }
     prepare();
 
+#ifdef DM_IGEMM_TIMING
+    long long dbg[5] = {0, 0, 0, 0, 0};
+    long long tlast = (long long)__builtin_readcyclecounter();
+#endif
     int g = 0;                        // global k step of the stream: stage = g & 1
     int slot = 0;
     bool first = true;
@@ -469,6 +481,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
         else if (NSTORE == 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
         first = false;
+        PTICK(3);
         // next tile of this block: asked for now (one returning atomic by thread 0), published through LDS (a spare word
         // of the current vector slot) after k step 1's top wait, read by everyone after k step nk - 2  (nk >= 4)
         int ticket = 0;
@@ -478,6 +491,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
         for (int kt = 0; kt < nk; ++kt) {
             step(g & 1);                                   // computes stream step g, requests stream step g + 1
             ++g;
+            PTICK(0);
             // sources of stream step g + 1 (two ahead of the one just computed): from k step nk - 2 on they belong
             // to the next tile (without one the block re-requests its own first k steps: valid addresses, unused)
             if (kt == nk - 2) {
@@ -489,14 +503,23 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
             }
             prepare();
             if (kt < nk - 1) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            PTICK(1);
             if (kt == 0 && threadIdx.x == 0) *reinterpret_cast<volatile int*>(aux0 + slot * AUX_BYTES + 1020) = ticket;
         }
         epilogue(p0, c0out, slot);
+        PTICK(2);
+#ifdef DM_IGEMM_TIMING
+        dbg[4] += 1;
+#endif
         if (!has_next) break;
         tile = next;
         slot ^= 1;
     }
     finish();
+#ifdef DM_IGEMM_TIMING
+    if (blockIdx.x == 77 && threadIdx.x == 0)
+        for (int i = 0; i < 5; ++i) g_pers_dbg[i] = dbg[i];
+#endif
 }
 
 }  // namespace
