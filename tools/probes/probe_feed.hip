@@ -86,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void feed_vgpr_kernel(const _Float16* __res
 // wave.  RD / MF = 0 removes that activity (operands then come from registers).
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
-template <int DMA, int RD, int MF>
+template <int DMA, int RD, int MF, int ROT = 0>
 __global__ __launch_bounds__(512, 2) void mix_kernel(const _Float16* __restrict__ Wp, const _Float16* __restrict__ X, int K, int C, int nk,
                                                      int tiles_c, unsigned* sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -120,7 +120,10 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const _Float16* __restrict_
             }
             if (DMA && piece < NL && (g & 1) == 0) {
                 const int i = piece++;
-                const _Float16* src = (i < WI) ? wsrc + (size_t)i * NW * 8 * K + ((kt + 1) % nk) * 64 : xsrc + (size_t)(i - WI) * NW * 8 * C + ko;
+                // ROT: every block walks the weight k slabs from its own starting point, so the CUs of an XCD do not ask
+                // the L2 for the same weight lines at the same moment
+                const int kw = ROT ? ((kt + 1 + (int)blockIdx.x * ROT) % nk) : ((kt + 1) % nk);
+                const _Float16* src = (i < WI) ? wsrc + (size_t)i * NW * 8 * K + kw * 64 : xsrc + (size_t)(i - WI) * NW * 8 * C + ko;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + (wid + i * NW) * 1024), 16, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -224,6 +227,9 @@ int main() {
     runm("MFMA + DMA", mix_kernel<1, 0, 1>);
     runm("fragment reads + DMA", mix_kernel<1, 1, 0>);
     runm("MFMA + fragment reads + DMA", mix_kernel<1, 1, 1>);
+    runm("DMA only, weight k order rotated per block (+7)", mix_kernel<1, 0, 0, 7>);
+    runm("MFMA + reads + DMA, rotated (+7)", mix_kernel<1, 1, 1, 7>);
+    runm("MFMA + reads + DMA, rotated (+1)", mix_kernel<1, 1, 1, 1>);
     runm("32x32x16: MFMA only", mix32_kernel<0, 0>);
     runm("32x32x16: MFMA + fragment reads", mix32_kernel<0, 1>);
     runm("32x32x16: MFMA + DMA", mix32_kernel<1, 0>);
