@@ -62,10 +62,12 @@ __device__ __forceinline__ float gelu_erf(float x) {
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page_pers[1024];
 __device__ __attribute__((aligned(256))) unsigned char g_store_sink[8 * 64 * 16];      // one 16-byte slot per (wave, lane)
 // Dynamic tile hand-out: one counter per XCD (its blocks share an L2, so an XCD keeps its contiguous tile range) +
-// one completion counter; the last block to finish resets them for the next launch (launches are stream-ordered and
-// an engine is single-stream; __device__ storage is per device).  Static striding lost 3-5 % to the slowest CU.
-__device__ int g_tile_ctr[8 * 32];            // [xcd * 32] (128 bytes apart)
-__device__ int g_tile_done;
+// one completion counter; the last block to finish resets them.  A launch takes the next of CSETS counter sets (host
+// side round robin per process), so launches that overlap on different streams do not share counters; __device__
+// storage is per device.  Static striding lost 3-5 % to the slowest CU.
+constexpr int CSETS = 64;
+__device__ int g_tile_ctr[CSETS][8 * 32];     // [set][xcd * 32] (128 bytes apart)
+__device__ int g_tile_done[CSETS];
 #ifdef DM_IGEMM_TIMING
 // phase timers of one block (tools/igemm_timing.py): [0] k-step bodies, [1] waits at the top of k steps, [2] epilogue,
 // [3] tile switch (zeroing, first wait), [4] tiles, in shader cycles of wave 0
@@ -118,7 +120,7 @@ enum { PX_NONE = 0, PX_TEMB = 1, PX_RES = 2 };
 // same block tile — 64 x 80 wave tiles, <= 128 registers — was measured 1-5 % slower in r02: DESIGN.md §4b.)
 template <int EPI, bool LN, int EXTRA>
 __global__ __launch_bounds__(512, 2)
-void igemm_pers_kernel(IGemmParams p, int ntiles) {
+void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
     constexpr int WC = 2, CH = 2, NW = 8;
     constexpr int TP = 256, TC = 320;
     constexpr int WBYTES = TC * 128, XBYTES = TP * 128, STAGE = WBYTES + XBYTES;
@@ -149,10 +151,10 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
     }
     auto finish = [&]() __attribute__((always_inline)) {
         if (threadIdx.x == 0) {
-            if (atomicAdd(&g_tile_done, 1) == (int)gridDim.x - 1) {
+            if (atomicAdd(&g_tile_done[cset], 1) == (int)gridDim.x - 1) {
 #pragma unroll
-                for (int x = 0; x < 8; ++x) g_tile_ctr[x * 32] = 0;
-                g_tile_done = 0;
+                for (int x = 0; x < 8; ++x) g_tile_ctr[cset][x * 32] = 0;
+                g_tile_done[cset] = 0;
                 __threadfence();
             }
         }
@@ -485,7 +487,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles) {
         // next tile of this block: asked for now (one returning atomic by thread 0), published through LDS (a spare word
         // of the current vector slot) after k step 1's top wait, read by everyone after k step nk - 2  (nk >= 4)
         int ticket = 0;
-        if (threadIdx.x == 0) ticket = atomicAdd(&g_tile_ctr[xcd * 32], 1);
+        if (threadIdx.x == 0) ticket = atomicAdd(&g_tile_ctr[cset][xcd * 32], 1);
         int next = 0;
         bool has_next = false;
         for (int kt = 0; kt < nk; ++kt) {
@@ -547,13 +549,15 @@ static hipError_t launch_igemm_pers_t(const IGemmParams& p, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, false, PX_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         }
     }
+    static std::atomic<unsigned> launch_no{0};
+    const int cset = (int)(launch_no.fetch_add(1) % CSETS);
     const dim3 g(grid), b(512);
-    if (p.epi == EPI_GEGLU) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_GEGLU, LN, PX_NONE>), g, b, lds, s, p, ntiles); return hipGetLastError(); }
+    if (p.epi == EPI_GEGLU) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_GEGLU, LN, PX_NONE>), g, b, lds, s, p, ntiles, cset); return hipGetLastError(); }
     if constexpr (!LN) {        // the folded-LayerNorm layers never carry a time embedding or a residual (igemm_pers_ok)
-        if (p.temb) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_TEMB>), g, b, lds, s, p, ntiles); return hipGetLastError(); }
-        if (p.res) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_RES>), g, b, lds, s, p, ntiles); return hipGetLastError(); }
+        if (p.temb) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_TEMB>), g, b, lds, s, p, ntiles, cset); return hipGetLastError(); }
+        if (p.res) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_RES>), g, b, lds, s, p, ntiles, cset); return hipGetLastError(); }
     }
-    hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, LN, PX_NONE>), g, b, lds, s, p, ntiles);
+    hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, LN, PX_NONE>), g, b, lds, s, p, ntiles, cset);
     return hipGetLastError();
 }
 

@@ -45,7 +45,7 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def op_igemm(X, W, bias=None, X2=None, temb=None, res=None, mode=0, epi=0, OH=None, OW=None):
+def op_igemm(X, W, bias=None, X2=None, temb=None, res=None, mode=0, epi=0, OH=None, OW=None, sync=True):
     """X [N,H,W,C1] fp16 cuda; W packed [Cout, taps*Cin] fp16 cuda -> Y [N,OH,OW,Cout(/2)]"""
     lib = E.load_library()
     N, H, Wd, C1 = X.shape
@@ -58,7 +58,8 @@ def op_igemm(X, W, bias=None, X2=None, temb=None, res=None, mode=0, epi=0, OH=No
     rc = lib.dm_op_igemm(stream(), ptr(X), ptr(X2), ptr(W), ptr(bias), ptr(temb), ptr(res), ptr(Y),
                          N, H, Wd, C1, C2, Cout, OH, OW, mode, epi, temb.stride(0) if temb is not None else 0)
     assert rc == 0, "dm_op_igemm failed"
-    torch.cuda.synchronize()
+    if sync:
+        torch.cuda.synchronize()
     return Y
 
 

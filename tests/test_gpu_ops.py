@@ -433,3 +433,36 @@ def test_persistent_tile_fuzz_against_128_row_tile():
     finally:
         lib.dm_set_option(b"igemm_big", -1)
     assert n_pers >= 20
+
+
+def test_persistent_tile_launches_overlapping_on_two_streams():
+    """Two streams each issue a chain of persistent-tile launches with no synchronisation between the streams, so
+    launches overlap on the device (each is 40-320 tiles, well under a full chip).  Every launch takes its own set of
+    tile counters, so each result equals the serial one bit for bit."""
+    d = U.dev()
+    g = torch.Generator(device="cuda").manual_seed(5)
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g, device=d, dtype=torch.float32) * scale).half()
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    cases = []
+    for M, K, Cout in [(10240, 640, 640), (40960, 320, 320), (20480, 1280, 1280), (81920, 320, 640)]:
+        cases.append((rnd(1, 1, M, K), rnd(Cout, K, scale=K ** -0.5), rnd(Cout, scale=0.1)))
+    try:
+        assert lib.dm_set_option(b"igemm_big", 1) == 0
+        for x, w, b in cases:
+            assert lib.dm_op_igemm_tile(x.shape[2], x.shape[3], w.shape[0], 0) == 1
+        serial = [U.op_igemm(x, w, b) for x, w, b in cases]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        torch.cuda.synchronize()
+        outs = []
+        for rep in range(6):
+            for i, (x, w, b) in enumerate(cases):
+                with torch.cuda.stream(streams[(i + rep) % 2]):
+                    outs.append((i, U.op_igemm(x, w, b, sync=False)))
+        torch.cuda.synchronize()
+    finally:
+        lib.dm_set_option(b"igemm_big", -1)
+    for i, y in outs:
+        assert torch.equal(y, serial[i]), i
