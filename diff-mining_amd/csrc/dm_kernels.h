@@ -19,9 +19,22 @@ inline bool first_use_on_device(std::atomic<uint64_t>& seen) {
     return (seen.fetch_or(bit) & bit) == 0;
 }
 
+// compute units of the current device (cached per device ordinal)
+inline int device_cu_count() {
+    static std::atomic<int> n_cu[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int v = n_cu[dev & 63].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n_cu[dev & 63].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 // Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of
 // the same name in upper case with a DM_ prefix (DM_IGEMM_PERSIST=0 ...), changeable through dm_set_option().
-enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_COUNT };
+enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_COUNT };
 int option(Option o);                       // engine.hip
 int set_option(const char* name, int value);   // 0 on success
 
@@ -58,7 +71,8 @@ hipError_t launch_igemm(const IGemmParams& p, hipStream_t s);
 // number of k parts for a layer with `spatial` output positions per sample (1 = no split); batch independent;
 // the caller provides the workspace
 int igemm_splitk_parts(const IGemmParams& p, int spatial);
-int igemm_tile_choice(const IGemmParams& p);     // 0 = 128-row tile, 1 = 256 x 320 tile
+int igemm_tile_choice(const IGemmParams& p);     // 0 = 128-row tile, 1 = 256 x 320 tile (for all rows or the leading full rounds)
+int igemm_head_rows(const IGemmParams& p);       // rows [0, r) run on the 256 x 320 tile, rows [r, M) on the 128-row tile
 // shapes the persistent 256 x 320 tile (igemm_pers_tile.h) takes; the others run on the 128-row tile of igemm_tile.h
 // (bit-identical results): >= 4 k steps, a time embedding only when every 256-row tile lies
 // inside one sample, never a time embedding and a residual together

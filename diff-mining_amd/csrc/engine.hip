@@ -976,7 +976,7 @@ namespace {
 struct OptDef { const char* name; const char* env; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
-    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1},
+    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<int> g_opt_init{0};
@@ -1710,6 +1710,14 @@ int dm_op_igemm_tile(int M, int Cin, int Cout, int mode) {
     p.M = M; p.Cin = Cin; p.C1 = Cin; p.Cout = Cout; p.mode = mode; p.epi = EPI_PLAIN;
     p.OH = 1; p.OW = M > 511 ? 256 : (M > 0 ? M : 1);      // spatial extent unknown here: any value inside the kernel's coordinate range
     return igemm_tile_choice(p);
+}
+
+int dm_op_igemm_head_rows(int M, int spatial, int Cin, int Cout, int mode) {
+    IGemmParams p{};
+    p.M = M; p.Cin = Cin; p.C1 = Cin; p.Cout = Cout; p.mode = mode; p.epi = EPI_PLAIN;
+    p.OH = 1; p.OW = mode == IG_DENSE ? (M > 0 ? M : 1) : (spatial > 0 ? spatial : 1);
+    p.H = 1; p.W = p.OW;
+    return igemm_head_rows(p);
 }
 
 int dm_op_attention(void* stream, const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv,

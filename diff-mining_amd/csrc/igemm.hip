@@ -35,7 +35,7 @@ hipError_t launch_igemm_pers_ln(const IGemmParams& p, hipStream_t s);  // igemm_
 // persistent 256 x 320 tile (igemm_pers_tile.h: 13.8 instead of 21.9 LDS-DMA bytes per kMAC, no per-tile prologue, stores
 // draining under the next tile) wins or ties on every U-Net shape that gives it >= 2 tiles per CU — -12 % on the
 // 320-channel q/k/v projections, -5..8 % on the 320-channel 3x3 convolutions, -7 % on ff.net.2 at 16x16, -3 % on the
-// 1280-channel projections — except the plain 1280 -> 1280 3x3 convolutions at 16x16 (640 tiles = 2.5 per CU: +2 %).
+// 1280-channel projections — as long as its tiles fill whole rounds over the CUs; head_rows() below deals with the rest.
 // The choice depends on the batch size through the tile count; the two kernels are bit-identical
 // (tests/test_gpu_ops.py::test_persistent_tile_is_bit_identical), so a sample's result does not.
 static bool use_big(const IGemmParams& p) {
@@ -43,9 +43,7 @@ static bool use_big(const IGemmParams& p) {
     if (p.Cout % 320 != 0 || !igemm_pers_ok(p)) return false;
     if (force >= 0) return force != 0;
     const long long tiles = (long long)((p.M + 255) / 256) * (p.Cout / 320);
-    if (tiles < 512) return false;
-    if (p.mode == IG_CONV3 && tiles < 1024 && p.Cin <= 1280) return false;
-    return true;
+    return tiles >= 2LL * device_cu_count();
 }
 
 // Layers at <= 8x8 spatial positions per sample (M = 10 240 rows at the bench batch: 320 tiles for 256 CUs):
@@ -62,22 +60,103 @@ int igemm_splitk_parts(const IGemmParams& p, int spatial) {
     return 1;
 }
 
-// which tile geometry launch_igemm picks for a plain (no LN fold, no split-K) shape: 0 = 128-row, 1 = 256 x 320
+// Rows [r0, r1) of a launch as a launch of its own.  Dense rows are independent; for the convolution modes both cuts
+// must lie on sample boundaries (multiples of OH*OW), so every pointer moves by whole samples.
+static IGemmParams row_range(const IGemmParams& p, int r0, int r1) {
+    IGemmParams q = p;
+    const int C2 = p.Cin - p.C1;
+    q.M = r1 - r0;
+    q.Y = p.Y + (size_t)r0 * p.ldy;
+    if (p.res) q.res = p.res + (size_t)r0 * p.ldres;
+    if (p.ln_stats) q.ln_stats = p.ln_stats + (size_t)r0 * 2;
+    if (p.mode == IG_DENSE) {
+        q.X = p.X + (size_t)r0 * p.C1;
+        if (p.X2) q.X2 = p.X2 + (size_t)r0 * C2;
+        q.W = q.OW = q.M;
+    } else {
+        const size_t n0 = (size_t)r0 / ((size_t)p.OH * p.OW), src = (size_t)p.H * p.W;
+        q.X = p.X + n0 * src * p.C1;
+        if (p.X2) q.X2 = p.X2 + n0 * src * C2;
+        if (p.temb) q.temb = p.temb + n0 * p.temb_ld;
+    }
+    return q;
+}
+
+// Tile quantisation: a launch whose 256 x 320 tiles do not fill a whole number of rounds over the CUs (640 tiles on
+// 256 CUs = 2.5 rounds: every 16x16-level layer at the bench batch) keeps the full rounds on the persistent kernel and
+// hands the remaining rows to the 128-row tile (half the rows per tile = twice the blocks for the last, partial
+// round).  Both kernels give the same bits, so the cut only moves time.  Returns the first row of the tail (a multiple of
+// 256 and, for the convolutions, of OH*OW), 0 = everything on the 128-row tile, M = everything on the persistent tile.
+// Cost model in units of one round of 256 x 320 tiles; a round of 128-row tiles is measured at 0.59-0.62 of that on
+// the long-k shapes and ~0.68 on the short ones (per-tile prologue and LDS-staged epilogue).  Measured at the bench
+// batch (tools/ab_igemm.py igemm_tail 0 1 @16, profiles/r02_ab_head_tail.txt): -6..-9 % on every 1280-channel
+// convolution / projection / shortcut at 16x16, +-0 where the rounds are whole.
+static int head_rows(const IGemmParams& p) {
+    const int force = option(OPT_IGEMM_BIG);
+    if (p.Cout % 320 != 0 || !igemm_pers_ok(p)) return 0;
+    if (force >= 0) return force ? p.M : 0;
+    if (!use_big(p) && !option(OPT_IGEMM_TAIL)) return 0;
+    if (!option(OPT_IGEMM_TAIL)) return p.M;
+    const int n_cu = device_cu_count(), tc = p.Cout / 320;
+    const long long rt = (p.M + 255) / 256, tiles = rt * tc;
+    const long long rounds_full = tiles / n_cu;
+    const int nk = ((p.mode == IG_DENSE) ? 1 : 9) * (p.Cin / BK);
+    const double rho = nk >= 32 ? 0.62 : 0.68;
+    const long long small_tiles = (long long)((p.M + 127) / 128) * tc;
+    const double cost_big = (double)((tiles + n_cu - 1) / n_cu);
+    const double cost_small = rho * (double)((small_tiles + n_cu - 1) / n_cu);
+    double best = use_big(p) ? cost_big : cost_small;
+    int best_rows = use_big(p) ? p.M : 0;
+    if (rounds_full >= 2 && tiles % n_cu != 0) {
+        long long unit = 256;                                   // rows per cut step: whole tiles and whole samples
+        if (p.mode != IG_DENSE) {
+            const long long ohw = (long long)p.OH * p.OW;
+            if (256 % ohw == 0) unit = 256; else if (ohw % 256 == 0) unit = ohw; else unit = 0;
+        } else if (p.temb) unit = 0;
+        if (unit) {
+            long long head = (rounds_full * n_cu / tc) * 256 / unit * unit;        // rows
+            if (head > 0 && head < p.M) {
+                const IGemmParams h = row_range(p, 0, (int)head);
+                const long long head_tiles = head / 256 * tc, tail_tiles = (long long)((p.M - head + 127) / 128) * tc;
+                const double cost = (double)((head_tiles + n_cu - 1) / n_cu) + rho * (double)((tail_tiles + n_cu - 1) / n_cu);
+                if (igemm_pers_ok(h) && cost < best - 0.05) { best = cost; best_rows = (int)head; }
+            }
+        }
+    }
+    return best_rows;
+}
+
+// which tile geometry launch_igemm picks for a plain (no split-K) shape: 0 = 128-row, 1 = 256 x 320 (for all or for the
+// leading full rounds of the rows)
 int igemm_tile_choice(const IGemmParams& p) {
     if (p.Cout % 160 != 0 || p.mode == IG_CONV3_S2P0) return 0;
-    return use_big(p) ? 1 : 0;
+    return head_rows(p) > 0 ? 1 : 0;
+}
+
+int igemm_head_rows(const IGemmParams& p) {
+    if (p.Cout % 160 != 0 || p.mode == IG_CONV3_S2P0) return 0;
+    return head_rows(p);
+}
+
+static hipError_t launch_small(const IGemmParams& p, hipStream_t s) {
+    if (p.ln_stats) return launch_igemm_tile_ln(p, s);
+    return (p.Cout % 320 == 0) ? launch_t<4, 5>(p, s) : launch_t<2, 5>(p, s);
 }
 
 hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
     if (p.ksplit > 1 && p.partial) return launch_igemm_splitk(p, s);
     if (p.ln_stats) {
         if (!p.ln_s || !p.ln_t || p.Cout % 160 != 0) return hipErrorInvalidValue;
-        return use_big(p) ? launch_igemm_pers_ln(p, s) : launch_igemm_tile_ln(p, s);
+    } else {
+        if (p.Cout % 160 != 0 || p.mode == IG_CONV3_S2P0) return launch_igemm64(p, s);        // VAE channel counts
+        if (p.Cin % BK != 0 || p.C1 % BK != 0 || p.M <= 0) return hipErrorInvalidValue;
     }
-    if (p.Cout % 160 != 0 || p.mode == IG_CONV3_S2P0) return launch_igemm64(p, s);        // VAE channel counts
-    if (p.Cout % 160 != 0 || p.Cin % BK != 0 || p.C1 % BK != 0 || p.M <= 0) return hipErrorInvalidValue;
-    if (use_big(p)) return launch_igemm_pers(p, s);
-    return (p.Cout % 320 == 0) ? launch_t<4, 5>(p, s) : launch_t<2, 5>(p, s);
+    const int head = head_rows(p);
+    if (head <= 0) return launch_small(p, s);
+    const IGemmParams h = head < p.M ? row_range(p, 0, head) : p;
+    const hipError_t rc = p.ln_stats ? launch_igemm_pers_ln(h, s) : launch_igemm_pers(h, s);
+    if (rc != hipSuccess || head >= p.M) return rc;
+    return launch_small(row_range(p, head, p.M), s);
 }
 
 }  // namespace dm

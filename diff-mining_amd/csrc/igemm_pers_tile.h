@@ -531,15 +531,8 @@ static hipError_t launch_igemm_pers_t(const IGemmParams& p, hipStream_t s) {
     constexpr int TP = 256, TC = 320;
     constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 2 * AUX_BYTES;           // 160 KiB: two operand stages + two vector slots
     const int ntiles = ((p.M + TP - 1) / TP) * (p.Cout / TC);
-    static int n_cu[64] = {0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (n_cu[dev & 63] == 0) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        n_cu[dev & 63] = v;
-    }
-    const int grid = ntiles < n_cu[dev & 63] ? ntiles : n_cu[dev & 63];
+    const int n_cu = device_cu_count();
+    const int grid = ntiles < n_cu ? ntiles : n_cu;
     static std::atomic<uint64_t> attr_seen{0};      // hipFuncSetAttribute is per DEVICE, not per process
     if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, LN, PX_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -24,7 +24,7 @@ SYMBOLS = [
     "dm_op_igemm", "dm_op_attention", "dm_op_groupnorm", "dm_op_layernorm",
     "dm_engine_load_vae_weight", "dm_engine_finalize_vae", "dm_vae_encode", "dm_op_attention512", "dm_patch_embed",
     "dm_engine_load_clip_weight", "dm_engine_finalize_clip", "dm_clip_encode", "dm_op_igemm_splitk",
-    "dm_op_ln_stats", "dm_op_igemm_ln", "dm_reduce_typicality_batched", "dm_op_igemm_tile", "dm_set_option",
+    "dm_op_ln_stats", "dm_op_igemm_ln", "dm_reduce_typicality_batched", "dm_op_igemm_tile", "dm_op_igemm_head_rows", "dm_set_option",
 ]
 
 

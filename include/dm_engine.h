@@ -216,12 +216,15 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
                 const void* res, void* Y, int N, int H, int W, int C1, int C2, int Cout, int OH, int OW,
                 int mode, int epi, int temb_ld);
 /* Runtime switches for A/B measurements (process-wide; each defaults to the measured best and is initialised from the
- * environment variable DM_<NAME>): "igemm_big" (-1 per shape / 0 / 1), "igemm_splitk", "ln_fold", "attn_pipe" (0 / 1).  None of them changes a result bit, except ln_fold (LayerNorm folded into the next GEMM).
+ * environment variable DM_<NAME>): "igemm_big" (-1 per shape / 0 / 1), "igemm_splitk", "ln_fold", "attn_pipe", "igemm_tail" (0 / 1).  None of them changes a result bit, except ln_fold (LayerNorm folded into the next GEMM).
  * Returns nonzero for an unknown name. */
 int dm_set_option(const char* name, int value);
 
 /* which tile geometry dm_op_igemm runs a shape on: 0 = 128-row tile (128x320 / 128x160), 1 = persistent 256x320 tile */
 int dm_op_igemm_tile(int M, int Cin, int Cout, int mode);
+/* rows [0, r) of such a launch run on the persistent 256x320 tile (whole rounds over the CUs), rows [r, M) on the
+ * 128-row tile ("igemm_tail"; r = 0 / M: one kernel for all rows).  `spatial` = OH*OW of one sample (ignored for mode 0). */
+int dm_op_igemm_head_rows(int M, int spatial, int Cin, int Cout, int mode);
 int dm_op_attention(void* stream, const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv,
                     int ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso, const int32_t* kv_slot,
                     int B, int heads, int Tq, int Tk, int D, float scale);

@@ -466,3 +466,63 @@ def test_persistent_tile_launches_overlapping_on_two_streams():
         lib.dm_set_option(b"igemm_big", -1)
     for i, y in outs:
         assert torch.equal(y, serial[i]), i
+
+
+@pytest.mark.parametrize("case", ["conv_temb", "conv_cat_res", "conv_150_samples", "dense_res_ragged", "ln_plain", "conv_8x8"])
+def test_head_tail_split_is_bit_identical(case):
+    """640 tiles of 256 x 320 on 256 CUs are 2.5 rounds: launch_igemm keeps the two full rounds on the persistent kernel
+    and runs the remaining rows on the 128-row tile (`igemm_tail`).  The cut lies on a tile and sample boundary and both
+    kernels give the same bits, so the result equals the single-kernel one; `dm_op_igemm_head_rows` reports the cut."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    g = torch.Generator(device="cuda").manual_seed(17)
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g, device=d, dtype=torch.float32) * scale).half()
+    N, H, W, C1, C2, Cout, mode, temb, res, ln = {
+        "conv_temb": (160, 16, 16, 1280, 0, 1280, 1, True, False, False),
+        "conv_cat_res": (160, 16, 16, 640, 640, 1280, 1, False, True, False),
+        "conv_150_samples": (150, 16, 16, 640, 0, 1280, 1, True, False, False),
+        "dense_res_ragged": (1, 1, 40960 - 100, 1280, 0, 1280, 0, False, True, False),
+        "ln_plain": (1, 1, 40960, 1280, 0, 1280, 0, False, False, True),
+        "conv_8x8": (640, 8, 8, 640, 0, 1280, 1, True, False, False),
+    }[case]
+    taps = 9 if mode else 1
+    M = N * H * W
+    head = lib.dm_op_igemm_head_rows(M, H * W, C1 + C2, Cout, mode)
+    if n_cu == 256:
+        assert 0 < head < M and head % 256 == 0 and head % (H * W if mode else 256) == 0, head
+        assert (head // 256) * (Cout // 320) % n_cu == 0
+    x = rnd(N, H, W, C1)
+    x2 = rnd(N, H, W, C2, scale=0.5) if C2 else None
+    w = rnd(Cout, taps * (C1 + C2), scale=(taps * (C1 + C2)) ** -0.5)
+    b = rnd(Cout, scale=0.1)
+    tb = rnd(N, Cout) if temb else None
+    rs = rnd(N, H, W, Cout) if res else None
+    if ln:
+        ln_s = w.float().sum(1).contiguous()
+        ln_t = (torch.randn(Cout, generator=g, device=d) * 0.1).contiguous()
+        stats = torch.empty(M, 2, dtype=torch.float32, device=d)
+        assert lib.dm_op_ln_stats(U.stream(), U.ptr(x), M, C1, 1e-5, U.ptr(stats)) == 0
+
+    def run():
+        if ln:
+            y = torch.full((M, Cout), float("nan"), dtype=torch.float16, device=d)
+            assert lib.dm_op_igemm_ln(U.stream(), U.ptr(x), U.ptr(w), U.ptr(ln_s), U.ptr(ln_t), U.ptr(stats), U.ptr(y), M, C1, Cout, 0) == 0
+            torch.cuda.synchronize()
+            return y
+        return U.op_igemm(x, w, b, X2=x2, temb=tb, res=rs, mode=mode)
+    try:
+        y_split = run()
+        assert lib.dm_set_option(b"igemm_tail", 0) == 0
+        assert lib.dm_op_igemm_head_rows(M, H * W, C1 + C2, Cout, mode) in (0, M)
+        y_one = run()
+        assert lib.dm_set_option(b"igemm_big", 0) == 0
+        y_small = run()
+    finally:
+        lib.dm_set_option(b"igemm_tail", 1)
+        lib.dm_set_option(b"igemm_big", -1)
+    assert not torch.isnan(y_split.float()).any()
+    assert torch.equal(y_split, y_one) and torch.equal(y_split, y_small)

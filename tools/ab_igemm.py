@@ -2,7 +2,8 @@
 """A/B of a runtime switch (dm_set_option) on the U-Net's igemm shapes at the bench batch, both arms in ONE process on ONE
 box, interleaved (box-to-box and run-to-run spread is +-2-3 %, more than most kernel changes):
 
-    python tools/ab_igemm.py igemm_big 0 1                # option, value A, value B (here: 128-row tile vs persistent 256 x 320)
+    python tools/ab_igemm.py igemm_big 0 1 [substr]       # option, value A, value B (here: 128-row tile vs persistent 256 x 320);
+                                                          # substr: only the shapes whose name contains it ("@16")
 Shapes: every (mode, M, N, K, epilogue) of a bench step that takes the 256 x 320 tile, with its launches per step."""
 import os
 import sys
@@ -42,6 +43,13 @@ SHAPES = [
     ("proj 1280->1280 @16 res", 20, 0, 16, 16, 1280, 0, 1280, 0, "res"),
     ("ff2 5120->1280 @16 res", 5, 0, 16, 16, 5120, 0, 1280, 0, "res"),
     ("down 3x3 s2 320->320 @64->32", 1, 2, 64, 64, 320, 0, 320, 0, ""),
+    # the rest of the 16x16 level (640 tiles of 256 x 320 at the bench batch = 2.5 rounds: "igemm_tail")
+    ("conv1 3x3 cat 1280+640->1280 @16", 1, 1, 16, 16, 1280, 640, 1280, 0, "temb"),
+    ("conv1 3x3 640->1280 @16 temb", 1, 1, 16, 16, 640, 0, 1280, 0, "temb"),
+    ("qkv 1280->3840 @16 ln", 5, 0, 16, 16, 1280, 0, 3840, 0, "ln"),
+    ("q2 1280->1280 @16 ln", 5, 0, 16, 16, 1280, 0, 1280, 0, "ln"),
+    ("shortcut 1x1 cat 1280+1280->1280 @16", 2, 0, 16, 16, 1280, 1280, 1280, 0, ""),
+    ("shortcut 1x1 640->1280 @16", 1, 0, 16, 16, 640, 0, 1280, 0, ""),
 ]
 
 
@@ -53,7 +61,10 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(1)
     print(f"# {opt}: A = {va}, B = {vb}; batch {B}; ms per launch (min of 3 interleaved rounds of {iters})")
     tot = [0.0, 0.0]
+    only = sys.argv[4] if len(sys.argv) > 4 else ""
     for name, n, mode, H, W, C1, C2, Cout, epi, extra in SHAPES:
+        if only and only not in name:
+            continue
         taps = 1 if mode == 0 else 9
         Cin = C1 + C2
         OH, OW = (H, W) if mode in (0, 1) else ((H // 2, W // 2) if mode == 2 else (2 * H, 2 * W))
