@@ -202,7 +202,7 @@ def main():
                        "parallelism": f"image-sharded x{world}, one all-gather of T(x|c)"},
             "roofline": {"bound": "mfma", "kernel": "igemm family: igemm_pers_kernel (persistent 256x320 tile) + igemm_kernel (128x320 / 128x160 tile) incl. their LayerNorm-folded and split-K instantiations (implicit-GEMM conv3x3/1x1/linear)",
                          "achieved": round(ig_tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ig_tf / PEAK_TFLOPS, 4), "traffic": hbm_traffic_per_launch(),
+                         "frac": round(ig_tf / PEAK_TFLOPS, 4), "traffic": hbm_traffic_per_launch(prof["igemm_launches"] / max(args.steps, 1)),
                          "launches": prof["igemm_launches"], "kernel_ms_total": round(prof["igemm_ms"], 3),
                          "whole_path_tflops": round(executed / step_s / 1e12, 2),
                          "whole_path_frac": round(executed / step_s / 1e12 / PEAK_TFLOPS, 4),
@@ -226,18 +226,17 @@ def main():
         dist.destroy_process_group()
 
 
-def hbm_traffic_per_launch():
-    """HBM bytes per igemm launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per
-    the gfx950 correction, + WRITE_SIZE); rocprofv3 cannot run inside this process, so the number is
-    the recorded one for this kernel build, or None when no record exists."""
-    for name in ("r02_final_pmc.json", "r01_final_pmc.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                k = json.load(f)["kernels"]
-                return round((k.get("igemm_family") or k["igemm_kernel+igemm_big_kernel"])["hbm_bytes_per_launch"])
-        except Exception:
-            continue
-    return None
+def hbm_traffic_per_launch(launches_per_step):
+    """HBM bytes per igemm launch (one launch_igemm call = one GEMM of the network; the head / tail row split makes some
+    of them two kernel dispatches) from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950
+    correction, + WRITE_SIZE): family bytes per step / launches per step.  rocprofv3 cannot run inside this process,
+    so the number is the recorded one for this kernel build, or None when no record exists."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_final_pmc.json")) as f:
+            k = json.load(f)["kernels"]["igemm_family"]
+        return round((k["fetch_GB_per_step"] + k["write_GB_per_step"]) * 1e9 / launches_per_step)
+    except Exception:
+        return None
 
 
 def side_workload(args, eng, dev):

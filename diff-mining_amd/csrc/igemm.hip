@@ -38,12 +38,19 @@ hipError_t launch_igemm_pers_ln(const IGemmParams& p, hipStream_t s);  // igemm_
 // 1280-channel projections — as long as its tiles fill whole rounds over the CUs; head_rows() below deals with the rest.
 // The choice depends on the batch size through the tile count; the two kernels are bit-identical
 // (tests/test_gpu_ops.py::test_persistent_tile_is_bit_identical), so a sample's result does not.
+// full rounds of 256 x 320 tiles a launch must have before the persistent kernel takes them: two (the stream across
+// tiles is what hides the per-tile prologue), one where a tile has >= 40 k steps (3x3 convolutions from 320 channels up,
+// ff.net.2 at 16x16: -6..-13 % at 256 tiles, batch 64; the short-k projections lose up to 20 % there)
+static int min_rounds(const IGemmParams& p) {
+    const int nk = ((p.mode == IG_DENSE) ? 1 : 9) * (p.Cin / BK);
+    return nk >= 40 ? 1 : 2;
+}
 static bool use_big(const IGemmParams& p) {
     const int force = option(OPT_IGEMM_BIG);                 // -1: per shape; 0 / 1: A/B switch for every eligible shape
     if (p.Cout % 320 != 0 || !igemm_pers_ok(p)) return false;
     if (force >= 0) return force != 0;
     const long long tiles = (long long)((p.M + 255) / 256) * (p.Cout / 320);
-    return tiles >= 2LL * device_cu_count();
+    return tiles >= (long long)min_rounds(p) * device_cu_count();
 }
 
 // Layers at <= 8x8 spatial positions per sample (M = 10 240 rows at the bench batch: 320 tiles for 256 CUs):
@@ -107,7 +114,7 @@ static int head_rows(const IGemmParams& p) {
     const double cost_small = rho * (double)((small_tiles + n_cu - 1) / n_cu);
     double best = use_big(p) ? cost_big : cost_small;
     int best_rows = use_big(p) ? p.M : 0;
-    if (rounds_full >= 2 && tiles % n_cu != 0) {
+    if (rounds_full >= min_rounds(p) && tiles % n_cu != 0) {
         long long unit = 256;                                   // rows per cut step: whole tiles and whole samples
         if (p.mode != IG_DENSE) {
             const long long ohw = (long long)p.OH * p.OW;

@@ -14,7 +14,7 @@ import torch  # noqa: E402
 
 from tests import gpu_util as U  # noqa: E402
 
-B = 160
+B = int(os.environ.get("DM_AB_BATCH", "160"))
 # (name, n/step, mode, H, W, C1, C2, Cout, epi, extra)   extra: "" | "temb" | "res" | "ln"
 SHAPES = [
     ("ff1 geglu 320->2560 @64 ln", 5, 0, 64, 64, 320, 0, 2560, 1, "ln"),

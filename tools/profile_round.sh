@@ -18,7 +18,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
         > $OUT/pmc_$i.json 2> $OUT/pmc_$i.err
     i=$((i+1))
 done
-python tools/pmc_to_json.py $OUT 2 > $OUT/pmc.json
+python tools/pmc_to_json.py $OUT 4 > $OUT/pmc.json    # a pass runs 4 steps: 1 warm-up + 1 timed + 2 of the grid-D2H leg
 find $OUT/stats -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
 # raw traces are large; keep only the summaries
 rm -rf $OUT/pmc_[0-9] $OUT/stats
