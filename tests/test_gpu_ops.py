@@ -108,7 +108,7 @@ def test_igemm_geglu():
     U.assert_close_fp16(y.view(M, 4 * Cc), ref, "geglu", rel=3e-3, abs_frac=3e-3)
 
 
-@pytest.mark.parametrize("D,Tq,Tk", [(40, 256, 256), (40, 200, 200), (80, 336, 336), (160, 64, 64), (40, 4096, 4096)])
+@pytest.mark.parametrize("D,Tq,Tk", [(40, 256, 256), (40, 200, 200), (80, 336, 336), (160, 64, 64), (40, 4096, 4096), (80, 1024, 1024), (80, 256, 256)])
 def test_attention_self(D, Tq, Tk):
     heads, B = 8, 2
     Cc = heads * D
@@ -156,6 +156,36 @@ def test_attention_large_logits_online_softmax():
     d = U.dev()
     o = U.op_attention(q.to(d), k.to(d), v.to(d), heads)
     U.assert_close_fp16(o, ref, "attn spike", rel=3e-3, abs_frac=4e-3)
+
+
+@pytest.mark.parametrize("D,Tq,Tk,spike", [(80, 300, 384, None), (80, 130, 512, 400), (40, 300, 384, 300), (80, 4096, 4096, 3000)])
+def test_attention_pipelined_kernels_ragged_queries_and_rescale(D, Tq, Tk, spike):
+    """The software-pipelined kernels (head_dim 40 and 80; Tk % 128 == 0, >= 256) with a query count that is not a
+    multiple of the 128-query block, K/V of another length than Q, and a late dominating key that forces the lazy
+    running-max rescale; checked against fp32 SDPA and against the un-pipelined kernel (`attn_pipe` = 0)."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    heads, B = 8, 2
+    Cc = heads * D
+    q = U.f16_randn(B, Tq, Cc, seed=23)
+    k = U.f16_randn(B, Tk, Cc, seed=24)
+    v = U.f16_randn(B, Tk, Cc, seed=25)
+    if spike is not None:
+        k[:, spike] = q[:, 7] * 4.0
+
+    def split(t, T):
+        return t.float().view(B, T, heads, D).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(split(q, Tq), split(k, Tk), split(v, Tk)).transpose(1, 2).reshape(B, Tq, Cc)
+    d = U.dev()
+    qd, kd, vd = q.to(d), k.to(d), v.to(d)
+    try:
+        o = U.op_attention(qd, kd, vd, heads)
+        assert lib.dm_set_option(b"attn_pipe", 0) == 0
+        o_plain = U.op_attention(qd, kd, vd, heads)
+    finally:
+        lib.dm_set_option(b"attn_pipe", 1)
+    U.assert_close_fp16(o, ref, f"pipelined attn D={D} Tq={Tq} Tk={Tk}", rel=3e-3, abs_frac=4e-3)
+    U.assert_close_fp16(o, o_plain.float().cpu(), f"pipelined vs plain D={D}", rel=3e-3, abs_frac=4e-3)
 
 
 @pytest.mark.parametrize("C1,C2,silu,eps", [(320, 0, True, 1e-5), (640, 0, False, 1e-6), (1280, 640, True, 1e-5),

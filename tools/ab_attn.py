@@ -10,10 +10,10 @@ import torch  # noqa: E402
 
 from tests import gpu_util as U  # noqa: E402
 
-B, HEADS = 160, 8
+B0, HEADS = 160, 8
 # (name, n/step, D, Tq, Tk)   Tk = 77: cross-attention against 2 prompts
 SHAPES = [("cross D40 T4096", 5, 40, 4096, 77), ("cross D80 T1024", 5, 80, 1024, 77), ("cross D160 T256", 5, 160, 256, 77),
-          ("self D40 T4096", 5, 40, 4096, 4096), ("self D80 T1024", 5, 80, 1024, 1024), ("self D160 T256", 5, 160, 256, 256)]
+          ("self D40 T4096", 5, 40, 4096, 4096), ("self D80 T1024", 5, 80, 1024, 1024), ("self D160 T256", 5, 160, 256, 256), ("self D80 T4096 (x-ray, batch 20)", 5, 80, 4096, 4096)]
 
 
 def main():
@@ -21,9 +21,10 @@ def main():
     iters = int(os.environ.get("DM_BENCH_ITERS", "5"))
     lib = U.E.load_library()
     d = U.dev()
-    print(f"# {opt}: A = {va}, B = {vb}; batch {B}; ms per launch (min of 3 interleaved rounds of {iters})")
+    print(f"# {opt}: A = {va}, B = {vb}; batch {B0}; ms per launch (min of 3 interleaved rounds of {iters})")
     tot = [0.0, 0.0]
     for name, n, D, Tq, Tk in SHAPES:
+        B = 20 if "batch 20" in name else B0
         C = HEADS * D
         cross = Tk == 77
         q = torch.randn(B, Tq, C, device=d).half()

@@ -21,19 +21,21 @@ for _ in range(2):
     U.op_attention(q, k, v, heads)
 print('hipOccupancyMaxActiveBlocksPerMultiprocessor:', lib.dm_debug_attn_occupancy())
 span = (C.c_ulonglong * 2)()
-lib.dm_debug_attn_span(span, 1)
+dbg_span = lib.dm_debug_attn80_span if D == 80 else lib.dm_debug_attn_span
+dbg_timing = lib.dm_debug_attn80_timing if D == 80 else lib.dm_debug_attn_timing
+dbg_span(span, 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 U.op_attention(q, k, v, heads)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
-lib.dm_debug_attn_span(span, 0)
+dbg_span(span, 0)
 ticks_per_ns = (span[1] - span[0]) / (ms * 1e6)
 print(f"kernel {ms:.3f} ms, {span[1] - span[0]} ticks first-start..last-end -> {ticks_per_ns:.3f} ticks/ns")
 out = (C.c_longlong * 16)()
-assert lib.dm_debug_attn_timing(out) == 0
-names = ["vmcnt wait", "barrier", "dma issue", "phase A (QK || exp)", "V reads+max+wait", "phase B (PV)", "epilogue-pre", "prologue"]
+assert dbg_timing(out) == 0
+names = ["vmcnt wait", "barrier", "dma issue (D40) / rescale check (D80)", "phase A (QK || exp)", "V reads+max+wait", "phase B (PV)", "epilogue-pre", "prologue"]
 nt = T // 64
 for w in range(2):
     print(f"wave {w}: per-tile cycles (shader clock ticks; {nt} tiles)")
