@@ -48,7 +48,8 @@ template <int OP> void run(const char* name, int waves_per_simd) {
 }
 int main() {
     for (int w = 1; w <= 4; ++w) {
-        run<0>("v_exp_f32", w); run<1>("v_fma_f32", w); run<2>("v_pk_fma_f32", w); run<6>("mfma_16x16x32_f16", w);
+        run<0>("v_exp_f32", w); run<5>("v_exp_f16", w); run<1>("v_fma_f32", w); run<2>("v_pk_fma_f32", w); run<3>("v_max3_f32", w);
+        run<4>("v_cvt_pk_f16_f32", w); run<6>("mfma_16x16x32_f16", w);
     }
     return 0;
 }
