@@ -358,7 +358,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     // long head_dim-40 / 80 self-attention: software-pipelined variants (DM_ATTN_PIPE=0 disables)
     const int pipe = option(OPT_ATTN_PIPE);
     if (pipe && attention_pipe_supports(p)) return launch_attention_pipe(p, s);
-    if (pipe == 1 && attention_pipe80_supports(p)) return launch_attention_pipe80(p, s);     // attn_pipe = 2: head_dim 40 only (A/B)
+    if ((pipe == 1 || pipe == 3) && attention_pipe80_supports(p)) return launch_attention_pipe80(p, s);     // attn_pipe = 2: head_dim 40 only (A/B)
     switch (p.D) {
         case 40: return launch_t<40, 2>(p, s);
         case 80: return launch_t<80, 2>(p, s);

@@ -2,20 +2,24 @@
 // self-attention of the 32x32 level, 4096 tokens at 1024 px) reached from `unet(...)`,
 // diffmining/typicality/compute.py:100.  Same mathematics and operand tricks (S^T = K Q^T so P is directly the PV B
 // operand, V^T by ds_read_b64_tr_b16, running max folded into two padded k columns, denominator in a ones row of V^T,
-// lazy rescale) and the same schedule, with the head_dim-dependent geometry as template constants:
-//   * LDS rows: D/8 real 16-byte chunks + one constant chunk ({1,1,0..} for K, {1,0,0..} for V) = 176 bytes at D = 80
-//     (conflict-free for the 16-byte K fragment reads: 176 mod 128 = 48 walks all eight 16-byte slots);
-//   * k steps of the score MFMA: ceil((D + 8) / 32) = 3; the -m_hi / -m_lo columns of Q' sit at k = D, D + 1;
-//   * O^T row blocks: ceil((D + 1) / 16) = 6; row D (the ones row of V^T) is the softmax denominator;
-//   * 11 K + 11 V LDS-DMA pieces per 64-key tile, six slots per wave (the 23rd / 24th slot fetch a dummy chunk into a
-//     scratch KiB so that every wave has the same vmcnt bookkeeping);
-//   * registers (two blocks of four waves per CU, <= 256 VGPRs): the V^T fragments of the second 32-key half are read
+// lazy rescale) and the same schedule, with the head_dim-dependent geometry as template constants, and one change of
+// layout: the LDS rows are bare (160 bytes at D = 80, no constant chunk).  The running max enters the score MFMAs as the
+// initial value of their accumulators (fp32 -m instead of the fp16 hi / lo pair in two padded k columns) and the row block
+// of V^T that holds the ones row (rows 80..95: ones, then fifteen zero rows) is a register constant.  That removes 9 % of
+// the LDS-DMA bytes, four of the 24 transpose reads per tile and — the part that pays — the bank conflicts of the V^T
+// transpose reads: eight rows of 176 bytes overlap in the 64 banks, eight rows of 160 bytes do not (PMC: 12 % -> 4 % LDS
+// conflict cycles over the attention family).  Same-box A/B against the constant-chunk layout (`attn_pipe` = 3):
+// 0.61 -> 0.56 ms at 160 x 8 x 1024, 0.98 -> 0.92 ms at 20 x 8 x 4096.
+//   * k steps of the score MFMA: ceil(D / 32) = 3 (k 80..95 multiply zero columns of Q');
+//   * O^T row blocks: 5 from LDS + the constant one; row D is the softmax denominator;
+//   * 10 K + 10 V LDS-DMA pieces per 64-key tile, five per wave;
+//   * registers (two blocks of four waves per CU, 243 VGPRs): the V^T fragments of the second 32-key half are read
 //     during the PV MFMAs of the first half, the K fragments of the third k step after the first step's MFMAs.
 // A 64-key tile costs a wave 48 MFMAs (768 matrix cycles) against ~75 VALU + 32 exp2 (~690 issue cycles).  Measured
-// (tools/ab_attn.py attn_pipe 2 1, same box): 0.77 -> 0.62 ms per launch at 160 x 8 heads x 1024 tokens (577 -> 722
-// TFLOP/s), 1.32 -> 1.04 ms at 20 x 8 x 4096.  Phase timers (tools/attn_timing.py 80 1024): an iteration is ~2500 cycles
-// per wave (phase A 1500, phase B 600), and the first wait of a block (K(0) + Q from a busy memory system) ~9700
-// cycles = a fifth of a 16-tile block's life, hidden only by the one other block resident on the CU.
+// (tools/ab_attn.py attn_pipe 2 1, same box) against attn_kernel<80>: 0.77 -> 0.56 ms per launch at 160 x 8 heads x 1024
+// tokens (577 -> 790 TFLOP/s), 1.32 -> 0.92 ms at 20 x 8 x 4096.  Phase timers (tools/attn_timing.py 80 1024): an iteration
+// is ~2500 cycles per wave (phase A 1500, phase B 600), and the first wait of a block (K(0) + Q from a busy memory
+// system) ~9700 cycles = a fifth of a 16-tile block's life, hidden only by the one other block resident on the CU.
 #include "dm_kernels.h"
 
 #include <type_traits>
@@ -37,24 +41,28 @@ constexpr int QF = 2;                 // 16-query fragments per wave
 constexpr float RESCALE_THR = 8.0f;   // log2 units
 constexpr int NSTG = 3;               // K/V ring depth: K is fetched three, V two tiles ahead of their use
 
-template <int D>
+// CC = 1: rows carry a constant 16-byte chunk behind the data ({1,1,0..} for K: the k columns that take -m_hi / -m_lo from
+// Q'; {1,0..} for V: the ones row of V^T), as attention_pipe.hip does.  CC = 0: bare rows; the running max enters as the
+// initial value of the score accumulators and the ones row block of V^T is a register constant (D % 16 == 0).
+template <int D, int CC>
 struct Geo {
     static constexpr int CH = D / 8;                       // real 16-byte chunks per row
-    static constexpr int RS = (CH + 1) * 16;               // LDS row stride (bytes)
-    static constexpr int KS = (D + 8 + 31) / 32;           // k steps of S^T = K Q^T
+    static constexpr int RS = (CH + CC) * 16;              // LDS row stride (bytes)
+    static constexpr int KS = (D + 8 * CC + 31) / 32;      // k steps of S^T = K Q^T
     static constexpr int EF = (D + 1 + 15) / 16;           // 16-row blocks of O^T
+    static constexpr int EFV = CC ? EF : D / 16;           // ... of which read from LDS
     static constexpr int S_M = D / 32, LG_M = (D % 32) / 8;   // where k = D, D + 1 live in the Q' fragments
     static constexpr int E_L = D / 16, LG_L = (D % 16) / 4;   // where row D of O^T lives in the accumulators
     static constexpr int TILE = KT * RS;
     static constexpr int PAD = 32;                         // zero bytes behind each tile (fragment reads overrun a row)
     static constexpr int KOFF = 0, VOFF = TILE + PAD;
     static constexpr int STAGE = 2 * (TILE + PAD);
-    static constexpr int NP = KT * (CH + 1) / 64;          // 1 KiB LDS-DMA pieces per operand tile
+    static constexpr int NP = KT * (CH + CC) / 64;         // 1 KiB LDS-DMA pieces per operand tile
     static constexpr int NPW = (2 * NP + 3) / 4;           // piece slots per wave
     static constexpr int SCRATCH = NSTG * STAGE;           // 1 KiB target of the dummy slots
     static constexpr int LDS = NSTG * STAGE + 1024;
-    static_assert(D % 8 == 0 && (KT * (CH + 1)) % 64 == 0, "tile must be whole pieces");
-    static_assert(16 * 3 + 64 * (KS - 1) + 16 <= RS + PAD && 32 * (EF - 1) + 8 * 3 + 8 <= RS + PAD, "fragment overrun must stay inside the pad");
+    static_assert(D % 8 == 0 && (KT * (CH + CC)) % 64 == 0 && (CC || D % 16 == 0), "tile must be whole pieces");
+    static_assert(16 * 3 + 64 * (KS - 1) + 16 <= RS + PAD && 32 * (EFV - 1) + 8 * 3 + 8 <= RS + PAD, "fragment overrun must stay inside the pad");
 };
 
 __device__ __attribute__((aligned(16))) const unsigned short g_kconst80[8] = {0x3C00, 0x3C00, 0, 0, 0, 0, 0, 0};
@@ -86,11 +94,11 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-template <int D>
+template <int D, int CC>
 __global__ __launch_bounds__(NT, 2)
 void attn_pipe80_kernel(AttnParams p) {
-    using G = Geo<D>;
-    constexpr int RS = G::RS, KS = G::KS, EF = G::EF, STAGE = G::STAGE, KOFF = G::KOFF, VOFF = G::VOFF, NPW = G::NPW;
+    using G = Geo<D, CC>;
+    constexpr int RS = G::RS, KS = G::KS, EF = G::EF, EFV = G::EFV, STAGE = G::STAGE, KOFF = G::KOFF, VOFF = G::VOFF, NPW = G::NPW;
 #ifdef DM_ATTN_TIMING
     long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = (long long)__builtin_readcyclecounter();
@@ -141,7 +149,7 @@ void attn_pipe80_kernel(AttnParams p) {
         const bool isv = j >= G::NP;
         const int jj = isv ? j - G::NP : j;
         const int idx = jj * 64 + lane;
-        const int key = idx / (G::CH + 1), ch = idx - key * (G::CH + 1);
+        const int key = idx / (G::CH + CC), ch = idx - key * (G::CH + CC);
         const int ld = isv ? p.ldv : p.ldk;
         if (j < 2 * G::NP && ch < G::CH) { gsrc[i] = (isv ? Vb : Kb) + (size_t)key * ld + ch * 8; ginc[i] = KT * ld; }
         else { gsrc[i] = reinterpret_cast<const f16*>(isv ? g_vconst80 : g_kconst80); ginc[i] = 0; }
@@ -160,6 +168,11 @@ void attn_pipe80_kernel(AttnParams p) {
 
     const float sc = p.scale * 1.44269504088896340736f;
     half8 qf[QF][KS];                  // Q' = fp16(sc * q), loaded in the prologue
+    half8 ones_a;                      // A operand of the constant V^T row block (CC = 0): lane row 0 = ones
+    {
+        const f16 o = (l15 == 0) ? (f16)1.0f : (f16)0.0f;
+        ones_a = half8{o, o, o, o, o, o, o, o};
+    }
     floatx4 oacc[EF][QF];
 #pragma unroll
     for (int e = 0; e < EF; ++e)
@@ -184,10 +197,12 @@ void attn_pipe80_kernel(AttnParams p) {
             m_run[jq] += delta;
 #pragma unroll
             for (int e = 0; e < EF; ++e) oacc[e][jq] *= alpha;
-            if (lg == G::LG_M) {
-                const f16 mh = (f16)m_run[jq];
-                const f16 ml = (f16)(m_run[jq] - (float)mh);
-                qf[jq][G::S_M][0] = -mh; qf[jq][G::S_M][1] = -ml;
+            if constexpr (CC) {
+                if (lg == G::LG_M) {
+                    const f16 mh = (f16)m_run[jq];
+                    const f16 ml = (f16)(m_run[jq] - (float)mh);
+                    qf[jq][G::S_M][0] = -mh; qf[jq][G::S_M][1] = -ml;
+                }
             }
 #pragma unroll
             for (int f = 0; f < 4; ++f)
@@ -290,7 +305,10 @@ void attn_pipe80_kernel(AttnParams p) {
 #pragma unroll
             for (int f = 0; f < 4; ++f)
 #pragma unroll
-                for (int jq = 0; jq < QF; ++jq) Y[f][jq] = floatx4{0, 0, 0, 0};
+                for (int jq = 0; jq < QF; ++jq) {
+                    const float ini = CC ? 0.f : -m_run[jq];          // CC = 0: scores start from -m (fp32, not hi / lo halves)
+                    Y[f][jq] = floatx4{ini, ini, ini, ini};
+                }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) exp_slice(X, i);         // cover the latency of the K fragment reads
@@ -320,10 +338,10 @@ void attn_pipe80_kernel(AttnParams p) {
             // V(t)^T fragments of keys 0..31: 2 EF transpose reads behind the last four MFMAs;
             // offset = 32 e + (2 ss + hh) 16 RS
             if constexpr (m >= NMA - 4) {
-                constexpr int per = (2 * EF + 3) / 4;
+                constexpr int per = (2 * EFV + 3) / 4;
                 static_for<per>([&](auto R) __attribute__((always_inline)) {
                     constexpr int r = (m - (NMA - 4)) * per + decltype(R)::value;
-                    if constexpr (r < 2 * EF) {
+                    if constexpr (r < 2 * EFV) {
                         constexpr int e = r >> 1, hh = r & 1;
                         tr_read<VOFF + 32 * e + hh * 16 * RS>(vraw[0][e][hh], vcur);
                     }
@@ -336,7 +354,7 @@ void attn_pipe80_kernel(AttnParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         TICK(4);
-        static_for<2 * EF>([&](auto R) __attribute__((always_inline)) {
+        static_for<2 * EFV>([&](auto R) __attribute__((always_inline)) {
             constexpr int r = decltype(R)::value, e = r >> 1, hh = r & 1;
             tr_read<VOFF + 32 * e + (2 + hh) * 16 * RS>(vraw[1][e][hh], vcur);
         });
@@ -351,8 +369,12 @@ void attn_pipe80_kernel(AttnParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             half8 va, pbv;
-            __builtin_memcpy(&va, &vraw[ss][e][0], 8);
-            __builtin_memcpy(reinterpret_cast<char*>(&va) + 8, &vraw[ss][e][1], 8);
+            if constexpr (e < EFV) {
+                __builtin_memcpy(&va, &vraw[ss][e][0], 8);
+                __builtin_memcpy(reinterpret_cast<char*>(&va) + 8, &vraw[ss][e][1], 8);
+            } else {
+                va = ones_a;                                  // rows D .. D + 15 of V^T: the ones row and fifteen zero rows
+            }
             __builtin_memcpy(&pbv, &pbu[jq][ss][0], 16);
             oacc[e][jq] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pbv, oacc[e][jq], 0, 0, 0);
             PIN(oacc[e][jq]);
@@ -415,6 +437,9 @@ void attn_pipe80_kernel(AttnParams p) {
 
 }  // namespace
 
+#ifndef DM_ATTN80_CC
+#define DM_ATTN80_CC 0
+#endif
 bool attention_pipe80_supports(const AttnParams& p) {
     return p.D == 80 && p.Tk >= 256 && (p.Tk % 128) == 0;
 }
@@ -423,11 +448,14 @@ hipError_t launch_attention_pipe80(const AttnParams& p, hipStream_t s) {
     if (!attention_pipe80_supports(p)) return hipErrorInvalidValue;
     constexpr int QBLK = 64 * QF;
     dim3 grid(((p.Tq + QBLK - 1) / QBLK) * p.heads * p.B), block(NT);
-    constexpr size_t lds = Geo<80>::LDS;
     static std::atomic<uint64_t> attr_seen{0};      // hipFuncSetAttribute is per DEVICE, not per process
-    if (first_use_on_device(attr_seen))
-        (void)hipFuncSetAttribute((const void*)attn_pipe80_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_pipe80_kernel<80>, grid, block, lds, s, p);
+    if (first_use_on_device(attr_seen)) {
+        (void)hipFuncSetAttribute((const void*)attn_pipe80_kernel<80, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo<80, 0>::LDS);
+        (void)hipFuncSetAttribute((const void*)attn_pipe80_kernel<80, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo<80, 1>::LDS);
+    }
+    constexpr size_t lds0 = Geo<80, 0>::LDS, lds1 = Geo<80, 1>::LDS;
+    if (option(OPT_ATTN_PIPE) == 3) hipLaunchKernelGGL((attn_pipe80_kernel<80, 1>), grid, block, lds1, s, p);   // A/B: rows with constant chunks
+    else hipLaunchKernelGGL((attn_pipe80_kernel<80, 0>), grid, block, lds0, s, p);
     return hipGetLastError();
 }
 
