@@ -352,10 +352,13 @@ hipError_t launch_attention_pipe(const AttnParams& p, hipStream_t s);    // atte
 bool attention_pipe_supports(const AttnParams& p);
 hipError_t launch_attention_pipe80(const AttnParams& p, hipStream_t s);  // attention_pipe80.hip
 bool attention_pipe80_supports(const AttnParams& p);
+hipError_t launch_attention_cross(const AttnParams& p, hipStream_t s);   // attention_cross.hip
+bool attention_cross_supports(const AttnParams& p);
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.Tq <= 0 || p.Tk <= 0 || p.B <= 0) return hipErrorInvalidValue;
     // long head_dim-40 / 80 self-attention: software-pipelined variants (DM_ATTN_PIPE=0 disables)
+    if (option(OPT_ATTN_CROSS) && attention_cross_supports(p)) return launch_attention_cross(p, s);   // 77-key cross-attention
     const int pipe = option(OPT_ATTN_PIPE);
     if (pipe && attention_pipe_supports(p)) return launch_attention_pipe(p, s);
     if ((pipe == 1 || pipe == 3) && attention_pipe80_supports(p)) return launch_attention_pipe80(p, s);     // attn_pipe = 2: head_dim 40 only (A/B)

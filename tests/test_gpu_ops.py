@@ -141,6 +141,36 @@ def test_attention_cross_with_prompt_slots(D):
     U.assert_close_fp16(o, ref, f"cross-attn D={D}", rel=3e-3, abs_frac=4e-3)
 
 
+@pytest.mark.parametrize("D,Tq,B", [(40, 4096, 4), (40, 1000, 5), (80, 1024, 5), (80, 300, 3)])
+def test_attention_cross_resident_kv_kernel(D, Tq, B):
+    """The 77-key cross-attention kernel that keeps K / V of a (prompt, head) resident in LDS over all query blocks of a
+    sample (head_dim 40 / 80, Tq >= 256): ragged query counts, prompt slots, a dominating key; against fp32 SDPA and the
+    generic kernel (`attn_cross` = 0)."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    heads, Tk, P = 8, 77, 3
+    Cc = heads * D
+    q = U.f16_randn(B, Tq, Cc, seed=28)
+    kv = U.f16_randn(P, Tk, 2 * Cc, seed=29)
+    kv[1, 70, :Cc] = q[1, 9] * 3.0                    # one late key dominates some rows of prompt 1
+    slots = torch.tensor([2, 1, 0, 1, 2][:B], dtype=torch.int32)
+    k, v = kv[..., :Cc][slots.long()], kv[..., Cc:][slots.long()]
+
+    def split(t, T):
+        return t.float().view(B, T, heads, D).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(split(q, Tq), split(k, Tk), split(v, Tk)).transpose(1, 2).reshape(B, Tq, Cc)
+    d = U.dev()
+    qd, kvg, sl = q.to(d), kv.to(d), slots.to(d)
+    try:
+        o = U.op_attention(qd, kvg[..., :Cc], kvg[..., Cc:], heads, slots=sl)
+        assert lib.dm_set_option(b"attn_cross", 0) == 0
+        o_gen = U.op_attention(qd, kvg[..., :Cc], kvg[..., Cc:], heads, slots=sl)
+    finally:
+        lib.dm_set_option(b"attn_cross", 1)
+    U.assert_close_fp16(o, ref, f"cross-attn resident D={D} Tq={Tq}", rel=3e-3, abs_frac=4e-3)
+    U.assert_close_fp16(o, o_gen.float().cpu(), f"cross-attn resident vs generic D={D}", rel=3e-3, abs_frac=4e-3)
+
+
 def test_attention_large_logits_online_softmax():
     """Force the running-max rescale path: one key per row dominates at a late tile."""
     heads, B, T, D = 8, 1, 320, 40
