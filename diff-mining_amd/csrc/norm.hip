@@ -239,6 +239,51 @@ __global__ void ln_stats_kernel(const f16* __restrict__ X, int rows, int C, floa
     }
 }
 
+// The same statistics with G lanes per row (C = 40 G: 320 / 640 / 1280 channels, five 16-byte chunks per lane) and
+// 64 / G rows per load instruction, SETS row sets per wave: every lane carries data (one row per wave leaves 24 of 64
+// lanes idle at C = 320), a row's chunks of one load instruction are G * 16 contiguous bytes, and the reduction crosses
+// log2(G) lanes instead of six.  Two passes in registers as above (sum -> mean, then the centred squares).
+template <int G, int SETS>
+__global__ void ln_stats_g_kernel(const f16* __restrict__ X, int rows, float eps, float* __restrict__ stats) {
+    constexpr int C = 40 * G, RW = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int g = lane / G, j = lane % G;
+    const int row0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (RW * SETS);
+    if (row0 >= rows) return;
+    half8 v[SETS][5];
+#pragma unroll
+    for (int t = 0; t < SETS; ++t) {
+        int r = row0 + t * RW + g;
+        r = r < rows ? r : rows - 1;
+        const f16* x = X + (size_t)r * C + j * 8;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v[t][i] = *reinterpret_cast<const half8*>(x + i * G * 8);
+    }
+#pragma unroll
+    for (int t = 0; t < SETS; ++t) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += (float)v[t][i][k];
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float d = (float)v[t][i][k] - mean; q += d * d; }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const int r = row0 + t * RW + g;
+        if (j == 0 && r < rows) {
+            stats[2 * (size_t)r] = mean;
+            stats[2 * (size_t)r + 1] = rsqrtf(q / (float)C + eps);
+        }
+    }
+}
+
 }  // namespace
 
 static int gn_pix(int HW) { int p = GN_PIX_MAX; while (p > 32 && HW / p < 16) p >>= 1; return p; }
@@ -289,6 +334,15 @@ hipError_t launch_layernorm(const f16* X, int rows, int C, const float* gamma, c
 
 hipError_t launch_ln_stats(const f16* X, int rows, int C, float eps, float* stats, hipStream_t s) {
     if (C % 8 || C > 64 * 8 * 3) return hipErrorInvalidValue;
+    if (option(OPT_LN_STATS_G) && (C == 320 || C == 640 || C == 1280)) {        // the U-Net's token widths
+        constexpr int SETS = 2, WPB = 4;
+        const int rpw = (C == 320 ? 8 : C == 640 ? 4 : 2) * SETS;
+        dim3 grid((rows + WPB * rpw - 1) / (WPB * rpw)), block(64 * WPB);
+        if (C == 320) hipLaunchKernelGGL((ln_stats_g_kernel<8, SETS>), grid, block, 0, s, X, rows, eps, stats);
+        else if (C == 640) hipLaunchKernelGGL((ln_stats_g_kernel<16, SETS>), grid, block, 0, s, X, rows, eps, stats);
+        else hipLaunchKernelGGL((ln_stats_g_kernel<32, SETS>), grid, block, 0, s, X, rows, eps, stats);
+        return hipGetLastError();
+    }
     const int wpb = 4;
     const int nvec = C / 8;
     constexpr int RPW = 4;          // measured: 1 row/wave 145 us, 4 rows 104 us, 8 rows 98 us (C = 320, 655 360 rows)

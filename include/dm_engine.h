@@ -216,7 +216,7 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
                 const void* res, void* Y, int N, int H, int W, int C1, int C2, int Cout, int OH, int OW,
                 int mode, int epi, int temb_ld);
 /* Runtime switches for A/B measurements (process-wide; each defaults to the measured best and is initialised from the
- * environment variable DM_<NAME>): "igemm_big" (-1 per shape / 0 / 1), "igemm_splitk", "ln_fold", "attn_pipe", "igemm_tail", "attn_cross" (0 / 1).  None of them changes a result bit, except ln_fold (LayerNorm folded into the next GEMM).
+ * environment variable DM_<NAME>): "igemm_big" (-1 per shape / 0 / 1), "igemm_splitk", "ln_fold", "attn_pipe", "igemm_tail", "attn_cross", "ln_stats_g" (0 / 1).  None of them changes a result bit, except ln_fold (LayerNorm folded into the next GEMM).
  * Returns nonzero for an unknown name. */
 int dm_set_option(const char* name, int value);
 

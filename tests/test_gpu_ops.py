@@ -586,3 +586,27 @@ def test_head_tail_split_is_bit_identical(case):
         lib.dm_set_option(b"igemm_big", -1)
     assert not torch.isnan(y_split.float()).any()
     assert torch.equal(y_split, y_one) and torch.equal(y_split, y_small)
+
+
+@pytest.mark.parametrize("C,rows", [(320, 4096 + 5), (640, 1031), (1280, 257), (768, 77)])
+def test_ln_stats_kernels_against_torch(C, rows):
+    """Per-row (mean, rstd) of a token matrix: the grouped-lane kernel (C = 320 / 640 / 1280, `ln_stats_g` = 1: G lanes per
+    row, 64 / G rows per load) and the row-per-wave kernel (every other width, or `ln_stats_g` = 0) against fp64 torch,
+    with a row count that is not a multiple of the rows per wave."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = (torch.randn(rows, C, generator=g, device=d) * 1.7 + 0.3).half()
+    ref_mean = x.double().mean(1)
+    ref_rstd = (x.double().var(1, unbiased=False) + 1e-5).rsqrt()
+    try:
+        for opt in (1, 0):
+            assert lib.dm_set_option(b"ln_stats_g", opt) == 0
+            stats = torch.full((rows, 2), float("nan"), dtype=torch.float32, device=d)
+            assert lib.dm_op_ln_stats(U.stream(), U.ptr(x), rows, C, 1e-5, U.ptr(stats)) == 0
+            torch.cuda.synchronize()
+            assert (stats[:, 0].double() - ref_mean).abs().max().item() < 2e-6
+            assert ((stats[:, 1].double() - ref_rstd) / ref_rstd).abs().max().item() < 2e-6
+    finally:
+        lib.dm_set_option(b"ln_stats_g", 1)
