@@ -113,6 +113,16 @@ def bench_norm():
         lib = U.E.load_library(); st = U.stream()
         ms = timeit(lambda: lib.dm_op_layernorm(st, U.ptr(x), rows, C, U.ptr(g), U.ptr(b), 1e-5, U.ptr(y)))
         print(f"layernorm C={C} rows={rows}: {ms:.3f} ms  {2 * rows * C * 2 / ms / 1e9:.2f} TB/s")
+    # GroupNorm(32) + SiLU: statistics pass (read) + apply pass (read + write) = 3 x the tensor
+    lib = U.E.load_library(); st = U.stream()
+    for C1, C2, HW in ((320, 0, 4096), (640, 320, 4096), (320, 320, 4096), (640, 0, 1024), (1280, 640, 1024), (1280, 0, 256), (1280, 1280, 256), (1280, 0, 64)):
+        C = C1 + C2
+        x = torch.randn(B, HW, C1, device=d).half()
+        x2 = torch.randn(B, HW, C2, device=d).half() if C2 else None
+        g = torch.ones(C, device=d); b = torch.zeros(C, device=d)
+        y = torch.empty(B, HW, C, device=d, dtype=torch.float16)
+        ms = timeit(lambda: lib.dm_op_groupnorm(st, U.ptr(x), U.ptr(x2), B, HW, C, C1, 32, 1e-5, U.ptr(g), U.ptr(b), 1, U.ptr(y)), iters=10)
+        print(f"groupnorm C={C1}+{C2} HW={HW}: {ms * 1e3:8.1f} us  {3 * B * HW * C * 2 / ms / 1e9:.2f} TB/s (2 reads + 1 write)")
 
 
 if __name__ == "__main__":
