@@ -97,7 +97,10 @@ __global__ void im2col_in_kernel(const T* __restrict__ x, const int32_t* __restr
 // The products go through v_dot2_f32_f16 (two fp16 x fp16 products, exact, + an fp32 accumulator per instruction):
 // 16 VALU instructions per 16-byte chunk instead of 40 converts + 32 FMAs — the layer was VALU-bound at 7x its
 // HBM time (0.63 ms for one 419 MB read at the bench batch; 0.44 ms now — four pixels per weight chunk read measured
-// slower again, 0.50 ms: the loop is bound by the 16-byte gathers, not by LDS).
+// slower again, 0.50 ms, and so did the same layer on the matrix cores — four channels as rows 0..3 of a 16x16x32
+// MFMA, sixteen pixels as columns, operands straight from NHWC: 0.47 ms, 99.7 % of the outputs bit-equal.  The loop is
+// bound by the nine-fold 16-byte gather through L1 / L2 (lines of 128 bytes used 64 at a time by more waves than the L1
+// holds), not by arithmetic or LDS; the fix would be input rows staged once in LDS and walked by all nine taps).
 constexpr int CONV_OUT_GROUPS = 8;
 typedef _Float16 half2x __attribute__((ext_vector_type(2)));
 template <typename TE>
