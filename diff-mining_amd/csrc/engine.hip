@@ -488,7 +488,9 @@ struct Fwd {
         const int cin = x.C + (x2 ? x2->C : 0);
         if (cin != cv.cin) DM_FAIL(e, "igemm: channel mismatch %d vs %d", cin, cv.cin);
         const int cout_y = (epi == EPI_GEGLU) ? cv.cout / 2 : cv.cout;
-        DM_TRY(alloc(y, x.N, OH, OW, cout_y));
+        if (y->p && y->off == (size_t)-1) {            // pre-placed output (first_slot() of a stacked tensor): write in place
+            if (y->N != x.N || y->H != OH || y->W != OW || y->C != cout_y) DM_FAIL(e, "igemm: pre-placed output has the wrong shape");
+        } else DM_TRY(alloc(y, x.N, OH, OW, cout_y));
         IGemmParams p;
         p.X = x.p; p.X2 = x2 ? x2->p : nullptr; p.Wp = cv.w; p.bias = cv.b; p.temb = temb;
         p.res = res ? res->p : nullptr; p.Y = y->p;
@@ -652,13 +654,17 @@ struct Fwd {
         DM_TRY(transformer_pre(t, x, &t1));
         return transformer_post(t, x, t1, slots, out);
     }
-    // n_cond stacked copies of a [U, ...] tensor: out[k*U + i] = in[i]
-    int replicate(const Tensor& in, int n_cond, Tensor* out) {
-        DM_TRY(alloc(out, in.N * n_cond, in.H, in.W, in.C));
+    // n_cond stacked copies of a [U, ...] tensor, out[k*U + i] = in[i], without copying slot 0: the producer writes the
+    // first slot of the stacked tensor in place (first_slot() as its output), fill_slots() copies it to the others
+    static Tensor first_slot(const Tensor& stacked, int n_cond) {
+        Tensor v; v.p = stacked.p; v.off = (size_t)-1; v.N = stacked.N / n_cond; v.H = stacked.H; v.W = stacked.W; v.C = stacked.C;
+        return v;
+    }
+    int fill_slots(const Tensor& stacked, int n_cond) {
         if (!dry) {
-            const size_t bytes = (size_t)in.rows() * in.C * sizeof(f16);
-            for (int k = 0; k < n_cond; ++k)
-                DM_HIP(e, hipMemcpyAsync((char*)out->p + (size_t)k * bytes, in.p, bytes, hipMemcpyDeviceToDevice, s));
+            const size_t bytes = (size_t)(stacked.rows() / n_cond) * stacked.C * sizeof(f16);
+            for (int k = 1; k < n_cond; ++k)
+                DM_HIP(e, hipMemcpyAsync((char*)stacked.p + (size_t)k * bytes, stacked.p, bytes, hipMemcpyDeviceToDevice, s));
         }
         return 0;
     }
@@ -696,12 +702,20 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
     DM_TRY(F.alloc(&embs, 1, 1, U, TEMB));
     if (!dry) DM_HIP(e, launch_silu(emb.p, embs.p, (long long)U * TEMB, s));
     F.free(emb);
+    if (NC > 1) {
+        DM_TRY(F.alloc(&tproj, NC, 1, U, e->tproj_total));
+        tprojU = Fwd::first_slot(tproj, NC);
+    }
     DM_TRY(F.dense(e->tproj_all, embs, nullptr, nullptr, EPI_PLAIN, &tprojU));
     F.free(embs);
-    if (NC > 1) DM_TRY(F.replicate(tprojU, NC, &tproj)); else tproj = tprojU;
+    if (NC > 1) DM_TRY(F.fill_slots(tproj, NC)); else tproj = tprojU;
 
     // ---- conv_in (+ fused add_noise) ------------------------------------------------------------
-    Tensor h;
+    Tensor h, hB;
+    if (NC > 1) {                  // the stacked skip tensor; conv_in writes its first slot
+        DM_TRY(F.alloc(&hB, U * NC, A.H, A.W, BOC[0]));
+        h = Fwd::first_slot(hB, NC);
+    }
     {
         Tensor col;
         DM_TRY(F.alloc(&col, U, A.H, A.W, 64));
@@ -721,13 +735,16 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
         // stacked NC times and the per-prompt half continues on the full batch.  Bit-identical to
         // running every (draw, prompt) pair separately (the kernels are batch-position invariant).
         const DownBlockW& d = e->down[0];
-        Tensor rU, t1U, hB, rB, t1B, a;
+        Tensor rU, t1U, rB, t1B, a;
+        DM_TRY(F.alloc(&rB, U * NC, A.H, A.W, d.res[0].cout));
+        rU = Fwd::first_slot(rB, NC);
         DM_TRY(F.resnet(d.res[0], h, nullptr, tprojU.p, &rU));
+        DM_TRY(F.alloc(&t1B, U * NC, A.H, A.W, d.tf[0].c));
+        t1U = Fwd::first_slot(t1B, NC);
         DM_TRY(F.transformer_pre(d.tf[0], rU, &t1U));
-        DM_TRY(F.replicate(h, NC, &hB));
-        DM_TRY(F.replicate(rU, NC, &rB));
-        DM_TRY(F.replicate(t1U, NC, &t1B));
-        F.free(h); F.free(rU); F.free(t1U); F.free(tprojU);
+        DM_TRY(F.fill_slots(hB, NC));
+        DM_TRY(F.fill_slots(rB, NC));
+        DM_TRY(F.fill_slots(t1B, NC));
         DM_TRY(F.transformer_post(d.tf[0], rB, t1B, A.slots, &a));
         F.free(rB);
         skips.push_back(hB);
