@@ -30,6 +30,8 @@ hipError_t launch_igemm_splitk(const IGemmParams& p, hipStream_t s);  // igemm_s
 hipError_t launch_igemm_tile_ln(const IGemmParams& p, hipStream_t s);  // igemm_ln.hip
 hipError_t launch_igemm_pers(const IGemmParams& p, hipStream_t s);     // igemm_pers.hip (256 x 320 tile, persistent)
 hipError_t launch_igemm_pers_ln(const IGemmParams& p, hipStream_t s);  // igemm_pers_ln.hip
+hipError_t launch_igemm_pers_partial(const IGemmParams& p, hipStream_t s);   // igemm_pers_part.hip (split-K units, fp32 partials)
+hipError_t launch_splitk_reduce(const IGemmParams& p, hipStream_t s);         // igemm_splitk.hip
 
 // Shape -> tile choice, measured per shape on one box with both arms interleaved (tools/ab_igemm.py, r02): the
 // persistent 256 x 320 tile (igemm_pers_tile.h: 13.8 instead of 21.9 LDS-DMA bytes per kMAC, no per-tile prologue, stores
@@ -62,9 +64,23 @@ int igemm_splitk_parts(const IGemmParams& p, int spatial) {
     if (!on || spatial > 64 || p.epi != EPI_PLAIN || p.Cout % 320 != 0 || p.Cin % BK != 0 || p.C1 % BK != 0) return 1;
     const int nk = ((p.mode == IG_DENSE) ? 1 : 9) * (p.Cin / BK);
     if (nk < 40) return 1;
+    // 3x3 convolutions: three parts of three taps (the persistent split-K kernel walks whole taps); igemm_splitk = 2 keeps
+    // the r01 rule (four parts on the 128-row tile) for A/B
+    if (on != 2 && p.mode != IG_DENSE && (nk / 3) >= 10) return 3;
     for (int k = 4; k >= 2; --k)
         if (nk % k == 0 && nk / k >= 10) return k;
     return 1;
+}
+
+// the split-K launches the persistent 256 x 320 tile takes: 3x3 convolution, three tap-aligned parts, plain epilogue, at
+// least one unit per CU
+static bool splitk_on_pers(const IGemmParams& p) {
+    if (option(OPT_IGEMM_SPLITK) == 2 || p.ksplit != 3 || p.mode == IG_DENSE || p.epi != EPI_PLAIN || p.ln_stats) return false;
+    if (p.Cout % 320 != 0 || p.Cin % BK != 0 || p.C1 % BK != 0) return false;
+    IGemmParams q = p; q.temb = nullptr; q.res = nullptr;           // those are applied by the reduction kernel
+    if (!igemm_pers_ok(q)) return false;
+    const long long units = (long long)((p.M + 255) / 256) * (p.Cout / 320) * p.ksplit;
+    return units >= device_cu_count();
 }
 
 // Rows [r0, r1) of a launch as a launch of its own.  Dense rows are independent; for the convolution modes both cuts
@@ -151,7 +167,11 @@ static hipError_t launch_small(const IGemmParams& p, hipStream_t s) {
 }
 
 hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
-    if (p.ksplit > 1 && p.partial) return launch_igemm_splitk(p, s);
+    if (p.ksplit > 1 && p.partial) {
+        if (!splitk_on_pers(p)) return launch_igemm_splitk(p, s);
+        const hipError_t rc = launch_igemm_pers_partial(p, s);
+        return rc != hipSuccess ? rc : launch_splitk_reduce(p, s);
+    }
     if (p.ln_stats) {
         if (!p.ln_s || !p.ln_t || p.Cout % 160 != 0) return hipErrorInvalidValue;
     } else {

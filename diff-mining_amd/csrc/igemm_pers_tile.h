@@ -115,6 +115,10 @@ constexpr int AUX_BIAS = 0, AUX_TEMB = 1024, AUX_LNS = 2048, AUX_LNT = 4096, AUX
 // Compile-time, because runtime-optional loads in the epilogue make the compiler place their `s_waitcnt vmcnt` on the
 // common path, where they wait for the prefetched LDS-DMA and the previous stores instead.
 enum { PX_NONE = 0, PX_TEMB = 1, PX_RES = 2 };
+// EPI value of the split-K form (small-M 3x3 convolutions): the tile stream walks (tile, k part) units, a part is a
+// whole number of taps, and the epilogue stores the fp32 accumulators to partial[part][M][Cout]; the reduction kernel of
+// igemm_splitk.hip then applies the fused epilogue's arithmetic.
+constexpr int EPI_PARTIAL = 2;
 
 // 8 waves (2 per SIMD), wave tile 64 px x 160 ch in two 80-channel halves, <= 256 registers.  (A 16-wave form of the
 // same block tile — 64 x 80 wave tiles, <= 128 registers — was measured 1-5 % slower in r02: DESIGN.md §4b.)
@@ -127,7 +131,8 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
     constexpr int WI = TC / 8 / NW, XI = TP / 8 / NW;          // 5 + 4 LDS-DMA pieces (8 rows x 128 B) per wave per k step
     constexpr int NL = WI + XI;
     // stores per wave per tile (every wave issues all of them: rows beyond M go to the sink page)
-    constexpr int NSTORE = (EPI == EPI_GEGLU) ? 16 : 24;
+    constexpr bool PART = (EPI == EPI_PARTIAL);
+    constexpr int NSTORE = PART ? 40 : (EPI == EPI_GEGLU) ? 16 : 24;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const aux0 = smem + 2 * STAGE;
 
@@ -165,7 +170,8 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
     const int C2 = p.Cin - C1;
     const int ntaps = (p.mode == IG_DENSE) ? 1 : 9;
     const int cpt = p.Cin / BK;
-    const int nk = ntaps * cpt;                                  // >= 4 (igemm_pers_ok)
+    const int KSP = PART ? p.ksplit : 1;                         // k parts (each ntaps / KSP taps); `ntiles` counts units = tiles * KSP
+    const int nk = ntaps * cpt / KSP;                            // k steps of one unit, >= 4 (igemm_pers_ok)
     const int Ktot = ntaps * p.Cin;
     const int OHW = p.OH * p.OW;
     constexpr bool temb_lds = (EXTRA == PX_TEMB);                // a tile lies inside one sample: its temb row goes through LDS
@@ -189,14 +195,16 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
         const int oh = rem / p.OW;
         return (n << 18) | (oh << 9) | (rem - oh * p.OW);
     };
-    auto set_tile = [&](int tl) __attribute__((always_inline)) {
+    auto set_tile = [&](int unit) __attribute__((always_inline)) {
+        const int tl = PART ? unit / KSP : unit;
+        const int tap0 = PART ? (unit - tl * KSP) * (ntaps / KSP) : 0;
         const int pt = tl / tiles_c;
         lp0 = pt * TP;
         lc0 = (tl - pt * tiles_c) * TC;
         const int ln = hw_lane();
         const int lrow = ln >> 3, lchunk = ((ln & 7) ^ lrow) * 8;
-        woff = (unsigned)((size_t)(lc0 + wid * 8 + lrow) * Ktot + lchunk);
-        ld_tap = 0; ld_cc = 0;
+        woff = (unsigned)((size_t)(lc0 + wid * 8 + lrow) * Ktot + lchunk) + (unsigned)(tap0 * p.Cin);
+        ld_tap = tap0; ld_cc = 0;
 #pragma unroll
         for (int k = 0; k < XI; ++k) xpk[k] = pack_row(lp0 + (wid + k * NW) * 8 + lrow);
     };
@@ -325,6 +333,23 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+    };
+
+    // ---- split-K epilogue: the fp32 accumulators of this k part, 16 bytes (4 channels of a pixel) per store ------------
+    auto epilogue_partial = [&](int p0, int c0out, int part) __attribute__((always_inline)) {
+        const int eln = hw_lane();
+        const int e15 = eln & 15, eg = eln >> 4;
+        float* const sink = reinterpret_cast<float*>(g_store_sink) + (wid * 64 + eln) * 4;
+        float* const base = p.partial + (size_t)part * p.M * p.Cout + c0out + wc * 80 * CH + 4 * eg;
+#pragma unroll
+        for (int h = 0; h < CH; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = p0 + wp * 64 + 16 * j + e15;
+                float* const row = (m < p.M) ? base + (size_t)m * p.Cout + h * 80 : nullptr;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) *reinterpret_cast<floatx4*>(row ? row + 16 * i : sink) = acc[h][i][j];
+            }
     };
 
     // ---- epilogue: straight from the accumulators ---------------------------------------------------------------
@@ -467,8 +492,9 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
     int slot = 0;
     bool first = true;
     while (true) {
-        const int pt = tile / tiles_c;
-        const int p0 = pt * TP, c0out = (tile - pt * tiles_c) * TC;
+        const int rtile = PART ? tile / KSP : tile;
+        const int pt = rtile / tiles_c;
+        const int p0 = pt * TP, c0out = (rtile - pt * tiles_c) * TC;
 #pragma unroll
         for (int h = 0; h < CH; ++h)
 #pragma unroll
@@ -480,6 +506,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
         // NSTORE outstanding" proves they have landed; every later k step waits for everything, which is where the
         // previous tile's stores must have drained (they had the epilogue's own run time plus one k step).
         if (first) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (NSTORE == 40) asm volatile("s_waitcnt vmcnt(40)\n\ts_barrier" ::: "memory");
         else if (NSTORE == 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
         first = false;
@@ -508,7 +535,8 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
             PTICK(1);
             if (kt == 0 && threadIdx.x == 0) *reinterpret_cast<volatile int*>(aux0 + slot * AUX_BYTES + 1020) = ticket;
         }
-        epilogue(p0, c0out, slot);
+        if constexpr (PART) epilogue_partial(p0, c0out, tile - rtile * KSP);
+        else epilogue(p0, c0out, slot);
         PTICK(2);
 #ifdef DM_IGEMM_TIMING
         dbg[4] += 1;
@@ -551,6 +579,22 @@ static hipError_t launch_igemm_pers_t(const IGemmParams& p, hipStream_t s) {
         if (p.res) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_RES>), g, b, lds, s, p, ntiles, cset); return hipGetLastError(); }
     }
     hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, LN, PX_NONE>), g, b, lds, s, p, ntiles, cset);
+    return hipGetLastError();
+}
+
+// split-K form: units = tiles * ksplit, fp32 partials (see EPI_PARTIAL); the caller runs the reduction afterwards
+static hipError_t launch_igemm_pers_partial_t(const IGemmParams& p, hipStream_t s) {
+    constexpr int TP = 256, TC = 320;
+    constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 2 * AUX_BYTES;
+    const int units = ((p.M + TP - 1) / TP) * (p.Cout / TC) * p.ksplit;
+    const int n_cu = device_cu_count();
+    const int grid = units < n_cu ? units : n_cu;
+    static std::atomic<uint64_t> attr_seen{0};
+    if (first_use_on_device(attr_seen))
+        (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PARTIAL, false, PX_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static std::atomic<unsigned> launch_no{0};
+    const int cset = (int)(launch_no.fetch_add(1) % CSETS);
+    hipLaunchKernelGGL((igemm_pers_kernel<EPI_PARTIAL, false, PX_NONE>), dim3(grid), dim3(512), lds, s, p, units, cset);
     return hipGetLastError();
 }
 

@@ -47,6 +47,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int part
 
 }  // namespace
 
+hipError_t launch_splitk_reduce(const IGemmParams& p, hipStream_t s);
+
 hipError_t launch_igemm_splitk(const IGemmParams& p, hipStream_t s) {
     constexpr int WC = 4, NI = 5, TP = 128, TC = 16 * NI * WC;
     const int ntaps = (p.mode == IG_DENSE) ? 1 : 9;
@@ -59,6 +61,11 @@ hipError_t launch_igemm_splitk(const IGemmParams& p, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_PLAIN, NI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     hipLaunchKernelGGL((igemm_kernel<WC, EPI_PLAIN, NI, true>), dim3(tiles * p.ksplit), dim3(128 * WC), lds, s, p);
+    return launch_splitk_reduce(p, s);
+}
+
+// partial[ksplit][M][Cout] fp32 -> Y with the fused epilogue's arithmetic (also behind the persistent split-K kernel)
+hipError_t launch_splitk_reduce(const IGemmParams& p, hipStream_t s) {
     const long long MN = (long long)p.M * p.Cout;
     const int OHW = p.OH * p.OW;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, p.partial, p.ksplit, MN, p.M,

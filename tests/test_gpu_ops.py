@@ -302,6 +302,44 @@ def test_igemm_splitk_matches_unsplit(N, H, W, Cin, C2, Cout, mode, ks):
     assert (diff > 0).float().mean().item() < 0.02 and diff.max().item() <= 2e-3 * ref.float().abs().max().item()
 
 
+@pytest.mark.parametrize("N,H,W,Cin,C2,Cout", [(160, 8, 8, 1280, 0, 1280), (160, 8, 8, 1280, 1280, 1280), (157, 8, 8, 640, 0, 1280), (100, 9, 7, 640, 320, 640)])
+def test_persistent_splitk_is_bit_identical(N, H, W, Cin, C2, Cout):
+    """Split-K on the persistent 256 x 320 tile (three parts of three taps: (tile, part) units, fp32 partials, the common
+    reduction kernel) against the 128-row split-K kernel with the same three parts (`igemm_splitk` = 2 keeps every split
+    launch on the 128-row tile): same k order inside a part, same reduction -> the same bits, ragged last row tile and
+    channel concat included; and both agree with the unsplit kernel to fp32 summation order."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    x = U.f16_randn(N, H, W, Cin, seed=1).to(d)
+    x2 = U.f16_randn(N, H, W, C2, seed=2).to(d) if C2 else None
+    w = U.f16_randn(Cout, 9 * (Cin + C2), seed=3, scale=(9 * (Cin + C2)) ** -0.5).to(d)
+    b = U.f16_randn(Cout, seed=4, scale=0.1).to(d)
+    temb = U.f16_randn(N, Cout, seed=5).to(d)
+    res = U.f16_randn(N, H, W, Cout, seed=6).to(d)
+    ref = U.op_igemm(x, w, b, X2=x2, temb=temb, res=res, mode=1)
+    ws = torch.empty(3 * N * H * W * Cout, dtype=torch.float32, device=d)
+
+    def run():
+        y = torch.full_like(ref, float("nan"))
+        ws.fill_(float("nan"))
+        assert lib.dm_op_igemm_splitk(U.stream(), U.ptr(x), U.ptr(x2), U.ptr(w), U.ptr(b), U.ptr(temb), U.ptr(res), U.ptr(y),
+                                      N, H, W, Cin, C2, Cout, H, W, 1, temb.stride(0), 3, U.ptr(ws)) == 0
+        torch.cuda.synchronize()
+        return y
+    try:
+        y_pers = run()
+        y_again = run()
+        assert lib.dm_set_option(b"igemm_splitk", 2) == 0
+        y_small = run()
+    finally:
+        lib.dm_set_option(b"igemm_splitk", 1)
+    assert not torch.isnan(y_pers.float()).any()
+    assert torch.equal(y_pers, y_small) and torch.equal(y_pers, y_again)
+    diff = (y_pers.float() - ref.float()).abs()
+    assert (diff > 0).float().mean().item() < 0.02 and diff.max().item() <= 2e-3 * ref.float().abs().max().item()
+
+
 @pytest.mark.parametrize("M,C,Cout,epi", [(300, 320, 960, 0), (4096, 640, 640, 0), (131072 + 5, 320, 2560, 1), (8192, 1280, 10240, 1),
                                           (655360, 320, 320, 0)])
 def test_layernorm_folded_into_linear(M, C, Cout, epi):
