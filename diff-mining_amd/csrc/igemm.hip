@@ -72,15 +72,19 @@ int igemm_splitk_parts(const IGemmParams& p, int spatial) {
     return 1;
 }
 
-// the split-K launches the persistent 256 x 320 tile takes: 3x3 convolution, three tap-aligned parts, plain epilogue, at
-// least one unit per CU
+// the split-K launches the persistent 256 x 320 tile takes: 3x3 convolution, three tap-aligned parts, plain epilogue, and
+// fewer (weighted) rounds than the 128-row tile
 static bool splitk_on_pers(const IGemmParams& p) {
     if (option(OPT_IGEMM_SPLITK) == 2 || p.ksplit != 3 || p.mode == IG_DENSE || p.epi != EPI_PLAIN || p.ln_stats) return false;
     if (p.Cout % 320 != 0 || p.Cin % BK != 0 || p.C1 % BK != 0) return false;
     IGemmParams q = p; q.temb = nullptr; q.res = nullptr;           // those are applied by the reduction kernel
     if (!igemm_pers_ok(q)) return false;
-    const long long units = (long long)((p.M + 255) / 256) * (p.Cout / 320) * p.ksplit;
-    return units >= device_cu_count();
+    // rounds over the CUs x relative k-step cost (a 128-row step is measured at 0.73 of a 256-row one): the 128-row
+    // kernel keeps the launches whose rows do not fill its own first round (a 256-row tile would be half empty)
+    const int n_cu = device_cu_count();
+    const long long up = (long long)((p.M + 255) / 256) * (p.Cout / 320) * p.ksplit;
+    const long long us = (long long)((p.M + 127) / 128) * (p.Cout / 320) * p.ksplit;
+    return (double)((up + n_cu - 1) / n_cu) < 0.73 * (double)((us + n_cu - 1) / n_cu);
 }
 
 // Rows [r0, r1) of a launch as a launch of its own.  Dense rows are independent; for the convolution modes both cuts
