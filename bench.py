@@ -133,7 +133,7 @@ def main():
     for _ in range(args.warmup):
         step()
     if eng is not None:
-        eng.prof_enable(True)
+        eng.prof_enable(os.environ.get("DM_BENCH_NOPROF", "0") in ("", "0"))     # DM_BENCH_NOPROF=1: cost of the per-launch events (diagnostic)
         eng.prof_read()
     if world > 1:
         dist.barrier()
