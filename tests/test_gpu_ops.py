@@ -648,3 +648,72 @@ def test_ln_stats_kernels_against_torch(C, rows):
             assert ((stats[:, 1].double() - ref_rstd) / ref_rstd).abs().max().item() < 2e-6
     finally:
         lib.dm_set_option(b"ln_stats_g", 1)
+
+
+def test_igemm_dispatch_fuzz_over_batch_sizes():
+    """Whatever the batch size makes of the tile count — all rows on the 128-row tile, all on the persistent 256 x 320
+    tile, or full rounds on the persistent tile plus a 128-row tail — a launch returns the bits of the 128-row kernel
+    (`igemm_big` = 0): random sample counts at the 16x16 / 32x32 / 8x8 levels, every epilogue the U-Net uses there."""
+    import random
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    rng = random.Random(77)
+    g = torch.Generator(device="cuda").manual_seed(78)
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g, device=d, dtype=torch.float32) * scale).half()
+    kinds = {0: 0, 1: 0, 2: 0}
+    try:
+        for it in range(24):
+            H = W = rng.choice([8, 16, 16, 16, 32])
+            N = rng.randint(1, 40) if it % 3 == 0 else rng.randint(*{8: (300, 900), 16: (90, 260), 32: (25, 70)}[H])
+            Cin, Cout = rng.choice([(640, 1280), (1280, 1280), (640, 640), (1280, 640)])
+            mode = rng.choice([0, 1, 1])
+            extra = rng.choice(["", "temb", "res"]) if mode else rng.choice(["", "res"])
+            taps = 9 if mode else 1
+            x = rnd(N, H, W, Cin)
+            w = rnd(Cout, taps * Cin, scale=(taps * Cin) ** -0.5)
+            b = rnd(Cout, scale=0.1)
+            tb = rnd(N, Cout) if extra == "temb" else None
+            rs = rnd(N, H, W, Cout) if extra == "res" else None
+            M = N * H * W
+            assert lib.dm_set_option(b"igemm_big", -1) == 0
+            head = lib.dm_op_igemm_head_rows(M, H * W, Cin, Cout, mode)
+            kinds[0 if head == 0 else (1 if head == M else 2)] += 1
+            y = U.op_igemm(x, w, b, temb=tb, res=rs, mode=mode)
+            assert lib.dm_set_option(b"igemm_big", 0) == 0
+            y0 = U.op_igemm(x, w, b, temb=tb, res=rs, mode=mode)
+            assert torch.equal(y, y0), (it, N, H, Cin, Cout, mode, extra, head)
+    finally:
+        lib.dm_set_option(b"igemm_big", -1)
+    print("dispatch kinds (128-row / persistent / head+tail):", kinds)
+    assert kinds[0] > 0 and kinds[1] > 0 and kinds[2] > 0
+
+
+def test_attention_cross_fuzz():
+    """The resident-K/V cross-attention kernel on random (samples, query count, prompt slots) against the generic kernel."""
+    import random
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    rng = random.Random(5)
+    try:
+        for it in range(10):
+            D = rng.choice([40, 80])
+            heads, Tk = 8, 77
+            B = rng.randint(1, 9)
+            Tq = rng.choice([256, 300, 1024, 1111, 4096])
+            P = rng.randint(1, 3)
+            Cc = heads * D
+            q = U.f16_randn(B, Tq, Cc, seed=100 + it).to(d)
+            kv = U.f16_randn(P, Tk, 2 * Cc, seed=200 + it).to(d)
+            slots = torch.tensor([rng.randrange(P) for _ in range(B)], dtype=torch.int32, device=d)
+            assert lib.dm_set_option(b"attn_cross", 1) == 0
+            o = U.op_attention(q, kv[..., :Cc], kv[..., Cc:], heads, slots=slots)
+            assert lib.dm_set_option(b"attn_cross", 0) == 0
+            o0 = U.op_attention(q, kv[..., :Cc], kv[..., Cc:], heads, slots=slots)
+            assert not torch.isnan(o.float()).any()
+            U.assert_close_fp16(o, o0.float().cpu(), f"cross fuzz it={it} D={D} B={B} Tq={Tq}", rel=3e-3, abs_frac=4e-3)
+    finally:
+        lib.dm_set_option(b"attn_cross", 1)
