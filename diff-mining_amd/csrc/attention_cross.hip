@@ -88,7 +88,8 @@ void attn_cross_kernel(AttnParams p, int nsplit) {
     const int unit = (t / p.heads) * 8 + x;                  // (sample, slice)
     if (unit >= p.B * nsplit) return;
     const int b = unit / nsplit, part = unit - b * nsplit;
-    const int kvb = p.kv_slot ? p.kv_slot[b] : (p.slot_div > 0 ? b / p.slot_div : b);
+    int kvb = p.kv_slot ? p.kv_slot[b] : (p.slot_div > 0 ? b / p.slot_div : b);
+    if (p.n_slots > 0) kvb = kvb < 0 ? 0 : (kvb < p.n_slots ? kvb : p.n_slots - 1);      // memory safety: never beyond the registered prompts
     const int nqb = (p.Tq + 64 * QF - 1) / (64 * QF);
     const int qb0 = (int)((long long)part * nqb / nsplit), qb1 = (int)((long long)(part + 1) * nqb / nsplit);
 

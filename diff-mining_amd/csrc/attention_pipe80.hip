@@ -126,7 +126,8 @@ void attn_pipe80_kernel(AttnParams p) {
     const int h = bh % p.heads;
     const int b = bh / p.heads;
     const int q0 = qblk * (64 * QF) + wid * (16 * QF);
-    const int kvb = p.kv_slot ? p.kv_slot[b] : (p.slot_div > 0 ? b / p.slot_div : b);
+    int kvb = p.kv_slot ? p.kv_slot[b] : (p.slot_div > 0 ? b / p.slot_div : b);
+    if (p.n_slots > 0) kvb = kvb < 0 ? 0 : (kvb < p.n_slots ? kvb : p.n_slots - 1);      // memory safety: never beyond the registered prompts
 
     const f16* Qb = p.Q + (size_t)b * p.bsq + h * D;
     const f16* Kb = p.K + (size_t)kvb * p.bsk + h * D;

@@ -34,7 +34,7 @@ inline int device_cu_count() {
 
 // Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of
 // the same name in upper case with a DM_ prefix (DM_IGEMM_PERSIST=0 ...), changeable through dm_set_option().
-enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_COUNT };
+enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_COUNT };
 int option(Option o);                       // engine.hip
 int set_option(const char* name, int value);   // 0 on success
 
@@ -93,6 +93,7 @@ struct AttnParams {
     long long bsq, bsk, bsv, bso;    // batch strides in elements
     const int32_t* kv_slot;          // optional: K/V batch index per sample (prompt slot)
     int slot_div;                    // if > 0 (and kv_slot == nullptr): K/V batch index = sample / slot_div
+    int n_slots = 0;                 // > 0: K/V batch indices are clamped to [0, n_slots) on the device (prompt cache rows)
     int B, heads, Tq, Tk, D;
     float scale;
 };

@@ -627,7 +627,7 @@ struct Fwd {
             ap.Q = q.p; ap.K = kv; ap.V = kv + C; ap.O = a.p;
             ap.ldq = C; ap.ldk = 2 * C; ap.ldv = 2 * C; ap.ldo = C;
             ap.bsq = (long long)T * C; ap.bsk = (long long)CTX_LEN * 2 * C; ap.bsv = ap.bsk; ap.bso = (long long)T * C;
-            ap.kv_slot = slot_div > 0 ? nullptr : slots; ap.slot_div = slot_div;
+            ap.kv_slot = slot_div > 0 ? nullptr : slots; ap.slot_div = slot_div; ap.n_slots = e->n_prompts;
             ap.B = B; ap.heads = HEADS; ap.Tq = T; ap.Tk = CTX_LEN; ap.D = C / HEADS;
             ap.scale = 1.0f / sqrtf((float)ap.D);
             DM_TRY(prof_begin(1, 4.0 * B * HEADS * (double)T * CTX_LEN * ap.D, B * T, CTX_LEN, ap.D, 101));
@@ -993,7 +993,7 @@ namespace {
 struct OptDef { const char* name; const char* env; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
-    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1},
+    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<int> g_opt_init{0};

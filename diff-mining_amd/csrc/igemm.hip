@@ -28,6 +28,7 @@ namespace dm {
 hipError_t launch_igemm64(const IGemmParams& p, hipStream_t s);      // igemm64.hip (64-channel waves)
 hipError_t launch_igemm_splitk(const IGemmParams& p, hipStream_t s);  // igemm_splitk.hip
 hipError_t launch_igemm_tile_ln(const IGemmParams& p, hipStream_t s);  // igemm_ln.hip
+hipError_t launch_igemm_tile_ln_half(const IGemmParams& p, hipStream_t s);
 hipError_t launch_igemm_pers(const IGemmParams& p, hipStream_t s);     // igemm_pers.hip (256 x 320 tile, persistent)
 hipError_t launch_igemm_pers_ln(const IGemmParams& p, hipStream_t s);  // igemm_pers_ln.hip
 hipError_t launch_igemm_pers_partial(const IGemmParams& p, hipStream_t s);   // igemm_pers_part.hip (split-K units, fp32 partials)
@@ -182,6 +183,7 @@ hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
         if (p.Cout % 160 != 0 || p.mode == IG_CONV3_S2P0) return launch_igemm64(p, s);        // VAE channel counts
         if (p.Cin % BK != 0 || p.C1 % BK != 0 || p.M <= 0) return hipErrorInvalidValue;
     }
+    if (option(OPT_IGEMM_EXP) == 1 && p.epi == EPI_GEGLU) return p.ln_stats ? launch_igemm_tile_ln_half(p, s) : launch_t<2, 5>(p, s);
     const int head = head_rows(p);
     if (head <= 0) return launch_small(p, s);
     const IGemmParams h = head < p.M ? row_range(p, 0, head) : p;

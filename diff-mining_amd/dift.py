@@ -1,11 +1,14 @@
 """Host-side mirror of the reference's DIFT featuriser (diffmining/typicality/dift.py:173-232) over
 the HIP engine.
 
-`SDFeaturizer.forward(latents, prompt_embeds, t=261, up_ft_index=1, ensemble_size=8)` keeps the
-reference's argument meaning and its output `[1, C, H/16, W/16]` (for up_ft_index=1), with two
-stated differences: `forward` takes the scaled VAE latent(s) (`forward_image` starts from pixels like
-dift.py:214-232 when VAE weights are loaded — one encoder pass, `ensemble_size` posterior samples), and
-the prompt arrives as CLIP hidden states `[1,77,768]` rather than as a string (text tower is outside).
+`SDFeaturizer.forward(img_tensor, prompt, t=261, up_ft_index=1, ensemble_size=8)` keeps the reference's
+argument meaning and its output `[1, C, H/16, W/16]` (for up_ft_index=1):
+  * `img_tensor` with 3 channels is an image in [-1, 1] like dift.py:214-232 (needs VAE weights on the engine: one
+    encoder pass, `ensemble_size` posterior samples — the reference encodes the same image `ensemble_size` times);
+    with 4 channels it is the scaled VAE latent (callers that hold latents);
+  * `prompt` is a string like the reference's (`pipe.encode_prompt`, dift.py:222-226: tokenizer with
+    padding="max_length", CLIP text tower, last hidden state) when the featurizer was built with a tokenizer and the
+    engine holds CLIP text weights, or the CLIP hidden states `[1,77,768]` themselves.
 `patch_embeddings` is the DIFT branch of `Cluster.compute_embeddings` (cluster.py:288-299) with a
 per-image cache of the feature map.
 """
@@ -35,8 +38,11 @@ def feature_boxes(boxes_px: Sequence[Tuple[int, int, int, int]], image_hw: Tuple
 
 
 class SDFeaturizer:
-    def __init__(self, engine: UNetEngine, cache_size: int = 64):
+    def __init__(self, engine: UNetEngine, cache_size: int = 64, tokenizer=None):
+        """`tokenizer`: e.g. transformers' `CLIPTokenizer` (dift.py:203); only needed for string prompts."""
         self.engine = engine
+        self.tokenizer = tokenizer
+        self._prompt_cache: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         self.device = engine.device
         self.acp = scheduler_alphas_cumprod().to(self.device)
         self._cache: "OrderedDict[object, torch.Tensor]" = OrderedDict()   # key -> ensemble-mean map on the GPU
@@ -48,11 +54,41 @@ class SDFeaturizer:
         return (a ** 0.5) * latents + ((1 - a) ** 0.5) * noise
 
     @torch.no_grad()
-    def forward(self, latents, prompt_embeds, t: int = 261, up_ft_index: int = 1, ensemble_size: int = 8,
-                noise: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None):
-        """latents [1,4,h,w] (repeated `ensemble_size` times, dift.py:220) or [ensemble_size,4,h,w]
-        (independent posterior draws, dift.py:187); prompt_embeds [1,77,768].
+    def encode_prompt(self, prompt):
+        """`pipe.encode_prompt(prompt, do_classifier_free_guidance=False)[0]` (dift.py:222-226) -> [1,77,768] fp32 on the
+        GPU: tokenizer (padding="max_length", truncation) on the host, CLIP text tower on the engine; one entry per
+        distinct string is kept (the reference re-encodes the category prompt for every patch, cluster.py:224-226)."""
+        if torch.is_tensor(prompt):
+            return prompt.reshape(1, 77, -1)
+        if not isinstance(prompt, str):
+            raise TypeError(f"prompt must be a str or a [1,77,768] tensor, got {type(prompt).__name__}")
+        hit = self._prompt_cache.get(prompt)
+        if hit is not None:
+            self._prompt_cache.move_to_end(prompt)
+            return hit
+        if self.tokenizer is None:
+            raise ValueError("a string prompt needs SDFeaturizer(engine, tokenizer=...) and CLIP text weights on the engine "
+                             "(engine.load_clip_state_dict); pass the [1,77,768] hidden states otherwise")
+        tok = self.tokenizer
+        ids = tok([prompt], max_length=tok.model_max_length, padding="max_length", truncation=True, return_tensors="pt").input_ids
+        emb = self.engine.clip_encode(ids)
+        self._prompt_cache[prompt] = emb
+        while len(self._prompt_cache) > 256:
+            self._prompt_cache.popitem(last=False)
+        return emb
+
+    @torch.no_grad()
+    def forward(self, img_tensor, prompt, t: int = 261, up_ft_index: int = 1, ensemble_size: int = 8,
+                noise: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None, vae_noise=None):
+        """`SDFeaturizer.forward` (dift.py:214-232).  img_tensor: image [1,3,H,W] / [3,H,W] in [-1,1] (VAE-encoded here),
+        or latents [1,4,h,w] (repeated `ensemble_size` times, dift.py:220) / [ensemble_size,4,h,w] (independent
+        posterior draws, dift.py:187); prompt: str or hidden states [1,77,768].
         Returns the ensemble-mean feature [1, C, h', w'] fp32 (dift.py:231)."""
+        prompt_embeds = self.encode_prompt(prompt)
+        if img_tensor.shape[-3] == 3:
+            return self.forward_image(img_tensor, prompt_embeds, t, up_ft_index, ensemble_size, vae_noise=vae_noise, noise=noise,
+                                      generator=generator)
+        latents = img_tensor
         lat = latents.to(self.device, torch.float32)
         if lat.shape[0] == 1:
             lat = lat.repeat(ensemble_size, 1, 1, 1)
@@ -75,6 +111,7 @@ class SDFeaturizer:
         image `ensemble_size` times and takes one posterior sample of each (dift.py:220,187); here the VAE
         encoder runs once and `ensemble_size` posterior samples are drawn from its moments (same distribution).
         img_tensor [3,H,W] or [1,3,H,W] in [-1,1] (`dift_pre`, dift.py:19-21).  Needs VAE weights."""
+        prompt_embeds = self.encode_prompt(prompt_embeds)
         img = img_tensor if img_tensor.dim() == 4 else img_tensor[None]
         _, _, H, W = img.shape
         if vae_noise is None:

@@ -239,11 +239,35 @@ class UNetEngine:
                     "dm_vae_encode")
         return (lat, mom) if return_moments else lat
 
-    def load_safetensors(self, path: str):
+    def load_safetensors(self, path: str, check_config: bool = True):
         """`unet/diffusion_pytorch_model.safetensors` of a diffusers pipeline directory (the format
-        the reference's `--export-only` writes, finetuning/base.py:245-250)."""
+        the reference's `--export-only` writes, finetuning/base.py:245-250).  The `config.json` next to it (the file
+        `from_pretrained` builds the U-Net from, compute.py:65-70) is read first: an architecture other than SDv1.5's
+        is rejected by key name (`unet_spec.check_unet_config`) instead of by a tensor-shape message later."""
         from safetensors.numpy import load_file
+        cfg = os.path.join(os.path.dirname(os.path.abspath(path)), "config.json")
+        if check_config and os.path.isfile(cfg):
+            from .unet_spec import check_unet_config_file
+            try:
+                check_unet_config_file(cfg)
+            except ValueError as e:
+                raise EngineError(f"{cfg}: {e}") from None
         self.load_state_dict(load_file(path))
+
+    def load_pipeline_dir(self, model_path: str, vae: bool = True, text_encoder: bool = True):
+        """`StableDiffusionPipeline.from_pretrained(model_path)` as far as the path needs it (compute.py:65-73): the
+        U-Net (config.json checked), and when present the VAE encoder and the CLIP text tower of the directory."""
+        unet = os.path.join(model_path, "unet", "diffusion_pytorch_model.safetensors")
+        if not os.path.isfile(unet):
+            raise EngineError(f"{unet} not found (a diffusers pipeline directory with safetensors weights is expected)")
+        self.load_safetensors(unet)
+        v = os.path.join(model_path, "vae", "diffusion_pytorch_model.safetensors")
+        if vae and os.path.isfile(v):
+            self.load_vae_safetensors(v)
+        c = os.path.join(model_path, "text_encoder", "model.safetensors")
+        if text_encoder and os.path.isfile(c):
+            from safetensors.numpy import load_file
+            self.load_clip_state_dict(load_file(c))
 
     # -- prompts ---------------------------------------------------------------------------------
     def set_prompts(self, ctx):
@@ -258,12 +282,15 @@ class UNetEngine:
         self.prompt_generation += 1
 
     def _slots(self, slots, batch):
-        """Prompt slots of a batch -> int32 on the device, range-checked against the registered prompts (a slot
-        beyond them would read another prompt set's stale K/V rows)."""
+        """Prompt slots of a batch -> int32 on the device.  Host-side inputs (lists, CPU tensors) are range-checked against
+        the registered prompts here (a slot beyond them would read another prompt set's stale K/V rows); a tensor that
+        already lives on the device is not pulled back for the check — that would be two blocking syncs in the hot path
+        (`TypicalityScorer.compute_loss` passes `torch.unique`'s inverse, in range by construction) — the kernels clamp
+        device-side slots to the registered range instead (memory-safe, never another engine's rows)."""
         torch = self._torch
         s = torch.as_tensor(slots)
         assert s.shape == (batch,), (s.shape, batch)
-        if s.numel():
+        if s.numel() and not s.is_cuda:
             lo, hi = int(s.min()), int(s.max())
             if lo < 0 or hi >= self.n_prompts:
                 raise EngineError(f"prompt slot {lo if lo < 0 else hi} outside the {self.n_prompts} prompts registered "

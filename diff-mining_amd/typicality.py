@@ -42,7 +42,8 @@ from .engine import UNetEngine
 
 class CategoryFeatures:
     """`CategoryFeatures` of compute.py:27-54 over the engine's CLIP text tower: one prompt per category
-    (templates of compute.py:41-48, '' = the null prompt), tokenised on the host by `tokenizer` (e.g.
+    (templates of compute.py:41-48, '' = the null prompt; which = "xray": the X-ray application's `Embed`,
+    applications/xray/compute.py:40-60, whose null prompt is the non-empty "Chest X-Ray"), tokenised on the host by `tokenizer` (e.g.
     transformers' `CLIPTokenizer`, called exactly like compute.py:36-37), encoded on the GPU."""
 
     def __init__(self, engine: UNetEngine, tokenizer, which: str):
@@ -56,6 +57,8 @@ class CategoryFeatures:
             return [(f"A car at the {c}'s." if len(c) else "A car.") for c in categories]
         if which == "places":
             return [("Image of " + c.replace("_", " ") + "." if len(c) else "") for c in categories]
+        if which == "xray":      # `Embed.embed_diseases` (applications/xray/compute.py:54-57): the null prompt is NOT empty
+            return [(f"Chest X-Ray with {c}." if len(c) else "Chest X-Ray") for c in categories]
         return [(f"{c}" if len(c) else "") for c in categories]
 
     def tokenize(self, prompts):
@@ -293,21 +296,91 @@ def shard_indices(n_items: int, rank: int, world: int) -> Sequence[int]:
     return list(range(rank, n_items, world))
 
 
-def gather_scores(local_scores: torch.Tensor, n_items: int, rank: int, world: int) -> torch.Tensor:
-    """Single all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests) of the per-image T(x|c)
-    scalars; returns them in global image order.  No other collective exists on the path."""
+def _all_gather_padded(local: torch.Tensor, per: int, world: int) -> torch.Tensor:
+    """ONE all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests) of `local` [n_local, ...] padded to `per` rows;
+    returns [world, per, ...]."""
     import torch.distributed as dist
-    per = (n_items + world - 1) // world
-    buf = torch.full((per,), float("nan"), dtype=torch.float32, device=local_scores.device)
-    buf[: local_scores.numel()] = local_scores.to(torch.float32)
+    buf = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    buf[: local.shape[0]] = local
+    out = torch.empty((world,) + tuple(buf.shape), dtype=buf.dtype, device=buf.device)
+    dist.all_gather_into_tensor(out.view(-1), buf.view(-1)) if hasattr(dist, "all_gather_into_tensor") and buf.is_cuda \
+        else dist.all_gather(list(out.unbind(0)), buf)
+    return out
+
+
+def gather_scores(local_scores: torch.Tensor, n_items: int, rank: int, world: int) -> torch.Tensor:
+    """Single all-gather of the per-image T(x|c) scalars of the ranks' `r::world` shards; returns them in global
+    image order.  No other collective exists on the path.  At world 1 this is the identity: the local tensor is
+    returned as it is (no kernel, no copy)."""
+    import torch.distributed as dist
     if world == 1 or not dist.is_initialized():
-        allv = buf[None]
+        assert local_scores.numel() == n_items, (local_scores.shape, n_items)
+        return local_scores if local_scores.dtype == torch.float32 else local_scores.to(torch.float32)
+    per = (n_items + world - 1) // world
+    allv = _all_gather_padded(local_scores.to(torch.float32).reshape(-1), per, world)        # [world, per]
+    # rank r holds items r, r + world, ...: item i sits at allv[i % world, i // world]  ->  transpose + trim
+    return allv.t().reshape(-1)[:n_items].contiguous()
+
+
+def gather_grids(local_grids: torch.Tensor, n_items: int, rank: int, world: int) -> torch.Tensor:
+    """Second gather mode (SURVEY 8e): the fp16 loss grids [n_local, N, n_cond, 4, h, w] of the ranks' `r::world`
+    image shards -> [n_items, N, n_cond, 4, h, w] in global image order (one all-gather; 655 KB per image at N = 10)."""
+    import torch.distributed as dist
+    if world == 1 or not dist.is_initialized():
+        assert local_grids.shape[0] == n_items
+        return local_grids
+    per = (n_items + world - 1) // world
+    allv = _all_gather_padded(local_grids, per, world)                                        # [world, per, ...]
+    return allv.transpose(0, 1).reshape((per * world,) + tuple(local_grids.shape[1:]))[:n_items].contiguous()
+
+
+def draw_shard(n_draws: int, rank: int, world: int) -> Sequence[int]:
+    """Draws of ONE image a rank scores when there are fewer images than ranks (SURVEY 8e fallback): `r::world`."""
+    return list(range(rank, n_draws, world))
+
+
+@torch.no_grad()
+def compute_losses_draw_split(scorer: "TypicalityScorer", x, country_embeds, rank: int, world: int, B: int = 10,
+                              noises=None, timesteps=None):
+    """`D.compute_losses` of ONE image with its N draws split over the ranks (n_img < world): every rank
+    makes the same N (eps, t) draws (same seed, compute.py:139-141), scores draws `rank::world` under all prompts, and
+    one all-gather of the fp16 grids reassembles [N, n_cond, 4, h, w] on every rank — bit-equal to the single-rank grid,
+    because a sample's loss does not depend on the batch it rides in."""
+    if noises is None or timesteps is None:
+        noises, timesteps = scorer.draw(x.shape)
+    N = noises.shape[0]
+    mine = draw_shard(N, rank, world)
+    idx = torch.as_tensor(mine, dtype=torch.long)
+    n_cond = country_embeds.shape[0]
+    if len(mine):
+        local = scorer.compute_losses(x, country_embeds, B, noises=noises[idx], timesteps=timesteps[idx], to_host=False)
     else:
-        out = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(out, buf)
-        allv = torch.stack(out, 0)
-    res = torch.empty(n_items, dtype=torch.float32, device=local_scores.device)
-    for r in range(world):
-        idx = shard_indices(n_items, r, world)
-        res[idx] = allv[r, : len(idx)]
-    return res
+        local = torch.zeros((0, n_cond) + tuple(x.shape[1:]), dtype=torch.float16, device=scorer.device)
+    return gather_grids(local, N, rank, world)
+
+
+@torch.no_grad()
+def score_images_sharded(scorer: "TypicalityScorer", latents, country_embeds, rank: int, world: int, B: int = 10,
+                         mode: str = "scalars"):
+    """The multi-GPU scoring step: `latents` = the whole work list [n_img, 4, h, w] (every rank sees the
+    list, as every reference process sees the submission files, compute.py:337-341).
+      n_img >= world: rank r scores images `r::world`; ONE all-gather of the per-image T(x|c) fp32 scalars
+                      (mode "scalars") or of the fp16 grids (mode "grids");
+      n_img <  world: every image's N draws are split over the ranks and the grids gathered (`compute_losses_draw_split`);
+                      the scalars are then reduced from the full grids on every rank.
+    Returns T(x|c) [n_img] fp32 (mode "scalars") or the grids [n_img, N, n_cond, 4, h, w] fp16 (mode "grids")."""
+    assert mode in ("scalars", "grids")
+    n_img = latents.shape[0]
+    if n_img >= world:
+        mine = shard_indices(n_img, rank, world)
+        grids = [scorer.compute_losses(latents[i:i + 1], country_embeds, B, to_host=False) for i in mine]
+        if mode == "grids":
+            local = torch.stack(grids) if grids else torch.zeros((0,), dtype=torch.float16, device=scorer.device)
+            return gather_grids(local, n_img, rank, world)
+        local = torch.cat([scorer.typicality_scalar(g).reshape(1) for g in grids]) if grids else \
+            torch.zeros(0, dtype=torch.float32, device=scorer.device)
+        return gather_scores(local, n_img, rank, world)
+    grids = torch.stack([compute_losses_draw_split(scorer, latents[i:i + 1], country_embeds, rank, world, B) for i in range(n_img)])
+    if mode == "grids":
+        return grids
+    return torch.cat([scorer.typicality_scalar(g).reshape(1) for g in grids])

@@ -167,3 +167,68 @@ def param_count(cfg: UNetConfig = SD15) -> int:
             k *= s
         n += k
     return n
+
+
+# ---- unet/config.json of an exported pipeline directory ---------------------------------------------------------
+# The reference loads `StableDiffusionPipeline.from_pretrained(model_path)` (compute.py:65-70), i.e. diffusers builds the
+# U-Net that `<model_path>/unet/config.json` describes (written by `--export-only`, finetuning/base.py:245-250).  The
+# engine implements exactly one architecture, so a config that describes another one is rejected BY KEY before any
+# tensor is packed (otherwise the first symptom would be a tensor-shape message, or — for options that do not change a
+# shape, like `use_linear_projection` with equal sizes or `upcast_attention` — silently different arithmetic).
+SD15_UNET_CONFIG = {
+    "in_channels": 4, "out_channels": 4, "block_out_channels": [320, 640, 1280, 1280], "layers_per_block": 2,
+    "cross_attention_dim": 768, "attention_head_dim": 8, "norm_num_groups": 32, "norm_eps": 1e-5, "act_fn": "silu",
+    "down_block_types": ["CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"],
+    "up_block_types": ["UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"],
+    "mid_block_type": "UNetMidBlock2DCrossAttn", "flip_sin_to_cos": True, "freq_shift": 0, "downsample_padding": 1,
+    "mid_block_scale_factor": 1, "center_input_sample": False,
+}
+# keys later diffusers versions add; absent (SDv1.5's own config.json) or at these defaults is fine, anything else is not
+_OPTIONAL_DEFAULTS = {
+    "use_linear_projection": False, "dual_cross_attention": False, "only_cross_attention": False,
+    "upcast_attention": False, "resnet_time_scale_shift": "default", "time_embedding_type": "positional",
+    "class_embed_type": None, "num_class_embeds": None, "addition_embed_type": None, "encoder_hid_dim": None,
+    "encoder_hid_dim_type": None, "transformer_layers_per_block": 1, "num_attention_heads": None,
+    "time_embedding_dim": None, "time_embedding_act_fn": None, "timestep_post_act": None, "time_cond_proj_dim": None,
+    "conv_in_kernel": 3, "conv_out_kernel": 3, "projection_class_embeddings_input_dim": None,
+    "class_embeddings_concat": False, "mid_block_only_cross_attention": None, "cross_attention_norm": None,
+    "resnet_skip_time_act": False, "resnet_out_scale_factor": 1.0, "attention_type": "default", "dropout": 0.0,
+    "addition_time_embed_dim": None, "addition_embed_type_num_heads": 64, "reverse_transformer_layers_per_block": None,
+}
+
+
+def check_unet_config(cfg: dict) -> None:
+    """Raise ValueError naming every key of a `unet/config.json` that differs from the SDv1.5 architecture."""
+    bad = []
+    cls = cfg.get("_class_name")
+    if cls is not None and cls != "UNet2DConditionModel":
+        bad.append(f"_class_name = {cls!r} (want 'UNet2DConditionModel')")
+
+    def same(a, b):
+        if isinstance(a, (list, tuple)) or isinstance(b, (list, tuple)):
+            return isinstance(a, (list, tuple)) and isinstance(b, (list, tuple)) and list(a) == list(b)
+        if isinstance(a, float) or isinstance(b, float):
+            return a is not None and b is not None and abs(float(a) - float(b)) <= 1e-12 + 1e-6 * abs(float(b))
+        return a == b
+    for k, want in SD15_UNET_CONFIG.items():
+        if k not in cfg:
+            if k in ("mid_block_type", "center_input_sample", "mid_block_scale_factor"):      # newer / optional keys
+                continue
+            bad.append(f"{k} missing (want {want!r})")
+        elif not same(cfg[k], want):
+            bad.append(f"{k} = {cfg[k]!r} (want {want!r})")
+    for k, default in _OPTIONAL_DEFAULTS.items():
+        if k in cfg and cfg[k] is not None and not same(cfg[k], default):
+            if k == "num_attention_heads" and same(cfg[k], 8):
+                continue
+            bad.append(f"{k} = {cfg[k]!r} (only {default!r} is implemented)")
+    if bad:
+        raise ValueError("unet/config.json does not describe the SDv1.5 U-Net this engine implements: " + "; ".join(bad))
+
+
+def check_unet_config_file(path: str) -> dict:
+    import json
+    with open(path) as f:
+        cfg = json.load(f)
+    check_unet_config(cfg)
+    return cfg
