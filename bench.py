@@ -20,7 +20,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
                  achieved = its algorithmic FLOPs / its summed launch time, measured with HIP events
                  on the launch stream over the timed steps (dm_prof_*); peak = 2.5 PFLOP/s dense fp16.
   cpu_baseline — the oracle (fp32 PyTorch-CPU restatement; kind "port") timed on this host's cores on
-                 a bounded sample (4 U-Net forwards @64x64 = 1/5 of one image's work).
+                 one full image of the workload (20 U-Net forwards @64x64, ~45 s).
+`--workload dift|xray` print the same keys for BASELINE configs[3] / [4].
 """
 import argparse
 import json
@@ -93,7 +94,7 @@ def main():
     sync = (lambda: None) if STUB else torch.cuda.synchronize
 
     from diff_mining_amd import synth
-    from diff_mining_amd.typicality import gather_scores
+    from diff_mining_amd.typicality import gather_scores, shard_indices
 
     n_img = args.images
     per_img = N_DRAWS * N_COND
@@ -108,11 +109,13 @@ def main():
         eng = UNetEngine(local_rank)
         eng.load_state_dict(sd)
         if args.workload != "typicality":
-            return side_workload(args, eng, dev)
+            return side_workload(args, eng, dev, sd)
         ldt = torch.float32 if args.latent_dtype == "f32" else torch.float16
         x, eps, t, c = synth.synth_inputs(n_img * world, N_DRAWS, LAT, LAT,
                                           latent_dtype=np.float32 if args.latent_dtype == "f32" else np.float16)
-        x = torch.from_numpy(x)[rank * n_img:(rank + 1) * n_img].to(dev)          # this rank's images
+        # this rank's images of the n_img * world work list: r::world, as the reference's `subs[i::sub_split]` (compute.py:339)
+        # and as gather_scores files them
+        x = torch.from_numpy(x)[shard_indices(n_img * world, rank, world)].to(dev)
         eps = torch.from_numpy(eps).to(dev)
         t = torch.from_numpy(t).to(dev)
         c = torch.from_numpy(c).to(dev)
@@ -128,7 +131,7 @@ def main():
             loss = eng.score_conds(x, eps_u, t_u, N_COND, x_index=x_index, latent_dtype=ldt)   # [2*n_img*10,4,64,64] fp32, cond-major
             _, scores = eng.reduce_typicality_batched(loss, n_img, N_DRAWS, N_COND, cond_major=True)   # one launch, no torch glue
             last["loss"] = loss
-            return gather_scores(scores, n_img * world, rank, world)
+            return gather_scores(scores, n_img * world, rank, world)     # world 1: the tensor itself (no kernel)
 
     for _ in range(args.warmup):
         step()
@@ -239,9 +242,12 @@ def hbm_traffic_per_launch(launches_per_step):
         return None
 
 
-def side_workload(args, eng, dev):
-    """BASELINE configs[3] (DIFT-161 tap, batch 64) and configs[4] (1024 px per-pixel heat-map)."""
+def side_workload(args, eng, dev, sd):
+    """BASELINE configs[3] (DIFT-161 tap, batch 64) and configs[4] (1024 px per-pixel heat-map) — and the 8f extras
+    (VAE encode, scoring from pixels) — with the same keys as the graded line: `roofline` from the engine's live per-launch
+    HIP events over the timed steps (igemm family), `cpu_baseline` from the oracle on a bounded sample."""
     from diff_mining_amd import synth
+    cfg, dtype_note = None, None
     if args.workload == "dift":
         n_lat, ens, lat = 8, 8, 64
         x, eps, _, c = synth.synth_inputs(n_lat, ens, lat, lat)
@@ -256,6 +262,12 @@ def side_workload(args, eng, dev):
         def step():
             return eng.dift(noisy, tt, slots, 1, ens)[1]
         units, name, flop = n_lat, "DIFT-161 images/s (ensemble 8, tap up_blocks[1], batch 64 @64x64 latent)", 438.79e9 * ens
+        cfg = {"workload": "configs[3]: DIFT-161 feature extraction, single-timestep U-Net forward with the up_blocks[1] tap "
+                           "(dift.py:133-165; BASELINE.json says 'mid-block': SURVEY F6a), batch 64 = 8 images x ensemble 8, 64x64 latent",
+               "images_per_step": n_lat, "ensemble": ens, "t": 161, "up_ft_index": 1}
+        dtype_note = ("the engine computes this path in fp16 (fp32 accumulation / norms / softmax), the reference's SDFeaturizer runs "
+                      "the U-Net in fp32 (dift.py:197-199): a REDUCED-PRECISION number by the bench rule; descriptor deviation vs the "
+                      "fp32 oracle: cosine >= 1 - 5e-7 (tests/test_gpu_e2e.py::test_dift_descriptor_deviation_vs_fp32_oracle)")
     elif args.workload in ("vae", "pixels"):
         n_img, lat = N_IMG, LAT
         eng.load_vae_state_dict(synth.synth_vae_state_dict(seed=0, dtype=np.float16))
@@ -274,62 +286,113 @@ def side_workload(args, eng, dev):
             def step():
                 x = eng.vae_encode(img, vnoise)
                 loss = eng.score_conds(x, eu, tu, N_COND, xi)
-                return loss.view(N_COND, n_img, N_DRAWS, -1).mean(dim=(2, 3))
+                return eng.reduce_typicality_batched(loss, n_img, N_DRAWS, N_COND, cond_major=True)[1]
             units, name, flop = n_img, ("typicality-scored images/s from pixels (VAE encode + 10 t x 2 prompts, 512px, "
                                         "batch 8)"), vae_flop + 20 * 803.27e9
+        cfg = {"workload": f"SURVEY 8f rank 2 ({args.workload}): 8 images @512x512", "images_per_step": n_img}
     else:
         lat = 128
-        x, eps, t, c = synth.synth_inputs(1, N_DRAWS, lat, lat)
+        x, eps, t, c = synth.synth_inputs(1, N_DRAWS, lat, lat, latent_dtype=np.float32)
         xd, ed, td, cd = (torch.from_numpy(a).to(dev) for a in (x, eps, t, c))
         eng.set_prompts(cd)
-        eb, tb = ed.repeat(N_COND, 1, 1, 1), td.repeat(N_COND)
-        slots = torch.arange(N_COND, dtype=torch.int32, device=dev).repeat_interleave(N_DRAWS)
 
         def step():
-            loss = eng.score(xd, eb, tb, slots)
-            grid = loss.view(N_COND, N_DRAWS, 4, lat, lat).transpose(0, 1).contiguous()
-            return eng.reduce_typicality(grid)[0]
+            loss = eng.score_conds(xd, ed, td, N_COND, latent_dtype=torch.float32)         # cond-major rows, as compute.py:150-155
+            return eng.reduce_typicality_batched(loss, 1, N_DRAWS, N_COND, cond_major=True)[0][0]     # [128,128] E_N[L_null - L_c]
         units, name, flop = 1, "X-ray 1024x1024 per-pixel typicality heat-maps/s (latent 128x128, 10 t x 2 prompts)", 4674.01e9 * 20
+        cfg = {"workload": "configs[4]: X-ray 1024x1024 per-pixel typicality heat-map (no patch reduction), latent 128x128, "
+                           "10 t-samples x 2 prompts = 20 U-Net forwards per heat-map (applications/xray/compute.py:117-143,210-218)",
+               "heatmaps_per_step": 1, "unet_forwards_per_heatmap": 20, "latent_dtype_flow": "f32"}
     for _ in range(args.warmup):
         step()
+    eng.prof_enable(os.environ.get("DM_BENCH_NOPROF", "0") in ("", "0"))
+    eng.prof_read()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    prof = eng.prof_read()
+    eng.prof_enable(False)
     val = units * args.steps / dt
-    print(json.dumps({"metric": name, "value": round(val, 4), "unit": "images/s", "n_gpus": 1, "steps": args.steps,
-                      "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": "f16",
-                      "data": "synthetic", "whole_path_tflops": round(val * flop / 1e12, 2),
-                      "whole_path_frac": round(val * flop / 1e12 / PEAK_TFLOPS, 4),
-                      "out_shape": list(out.shape), "memory": eng.memory()}), flush=True)
+    ig_tf = prof["igemm_flops"] / (prof["igemm_ms"] * 1e-3) / 1e12 if prof["igemm_ms"] > 0 else 0.0
+    at_tf = prof["attn_flops"] / (prof["attn_ms"] * 1e-3) / 1e12 if prof["attn_ms"] > 0 else 0.0
+    line = {"metric": name, "value": round(val, 4), "unit": "images/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic", "config": cfg,
+            "roofline": {"bound": "mfma", "kernel": "igemm family (igemm_pers_kernel + igemm_kernel)", "achieved": round(ig_tf, 2),
+                         "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ig_tf / PEAK_TFLOPS, 4), "traffic": None,
+                         "launches": prof["igemm_launches"], "kernel_ms_total": round(prof["igemm_ms"], 3),
+                         "attention_tflops": round(at_tf, 2), "attention_ms_total": round(prof["attn_ms"], 3),
+                         "whole_path_tflops_nominal": round(val * flop / 1e12, 2),
+                         "whole_path_frac_nominal": round(val * flop / 1e12 / PEAK_TFLOPS, 4)},
+            "out_shape": list(out.shape), "memory": eng.memory()}
+    if dtype_note:
+        line["dtype_note"] = dtype_note
+        line["reference_dtype"] = "f32"
+    if not args.no_cpu_baseline and args.workload in ("dift", "xray"):
+        line["cpu_baseline"] = cpu_baseline_side(sd, args.workload)
+    print(json.dumps(line), flush=True)
 
 
-def cpu_baseline(sd):
-    """Oracle (fp32 PyTorch CPU, kind "port") on a bounded sample of the same workload: 2 draws x 2
-    prompts of one 64x64 latent = 4 of the 20 U-Net forwards of one image.  Thread count: the fp32
-    oracle peaks at 16 threads on the GPU box's host (measured 681 / 500 / 169 / 78 GFLOP/s at
-    16 / 32 / 64 / 128 threads), so 16 are used and reported as `cores`."""
-    from diff_mining_amd import synth
-    from oracle import unet_ref as R
+def _oracle_threads():
+    """The fp32 oracle peaks at 16 threads on the GPU box's host (measured 681 / 500 / 169 / 78 GFLOP/s at 16 / 32 / 64 / 128
+    threads), so 16 are used and reported as `cores`."""
     cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
+    return cores
+
+
+def cpu_baseline(sd, forwards=None):
+    """Oracle (fp32 PyTorch CPU, kind "port") on ONE FULL IMAGE of the workload: 10 draws x 2 prompts of one 64x64 latent =
+    the 20 U-Net forwards D.compute_losses makes per image (compute.py:145-152), in two reference-sized chunks of B = 5
+    draws (U-Net batch 10).  DM_CPU_BASELINE_FORWARDS=4 gives the r02 quick sample (2 draws x 2 prompts)."""
+    from diff_mining_amd import synth
+    from oracle import unet_ref as R
+    cores = _oracle_threads()
+    forwards = forwards or int(os.environ.get("DM_CPU_BASELINE_FORWARDS", "20"))
+    draws = max(1, forwards // N_COND)
     sdt = {k: torch.from_numpy(v).float() for k, v in sd.items()}
-    x, eps, t, c = (torch.from_numpy(a) for a in synth.synth_inputs(1, 2, LAT, LAT))
-    nb, tb = torch.cat([eps] * 2), torch.cat([t] * 2)
-    cc = torch.cat([c[0:1].expand(2, -1, -1), c[1:2].expand(2, -1, -1)]).float()
+    x, eps, t, c = (torch.from_numpy(a) for a in synth.synth_inputs(1, draws, LAT, LAT))
     with torch.no_grad():
-        R.compute_loss(sdt, x[:, :, :16, :16], nb[:, :, :16, :16], tb, cc, autocast=False)     # warm-up (small)
+        R.compute_loss(sdt, x[:, :, :16, :16], eps[:1, :, :16, :16], t[:1], c[:1].float(), autocast=False)     # warm-up (small)
         t0 = time.perf_counter()
-        R.compute_loss(sdt, x, nb, tb, cc, autocast=False)
+        grid = R.compute_losses(sdt, x.float(), c.float(), eps.float(), t, B=5, autocast=False)
         dt = time.perf_counter() - t0
-    forwards = 4
+    forwards = draws * N_COND
     return {"value": round(forwards / (N_DRAWS * N_COND) / dt, 6), "unit": "images/s", "cores": cores, "kind": "port",
-            "kind_detail": "port, 4-forward sample (the fp32 oracle restatement; not BASELINE.md §3's 16-image protocol, "
-                           "and not diffusers, which is absent from the image)",
-            "sample": f"{forwards} U-Net forwards @64x64 (1/5 of one image's 20) in {dt:.1f}s, fp32 oracle, torch threads={cores}",
+            "kind_detail": "port: the fp32 oracle restatement (oracle/unet_ref.py) — not diffusers, which is absent from the image",
+            "sample": f"{forwards} U-Net forwards @64x64 ({'one full image: 10 draws x 2 prompts' if forwards == 20 else f'{forwards}/20 of one image'}) "
+                      f"in {dt:.1f}s, fp32 oracle, torch threads={cores}, grid {list(grid.shape)}",
             "gflops": round(forwards * FLOP_PER_FORWARD_64 / dt / 1e9, 1)}
+
+
+def cpu_baseline_side(sd, workload):
+    """The oracle on a bounded sample of a side workload: DIFT = one image (ensemble 8 @64x64, fp32 like the reference,
+    dift.py:197-199); X-ray = one draw x 2 prompts @128x128 (2 of the 20 forwards of one heat-map)."""
+    from diff_mining_amd import synth
+    from oracle import unet_ref as R
+    cores = _oracle_threads()
+    sdt = {k: torch.from_numpy(v).float() for k, v in sd.items()}
+    with torch.no_grad():
+        if workload == "dift":
+            x, eps, _, c = (torch.from_numpy(a) for a in synth.synth_inputs(1, 8, LAT, LAT))
+            noisy = R.add_noise(x.float().expand(8, -1, -1, -1), eps.float(), torch.tensor(161))
+            t0 = time.perf_counter()
+            R.dift_features(sdt, noisy, 161, c[:1].float().expand(8, -1, -1), 1)
+            dt = time.perf_counter() - t0
+            return {"value": round(1.0 / dt, 6), "unit": "images/s", "cores": cores, "kind": "port",
+                    "sample": f"one image = ensemble 8 @64x64, tap up_blocks[1], in {dt:.1f}s, fp32 oracle, torch threads={cores}",
+                    "gflops": round(8 * 438.79 / dt, 1)}
+        x, eps, t, c = (torch.from_numpy(a) for a in synth.synth_inputs(1, 1, 128, 128))
+        nb, tb = torch.cat([eps] * 2).float(), torch.cat([t] * 2)
+        t0 = time.perf_counter()
+        R.compute_loss(sdt, x.float(), nb, tb, c.float(), autocast=False)
+        dt = time.perf_counter() - t0
+        return {"value": round(2.0 / 20.0 / dt, 6), "unit": "images/s", "cores": cores, "kind": "port",
+                "sample": f"1 draw x 2 prompts @128x128 (2 of the 20 forwards of one heat-map) in {dt:.1f}s, fp32 oracle, torch threads={cores}",
+                "gflops": round(2 * 4674.01 / dt, 1)}
 
 
 if __name__ == "__main__":

@@ -34,7 +34,7 @@ inline int device_cu_count() {
 
 // Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of
 // the same name in upper case with a DM_ prefix (DM_IGEMM_PERSIST=0 ...), changeable through dm_set_option().
-enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_COUNT };
+enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_COUNT };
 int option(Option o);                       // engine.hip
 int set_option(const char* name, int value);   // 0 on success
 
@@ -63,10 +63,17 @@ struct IGemmParams {
     // LayerNorm folded into the GEMM (transformer blocks: LN -> Linear): X is the un-normalised token matrix,
     // Wp = W * diag(gamma) (fp16), and the epilogue applies  y = rstd_r * (acc - mean_r * ln_s[c]) + ln_t[c]
     // with ln_s[c] = sum_k Wp[c][k], ln_t[c] = sum_k W[c][k] beta[k] + bias[c];  ln_stats [M][2] = (mean, rstd)
-    const float* ln_stats = nullptr;
+    const float* ln_stats = nullptr;    // nullptr with ln_s set: the kernel takes the row statistics itself from the k loop's LDS tiles
     const float* ln_s = nullptr;
     const float* ln_t = nullptr;
+    float ln_eps = 1e-5f;
+    // persistent 256 x 320 kernel: tile hand-out counters owned by the caller (IGEMM_TILE_CTR_INTS ints, zero between
+    // launches; an engine passes its own, so engines / streams sharing a device never share counters).  nullptr: a
+    // process-wide set per device, valid only while the launches of a device are serialised on one stream (the
+    // operator-level entry points of the parity tests).
+    int* tile_ctr = nullptr;
 };
+constexpr int IGEMM_TILE_CTR_INTS = 8 * 32 + 32;
 hipError_t launch_igemm(const IGemmParams& p, hipStream_t s);
 // number of k parts for a layer with `spatial` output positions per sample (1 = no split); batch independent;
 // the caller provides the workspace
@@ -79,10 +86,16 @@ int igemm_head_rows(const IGemmParams& p);       // rows [0, r) run on the 256 x
 inline bool igemm_pers_ok(const IGemmParams& p) {
     const int nk = ((p.mode == IG_DENSE) ? 1 : 9) * (p.Cin / 64);
     if (nk < 4 || p.Cout % 320 != 0 || p.M < 2) return false;
+    {   // the kernel keeps activation element offsets (row * channels + chunk) in 32 bits: larger tensors take the 128-row tile
+        const long long cmax = p.C1 > p.Cin - p.C1 ? p.C1 : p.Cin - p.C1;
+        const long long src_rows = (p.mode == IG_DENSE) ? (long long)p.M : (long long)(p.M / (p.OH * p.OW > 0 ? p.OH * p.OW : 1)) * p.H * p.W;
+        if (src_rows * cmax >= (1LL << 31)) return false;
+    }
     if (p.mode != IG_DENSE && (p.OH < 1 || p.OW < 1 || p.OH > 511 || p.OW > 511 || p.M / (p.OH * p.OW) > 8191)) return false;   // packed row coordinates
-    if (p.temb && (p.res || p.epi == EPI_GEGLU || p.ln_stats || p.OH * p.OW < 1 || (p.OH * p.OW) % 256 != 0)) return false;
-    if (p.res && (p.epi == EPI_GEGLU || p.ln_stats)) return false;
-    if (p.ln_stats && (p.M & 1)) return false;
+    if (p.temb && (p.res || p.epi == EPI_GEGLU || p.ln_s || p.OH * p.OW < 1 || (p.OH * p.OW) % 256 != 0)) return false;
+    if (p.res && (p.epi == EPI_GEGLU || p.ln_s)) return false;
+    if (p.ln_s && (p.M & 1)) return false;
+    if (p.ln_s && (p.mode != IG_DENSE || p.C1 != p.Cin)) return false;
     return true;
 }
 
@@ -100,13 +113,13 @@ struct AttnParams {
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 
 // ---- K6: GroupNorm statistics + apply(+SiLU); K7: LayerNorm ----------------------------------
-// x = concat(X[...,C1], X2[...,C-C1]) NHWC; ab [N][C][2] = per-sample per-channel affine (a, b): y = x*a + b
-hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, float eps,
-                           const float* gamma, const float* beta,
-                           double* partial /* [N][chunks][G][2] */, float* ab /* [N][C][2] */, hipStream_t s);
+// x = concat(X[...,C1], X2[...,C-C1]) NHWC.  Two kernels: per-(sample, pixel chunk, group) fp64 partial sums (one read of x),
+// then the apply kernel, whose prologue combines them into the per-channel affine y = x * a + b (+ SiLU) — second read, one write.
+hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G,
+                           double* partial /* [N][chunks][G][2] */, hipStream_t s);
 int gn_stats_chunks(int HW);
-hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, int C1, const float* ab, int silu,
-                           f16* Y, hipStream_t s);
+hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, float eps, const float* gamma,
+                           const float* beta, const double* partial, int silu, f16* Y, hipStream_t s);
 hipError_t launch_layernorm(const f16* X, int rows, int C, const float* gamma, const float* beta,
                             float eps, f16* Y, hipStream_t s);
 // per-row (mean, rstd) of X [rows][C] -> stats [rows][2] fp32 (the statistics half of LayerNorm)

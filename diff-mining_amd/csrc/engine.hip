@@ -173,6 +173,11 @@ struct dm_engine {
     // workspace
     Arena arena;
     char* arena_base = nullptr; size_t arena_cap = 0;
+    std::map<std::vector<long long>, size_t> arena_need;   // exact peak per (schedule, shape) key: the dry run is done once
+    long long n_device_allocs = 0;                         // every hipMalloc this engine ever did (dm_engine_stats)
+    long long n_dry_runs = 0;
+    int kv_capacity = 0;                                   // prompts the K/V cache buffers hold
+    int* tile_ctr = nullptr;                               // tile hand-out counters of the persistent igemm (this engine's own)
 
     // profiling
     bool prof = false;
@@ -192,6 +197,7 @@ namespace {
     char _b[512]; snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #call, hipGetErrorString(_r), __FILE__, __LINE__); \
     (e)->err = _b; return 1; } } while (0)
 #define DM_TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+#define DM_MALLOC(e, pp, bytes) do { DM_HIP(e, hipMalloc((void**)(pp), (bytes))); ++(e)->n_device_allocs; } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // host-side scheduler / sinusoid tables (also exported for the CPU test tier)
@@ -498,7 +504,8 @@ struct Fwd {
         p.mode = mode; p.epi = epi; p.ldy = cout_y; p.ldres = res ? res->C : 0; p.temb_ld = temb_ld;
         if (mode == IG_DENSE) { p.M = (int)x.rows(); p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M; }
         else { p.M = x.N * OH * OW; p.H = x.H; p.W = x.W; p.OH = OH; p.OW = OW; }
-        if (ln) { p.ln_stats = ln_stats; p.ln_s = ln->s; p.ln_t = ln->t; }
+        if (ln) { p.ln_stats = ln_stats; p.ln_s = ln->s; p.ln_t = ln->t; p.ln_eps = LN_EPS; }
+        p.tile_ctr = e->tile_ctr;
         // small-M layers: split-K through an fp32 workspace (also accounted for in the dry run)
         const int parts = ln ? 1 : igemm_splitk_parts(p, OH * OW);
         size_t poff = (size_t)-1;
@@ -525,20 +532,23 @@ struct Fwd {
         if (C != nw.c) DM_FAIL(e, "groupnorm: channel mismatch %d vs %d", C, nw.c);
         const int HW = x.H * x.W;
         const int chunks = gn_stats_chunks(HW);
-        size_t poff, soff; void *pp, *sp;
+        size_t poff; void* pp;
         DM_TRY(alloc_raw((size_t)x.N * chunks * GROUPS * 2 * sizeof(double), &poff, &pp));
-        DM_TRY(alloc_raw((size_t)x.N * C * 2 * sizeof(float), &soff, &sp));
         DM_TRY(alloc(y, x.N, x.H, x.W, C));
         if (!dry) {
-            DM_HIP(e, launch_gn_stats(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, GROUPS, eps, nw.g, nw.b, (double*)pp, (float*)sp, s));
-            DM_HIP(e, launch_gn_apply(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, (const float*)sp, silu ? 1 : 0, y->p, s));
+            DM_HIP(e, launch_gn_stats(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, GROUPS, (double*)pp, s));
+            DM_HIP(e, launch_gn_apply(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, GROUPS, eps, nw.g, nw.b, (const double*)pp,
+                                      silu ? 1 : 0, y->p, s));
         }
-        free_raw(poff); free_raw(soff);
+        free_raw(poff);
         return 0;
     }
     // LayerNorm folded into the following Linear: per-row (mean, rstd), then the GEMM on the raw tokens with
     // the correction in its epilogue (saves writing and re-reading the normalised token matrix)
     int ln_dense(const LnFold& f, const Tensor& x, int epi, Tensor* y) {
+        if (option(OPT_LN_INKERNEL)) {      // the GEMM takes the row statistics itself (no statistics kernel, no extra read of x)
+            return igemm(f.w, IG_DENSE, x, nullptr, x.H, x.W, nullptr, 0, nullptr, epi, y, &f, nullptr);
+        }
         size_t soff; void* sp;
         DM_TRY(alloc_raw((size_t)x.rows() * 2 * sizeof(float), &soff, &sp));
         if (!dry) DM_HIP(e, launch_ln_stats(x.p, (int)x.rows(), x.C, LN_EPS, (float*)sp, s));
@@ -934,45 +944,61 @@ int run_clip(dm_engine* e, const int32_t* ids, int n, f16* out16, float* out32, 
     return 0;
 }
 
+// Workspace for one schedule run.  The exact peak comes from a dry run of the schedule against an unbounded virtual
+// arena; it depends only on `key` (which schedule, batch, shape, options), so it is computed once per key and cached:
+// the steady-state path does no host walk of the schedule and — once the largest shape has been seen or reserved
+// (dm_engine_reserve) — no allocation either.
 template <class RunFn>
-int ensure_arena_for(dm_engine* e, hipStream_t s, RunFn run_dry) {
-    e->arena.reset((size_t)1 << 60, true);
-    char* keep = e->arena_base;
-    e->arena_base = nullptr;
-    int rc = run_dry();
-    e->arena_base = keep;
-    if (rc) return rc;
-    const size_t need = e->arena.peak;
+int ensure_arena_for(dm_engine* e, hipStream_t s, const std::vector<long long>& key, RunFn run_dry) {
+    size_t need;
+    auto it = e->arena_need.find(key);
+    if (it != e->arena_need.end()) need = it->second;
+    else {
+        e->arena.reset((size_t)1 << 60, true);
+        char* keep = e->arena_base;
+        e->arena_base = nullptr;
+        int rc = run_dry();
+        e->arena_base = keep;
+        if (rc) return rc;
+        need = e->arena.peak;
+        e->arena_need[key] = need;
+        ++e->n_dry_runs;
+    }
     if (need > e->arena_cap) {
         DM_HIP(e, hipStreamSynchronize(s));
         if (e->arena_base) DM_HIP(e, hipFree(e->arena_base));
         e->arena_base = nullptr; e->arena_cap = 0;
         const size_t cap = need + (need >> 4);
-        DM_HIP(e, hipMalloc((void**)&e->arena_base, cap));
+        DM_MALLOC(e, &e->arena_base, cap);
         e->arena_cap = cap;
     }
     e->arena.reset(e->arena_cap, false);
     return 0;
 }
 
+std::vector<long long> fwd_key(const FwdArgs& A) {
+    return {0, A.B, A.H, A.W, A.n_cond, A.up_ft_index, A.add_noise ? 1 : 0, A.loss ? 1 : 0, A.pred ? 1 : 0, A.feat ? 1 : 0,
+            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL)};
+}
+
 int ensure_arena(dm_engine* e, const FwdArgs& A, hipStream_t s) {
-    // dry run with an unbounded virtual arena to get the exact peak, then (re)allocate if needed
-    e->arena.reset((size_t)1 << 60, true);
-    char* keep = e->arena_base;
-    e->arena_base = nullptr;
-    int rc = run_forward(e, A, s, true);
-    e->arena_base = keep;
-    if (rc) return rc;
-    const size_t need = e->arena.peak;
-    if (need > e->arena_cap) {
-        DM_HIP(e, hipStreamSynchronize(s));
-        if (e->arena_base) DM_HIP(e, hipFree(e->arena_base));
-        e->arena_base = nullptr; e->arena_cap = 0;
-        const size_t cap = need + (need >> 4);
-        DM_HIP(e, hipMalloc((void**)&e->arena_base, cap));
-        e->arena_cap = cap;
+    return ensure_arena_for(e, s, fwd_key(A), [&]() { return run_forward(e, A, s, true); });
+}
+
+// K/V cache capacity: at least 16 prompts (3.8 MB per prompt over the 16 transformer blocks), doubling when it has to grow,
+// so that a stream of calls with varying prompt counts stops allocating after the first few; dm_engine_reserve pre-sizes it.
+int reserve_prompts(dm_engine* e, int n_prompts, hipStream_t s) {
+    if (n_prompts <= e->kv_capacity) return 0;
+    int cap = e->kv_capacity > 0 ? 2 * e->kv_capacity : 16;
+    if (cap < n_prompts) cap = n_prompts;
+    DM_HIP(e, hipStreamSynchronize(s));
+    for (int l = 0; l < e->n_tf; ++l) {
+        if (e->kv_cache[l]) DM_HIP(e, hipFree(e->kv_cache[l]));
+        e->kv_cache[l] = nullptr;
+        DM_MALLOC(e, &e->kv_cache[l], (size_t)cap * CTX_LEN * 2 * e->tfs[l]->c * sizeof(f16));
     }
-    e->arena.reset(e->arena_cap, false);
+    e->kv_capacity = cap;
+    e->n_prompts = 0;                      // the old rows are gone
     return 0;
 }
 
@@ -993,7 +1019,7 @@ namespace {
 struct OptDef { const char* name; const char* env; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
-    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0},
+    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<int> g_opt_init{0};
@@ -1060,6 +1086,7 @@ void dm_engine_destroy(dm_engine* e) {
     if (e->vslab) (void)hipFree(e->vslab);
     if (e->cslab) (void)hipFree(e->cslab);
     if (e->arena_base) (void)hipFree(e->arena_base);
+    if (e->tile_ctr) (void)hipFree(e->tile_ctr);
     if (e->sin_table) (void)hipFree(e->sin_table);
     if (e->sa_tab) (void)hipFree(e->sa_tab);
     if (e->sb_tab) (void)hipFree(e->sb_tab);
@@ -1170,7 +1197,7 @@ int dm_engine_finalize(dm_engine* e) {
 
     // upload
     e->wslab_bytes = P.blob.size();
-    DM_HIP(e, hipMalloc((void**)&e->wslab, e->wslab_bytes));
+    DM_MALLOC(e, &e->wslab, e->wslab_bytes);
     DM_HIP(e, hipMemcpy(e->wslab, P.blob.data(), e->wslab_bytes, hipMemcpyHostToDevice));
     char* base = e->wslab;
     rebase_conv(e->conv_in, base); rebase_conv(e->conv_out, base); rebase_conv(e->time1, base); rebase_conv(e->time2, base);
@@ -1195,15 +1222,15 @@ int dm_engine_finalize(dm_engine* e) {
             const f16 om = (f16)(1.0f - (float)a16);            // fp16 subtraction
             sb[t] = (f16)sqrtf((float)om);
         }
-        DM_HIP(e, hipMalloc((void**)&e->sa_tab, NTRAIN * 2));
-        DM_HIP(e, hipMalloc((void**)&e->sb_tab, NTRAIN * 2));
+        DM_MALLOC(e, &e->sa_tab, NTRAIN * 2);
+        DM_MALLOC(e, &e->sb_tab, NTRAIN * 2);
         DM_HIP(e, hipMemcpy(e->sa_tab, sa.data(), NTRAIN * 2, hipMemcpyHostToDevice));
         DM_HIP(e, hipMemcpy(e->sb_tab, sb.data(), NTRAIN * 2, hipMemcpyHostToDevice));
         // fp32 flow: `alphas_cumprod[t] ** 0.5`, `(1 - alphas_cumprod[t]) ** 0.5` on the fp32 table
         std::vector<float> sa32(NTRAIN), sb32(NTRAIN);
         for (int t = 0; t < NTRAIN; ++t) { sa32[t] = sqrtf(acp[t]); sb32[t] = sqrtf(1.0f - acp[t]); }
-        DM_HIP(e, hipMalloc((void**)&e->sa32_tab, NTRAIN * 4));
-        DM_HIP(e, hipMalloc((void**)&e->sb32_tab, NTRAIN * 4));
+        DM_MALLOC(e, &e->sa32_tab, NTRAIN * 4);
+        DM_MALLOC(e, &e->sb32_tab, NTRAIN * 4);
         DM_HIP(e, hipMemcpy(e->sa32_tab, sa32.data(), NTRAIN * 4, hipMemcpyHostToDevice));
         DM_HIP(e, hipMemcpy(e->sb32_tab, sb32.data(), NTRAIN * 4, hipMemcpyHostToDevice));
         std::vector<f16> tab((size_t)NTRAIN * BOC[0]);
@@ -1212,10 +1239,14 @@ int dm_engine_finalize(dm_engine* e) {
             host_sinusoid(t, BOC[0], row.data());
             for (int k = 0; k < BOC[0]; ++k) tab[(size_t)t * BOC[0] + k] = (f16)row[k];
         }
-        DM_HIP(e, hipMalloc((void**)&e->sin_table, tab.size() * 2));
+        DM_MALLOC(e, &e->sin_table, tab.size() * 2);
         DM_HIP(e, hipMemcpy(e->sin_table, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
     }
     e->kv_cache.assign(e->n_tf, nullptr);
+    // tile hand-out counters of the persistent igemm kernel: this engine's own (8 XCD counters 128 B apart + a completion
+    // counter), so two engines / streams on one device never share them; a launch leaves them at zero
+    DM_MALLOC(e, &e->tile_ctr, IGEMM_TILE_CTR_INTS * sizeof(int));
+    DM_HIP(e, hipMemset(e->tile_ctr, 0, IGEMM_TILE_CTR_INTS * sizeof(int)));
     e->finalized = true;
     return 0;
 }
@@ -1311,7 +1342,7 @@ int dm_engine_finalize_vae(dm_engine* e) {
     if (e->host_vae.size() != 108) DM_FAIL(e, "expected 108 VAE encoder tensors, got %zu", e->host_vae.size());
 
     e->vslab_bytes = P.blob.size();
-    DM_HIP(e, hipMalloc((void**)&e->vslab, e->vslab_bytes));
+    DM_MALLOC(e, &e->vslab, e->vslab_bytes);
     DM_HIP(e, hipMemcpy(e->vslab, P.blob.data(), e->vslab_bytes, hipMemcpyHostToDevice));
     char* base = e->vslab;
     rebase_conv(v.conv_in, base); rebase_conv(v.qkv, base); rebase_conv(v.o, base); rebase_conv(v.conv_out, base);
@@ -1351,7 +1382,7 @@ int dm_vae_encode(dm_engine* e, const void* image_dev, const void* noise_dev, in
         A.latent16 = latent_f16_dev ? (f16*)latent_f16_dev + (size_t)b0 * D * 4 * lpx : nullptr;
         A.latent32 = latent_f32_dev ? (float*)latent_f32_dev + (size_t)b0 * D * 4 * lpx : nullptr;
         A.moments = moments_f32_dev ? (float*)moments_f32_dev + (size_t)b0 * 8 * lpx : nullptr;
-        DM_TRY(ensure_arena_for(e, s, [&]() { return run_vae(e, A, s, true); }));
+        DM_TRY(ensure_arena_for(e, s, {1, A.B, A.H, A.W, A.draws}, [&]() { return run_vae(e, A, s, true); }));
         DM_TRY(run_vae(e, A, s, false));
     }
     return 0;
@@ -1417,7 +1448,7 @@ int dm_engine_finalize_clip(dm_engine* e) {
     if (unused) DM_FAIL(e, "%zu unexpected tensors in the CLIP text state dict (first: %s)", unused, first_unused.c_str());
     if (e->host_clip.size() != 196) DM_FAIL(e, "expected 196 CLIP text tensors, got %zu", e->host_clip.size());
     e->cslab_bytes = P.blob.size();
-    DM_HIP(e, hipMalloc((void**)&e->cslab, e->cslab_bytes));
+    DM_MALLOC(e, &e->cslab, e->cslab_bytes);
     DM_HIP(e, hipMemcpy(e->cslab, P.blob.data(), e->cslab_bytes, hipMemcpyHostToDevice));
     char* base = e->cslab;
     rebase(c.tok, base); rebase(c.pos, base); rebase_norm(c.final_ln, base);
@@ -1445,7 +1476,7 @@ int dm_clip_encode(dm_engine* e, const int32_t* input_ids_dev, int n_prompts, in
         const int32_t* ids = input_ids_dev + (size_t)n0 * CL_T;
         f16* o16 = out_f16_dev ? (f16*)out_f16_dev + (size_t)n0 * CL_T * CL_H : nullptr;
         float* o32 = out_f32_dev ? (float*)out_f32_dev + (size_t)n0 * CL_T * CL_H : nullptr;
-        DM_TRY(ensure_arena_for(e, s, [&]() { return run_clip(e, ids, n, o16, o32, s, true); }));
+        DM_TRY(ensure_arena_for(e, s, {2, n}, [&]() { return run_clip(e, ids, n, o16, o32, s, true); }));
         DM_TRY(run_clip(e, ids, n, o16, o32, s, false));
     }
     return 0;
@@ -1499,14 +1530,7 @@ int dm_engine_set_prompts(dm_engine* e, const void* ctx_dev, int n_prompts, void
     if (!e->finalized) DM_FAIL(e, "set_prompts before finalize");
     DM_HIP(e, hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
-    if (n_prompts > e->n_prompts) {
-        DM_HIP(e, hipStreamSynchronize(s));
-        for (int l = 0; l < e->n_tf; ++l) {
-            if (e->kv_cache[l]) DM_HIP(e, hipFree(e->kv_cache[l]));
-            e->kv_cache[l] = nullptr;
-            DM_HIP(e, hipMalloc((void**)&e->kv_cache[l], (size_t)n_prompts * CTX_LEN * 2 * e->tfs[l]->c * sizeof(f16)));
-        }
-    }
+    DM_TRY(reserve_prompts(e, n_prompts, s));
     e->n_prompts = n_prompts;
     const int M = n_prompts * CTX_LEN;
     for (int l = 0; l < e->n_tf; ++l) {
@@ -1515,6 +1539,7 @@ int dm_engine_set_prompts(dm_engine* e, const void* ctx_dev, int n_prompts, void
         p.X = (const f16*)ctx_dev; p.X2 = nullptr; p.Wp = kv.w; p.bias = nullptr; p.temb = nullptr; p.res = nullptr;
         p.Y = e->kv_cache[l]; p.M = M; p.Cout = kv.cout; p.Cin = CTX_DIM; p.C1 = CTX_DIM;
         p.H = 1; p.W = M; p.OH = 1; p.OW = M; p.mode = IG_DENSE; p.epi = EPI_PLAIN; p.ldy = kv.cout; p.ldres = 0; p.temb_ld = 0;
+        p.tile_ctr = e->tile_ctr;
         DM_HIP(e, launch_igemm(p, s));
     }
     return 0;
@@ -1699,6 +1724,37 @@ int dm_prof_read(dm_engine* e, double* igemm_ms, double* igemm_flops, int64_t* i
     return 0;
 }
 
+int dm_engine_stats(dm_engine* e, int64_t* device_allocs, int64_t* schedule_dry_runs) {
+    if (!e) return 1;
+    if (device_allocs) *device_allocs = e->n_device_allocs;
+    if (schedule_dry_runs) *schedule_dry_runs = e->n_dry_runs;
+    return 0;
+}
+
+int dm_engine_reserve(dm_engine* e, int max_batch, int max_h, int max_w, int n_cond, int max_prompts, void* stream) {
+    if (!e) return 1;
+    if (!e->finalized) DM_FAIL(e, "dm_engine_reserve before finalize");
+    if (max_batch < 0 || max_h < 0 || max_w < 0 || max_prompts < 0) DM_FAIL(e, "dm_engine_reserve: negative argument");
+    DM_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (max_prompts > 0) {
+        const int keep = e->n_prompts;
+        if (max_prompts > e->kv_capacity && keep > 0) DM_FAIL(e, "dm_engine_reserve: grow the prompt cache before dm_engine_set_prompts (its rows would be lost)");
+        DM_TRY(reserve_prompts(e, max_prompts, s));
+        e->n_prompts = keep;
+    }
+    if (max_batch > 0 && max_h > 0 && max_w > 0) {
+        // the largest U-Net batch a call of that size is cut into (DM_CHUNK), full forward with the loss epilogue
+        int chunk = max_chunk(max_h, max_w);
+        FwdArgs A{};
+        A.H = max_h; A.W = max_w; A.add_noise = true; A.up_ft_index = -1; A.loss = reinterpret_cast<float*>(1);
+        if (n_cond > 1) { int uc = chunk / n_cond; if (uc < 1) uc = 1; const int nu = max_batch / n_cond < uc ? max_batch / n_cond : uc; A.n_cond = n_cond; A.B = (nu < 1 ? 1 : nu) * n_cond; }
+        else A.B = max_batch < chunk ? max_batch : chunk;
+        DM_TRY(ensure_arena(e, A, s));
+    }
+    return 0;
+}
+
 int dm_engine_memory(dm_engine* e, size_t* weights_bytes, size_t* arena_bytes) {
     if (!e) return 1;
     if (weights_bytes) *weights_bytes = e->wslab_bytes + e->vslab_bytes + e->cslab_bytes;     // U-Net + optional VAE / CLIP slabs
@@ -1750,14 +1806,13 @@ int dm_op_attention(void* stream, const void* Q, const void* K, const void* V, v
 int dm_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, int C, int C1, int G, float eps,
                     const float* gamma, const float* beta, int silu, void* Y) {
     hipStream_t s = (hipStream_t)stream;
-    double* partial = nullptr; float* ab = nullptr;
+    double* partial = nullptr;
     const int chunks = gn_stats_chunks(HW);
     if (hipMalloc((void**)&partial, (size_t)N * chunks * G * 2 * sizeof(double)) != hipSuccess) return 1;
-    if (hipMalloc((void**)&ab, (size_t)N * C * 2 * sizeof(float)) != hipSuccess) { (void)hipFree(partial); return 1; }
-    hipError_t r = launch_gn_stats((const f16*)X, (const f16*)X2, N, HW, C, C1, G, eps, gamma, beta, partial, ab, s);
-    if (r == hipSuccess) r = launch_gn_apply((const f16*)X, (const f16*)X2, N, HW, C, C1, ab, silu, (f16*)Y, s);
+    hipError_t r = launch_gn_stats((const f16*)X, (const f16*)X2, N, HW, C, C1, G, partial, s);
+    if (r == hipSuccess) r = launch_gn_apply((const f16*)X, (const f16*)X2, N, HW, C, C1, G, eps, gamma, beta, partial, silu, (f16*)Y, s);
     (void)hipStreamSynchronize(s);
-    (void)hipFree(partial); (void)hipFree(ab);
+    (void)hipFree(partial);
     return r == hipSuccess ? 0 : 1;
 }
 

@@ -76,7 +76,7 @@ int igemm_splitk_parts(const IGemmParams& p, int spatial) {
 // the split-K launches the persistent 256 x 320 tile takes: 3x3 convolution, three tap-aligned parts, plain epilogue, and
 // fewer (weighted) rounds than the 128-row tile
 static bool splitk_on_pers(const IGemmParams& p) {
-    if (option(OPT_IGEMM_SPLITK) == 2 || p.ksplit != 3 || p.mode == IG_DENSE || p.epi != EPI_PLAIN || p.ln_stats) return false;
+    if (option(OPT_IGEMM_SPLITK) == 2 || p.ksplit != 3 || p.mode == IG_DENSE || p.epi != EPI_PLAIN || p.ln_s) return false;
     if (p.Cout % 320 != 0 || p.Cin % BK != 0 || p.C1 % BK != 0) return false;
     IGemmParams q = p; q.temb = nullptr; q.res = nullptr;           // those are applied by the reduction kernel
     if (!igemm_pers_ok(q)) return false;
@@ -167,7 +167,7 @@ int igemm_head_rows(const IGemmParams& p) {
 }
 
 static hipError_t launch_small(const IGemmParams& p, hipStream_t s) {
-    if (p.ln_stats) return launch_igemm_tile_ln(p, s);
+    if (p.ln_s) return launch_igemm_tile_ln(p, s);
     return (p.Cout % 320 == 0) ? launch_t<4, 5>(p, s) : launch_t<2, 5>(p, s);
 }
 
@@ -177,17 +177,17 @@ hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
         const hipError_t rc = launch_igemm_pers_partial(p, s);
         return rc != hipSuccess ? rc : launch_splitk_reduce(p, s);
     }
-    if (p.ln_stats) {
-        if (!p.ln_s || !p.ln_t || p.Cout % 160 != 0) return hipErrorInvalidValue;
+    if (p.ln_s) {
+        if (!p.ln_t || p.Cout % 160 != 0 || p.mode != IG_DENSE || p.C1 != p.Cin) return hipErrorInvalidValue;
     } else {
         if (p.Cout % 160 != 0 || p.mode == IG_CONV3_S2P0) return launch_igemm64(p, s);        // VAE channel counts
         if (p.Cin % BK != 0 || p.C1 % BK != 0 || p.M <= 0) return hipErrorInvalidValue;
     }
-    if (option(OPT_IGEMM_EXP) == 1 && p.epi == EPI_GEGLU) return p.ln_stats ? launch_igemm_tile_ln_half(p, s) : launch_t<2, 5>(p, s);
+    if (option(OPT_IGEMM_EXP) == 1 && p.epi == EPI_GEGLU) return p.ln_s ? launch_igemm_tile_ln_half(p, s) : launch_t<2, 5>(p, s);
     const int head = head_rows(p);
     if (head <= 0) return launch_small(p, s);
     const IGemmParams h = head < p.M ? row_range(p, 0, head) : p;
-    const hipError_t rc = p.ln_stats ? launch_igemm_pers_ln(h, s) : launch_igemm_pers(h, s);
+    const hipError_t rc = p.ln_s ? launch_igemm_pers_ln(h, s) : launch_igemm_pers(h, s);
     if (rc != hipSuccess || head >= p.M) return rc;
     return launch_small(row_range(p, head, p.M), s);
 }

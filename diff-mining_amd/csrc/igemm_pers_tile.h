@@ -62,12 +62,15 @@ __device__ __forceinline__ float gelu_erf(float x) {
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page_pers[1024];
 __device__ __attribute__((aligned(256))) unsigned char g_store_sink[8 * 64 * 16];      // one 16-byte slot per (wave, lane)
 // Dynamic tile hand-out: one counter per XCD (its blocks share an L2, so an XCD keeps its contiguous tile range) +
-// one completion counter; the last block to finish resets them.  A launch takes the next of CSETS counter sets (host
-// side round robin per process), so launches that overlap on different streams do not share counters; __device__
-// storage is per device.  Static striding lost 3-5 % to the slowest CU.
+// one completion counter; the last block to finish resets them, so a launch finds and leaves them at zero.  Static
+// striding lost 3-5 % to the slowest CU.  The counters belong to the caller (IGemmParams::tile_ctr: an engine passes its
+// own buffer, and an engine's launches are ordered on one stream, so two kernels never share live counters).  Without
+// one (operator-level entry points) a launch takes the next of CSETS process-wide sets per device, round robin at enqueue
+// time: that only separates launches that overlap if the device's launches are serialised on one stream — which is what
+// those entry points document.
 constexpr int CSETS = 64;
-__device__ int g_tile_ctr[CSETS][8 * 32];     // [set][xcd * 32] (128 bytes apart)
-__device__ int g_tile_done[CSETS];
+constexpr int CTR_DONE = 8 * 32;                       // index of the completion counter
+__device__ int g_tile_ctr[CSETS][IGEMM_TILE_CTR_INTS];  // [set][xcd * 32] (128 bytes apart), [set][CTR_DONE]
 #ifdef DM_IGEMM_TIMING
 // phase timers of one block (tools/igemm_timing.py): [0] k-step bodies, [1] waits at the top of k steps, [2] epilogue,
 // [3] tile switch (zeroing, first wait), [4] tiles, in shader cycles of wave 0
@@ -154,12 +157,13 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
         tdyn = tstart + ((nblk - xcd + 7) >> 3);       // first dynamically handed-out tile of this XCD
         tile = tstart + loc;
     }
+    int* const ctr = p.tile_ctr ? p.tile_ctr : &g_tile_ctr[cset][0];
     auto finish = [&]() __attribute__((always_inline)) {
         if (threadIdx.x == 0) {
-            if (atomicAdd(&g_tile_done[cset], 1) == (int)gridDim.x - 1) {
+            if (atomicAdd(&ctr[CTR_DONE], 1) == (int)gridDim.x - 1) {
 #pragma unroll
-                for (int x = 0; x < 8; ++x) g_tile_ctr[cset][x * 32] = 0;
-                g_tile_done[cset] = 0;
+                for (int x = 0; x < 8; ++x) ctr[x * 32] = 0;
+                ctr[CTR_DONE] = 0;
                 __threadfence();
             }
         }
@@ -284,13 +288,21 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
             } else {
                 int row = lp0 + half * 128 + lane * 2;               // two (mean, rstd) pairs per lane
                 row = row < p.M - 1 ? row : p.M - 2;
-                s = reinterpret_cast<const char*>(p.ln_stats + 2 * (size_t)row);
+                s = p.ln_stats ? reinterpret_cast<const char*>(p.ln_stats + 2 * (size_t)row) : zp;     // in-kernel statistics: the slot is written after the k loop
             }
             __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(ax + AUX_LNS + (wid - 2) * 1024), 16, 0, 0);
         }
     };
 
     floatx4 acc[CH][5][4];
+    // folded LayerNorm without a statistics kernel (p.ln_stats == nullptr): K = C, so a tile's k steps carry every channel of
+    // its 256 rows through LDS once.  Lane pair (2r, 2r + 1) of the block owns row r: per k step each lane adds its 32
+    // channels (logical chunks 4 half .. 4 half + 3 of the 64-channel slab, ascending) to (sum, sum of squares) in fp32 —
+    // VALU work in the shadow of the MFMAs — and after the k loop the pair is combined into (mean, rstd) in the tile's
+    // vector slot.  The order depends on the row only, never on the tile geometry or the batch (igemm_tile.h adds the same
+    // numbers in the same order).
+    const bool ln_ink = LN && p.ln_stats == nullptr;
+    float ln_s1 = 0.f, ln_s2 = 0.f;
 
     // one k step on stage `cur`, with the LDS-DMA of the following k tile of the stream into the other stage interleaved
     // (its sources were prepared after the previous step's MFMAs, when no fragment registers are live: the address
@@ -330,6 +342,15 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
                 // piece per group / per other group: best by 0-7 % per shape; the later the last piece, the longer the wait)
                 if (piece < NL) { load_piece(cur ^ 1, piece, lchunk); ++piece; }
                 if (piece < NL) { load_piece(cur ^ 1, piece, lchunk); ++piece; }
+                if (LN && q >= 1 && i < 2 && q < 3) {       // four 16-byte chunks of this lane's row half, one per MFMA group, after the DMA issue
+                    if (ln_ink) {
+                        const int c4 = (q - 1) * 2 + i;
+                        const int row = (wid * 64 + ln) >> 1, hf = ln & 1;
+                        const half8 xv = *reinterpret_cast<const half8*>(xt + row * 128 + (((4 * hf + c4) ^ (row & 7)) << 4));
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { const float f = (float)xv[k]; ln_s1 += f; ln_s2 = __builtin_fmaf(f, f, ln_s2); }
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -514,7 +535,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
         // next tile of this block: asked for now (one returning atomic by thread 0), published through LDS (a spare word
         // of the current vector slot) after k step 1's top wait, read by everyone after k step nk - 2  (nk >= 4)
         int ticket = 0;
-        if (threadIdx.x == 0) ticket = atomicAdd(&g_tile_ctr[cset][xcd * 32], 1);
+        if (threadIdx.x == 0) ticket = atomicAdd(&ctr[xcd * 32], 1);
         int next = 0;
         bool has_next = false;
         for (int kt = 0; kt < nk; ++kt) {
@@ -534,6 +555,19 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
             if (kt < nk - 1) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             PTICK(1);
             if (kt == 0 && threadIdx.x == 0) *reinterpret_cast<volatile int*>(aux0 + slot * AUX_BYTES + 1020) = ticket;
+        }
+        if (LN) {
+            if (ln_ink) {
+                const int ln2 = hw_lane();
+                const float t1 = ln_s1 + __shfl_xor(ln_s1, 1), t2 = ln_s2 + __shfl_xor(ln_s2, 1);
+                const float mean = t1 / (float)p.Cin;
+                float var = t2 / (float)p.Cin - mean * mean;
+                var = var > 0.f ? var : 0.f;
+                if ((ln2 & 1) == 0)
+                    *reinterpret_cast<float2*>(aux0 + slot * AUX_BYTES + AUX_STATS + ((wid * 64 + ln2) >> 1) * 8) = float2{mean, rsqrtf(var + p.ln_eps)};
+                ln_s1 = 0.f; ln_s2 = 0.f;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
         }
         if constexpr (PART) epilogue_partial(p0, c0out, tile - rtile * KSP);
         else epilogue(p0, c0out, slot);

@@ -317,11 +317,15 @@ void igemm_kernel(IGemmParams p) {
             *reinterpret_cast<floatx4*>(smem + 2 * STAGE + 1024 + TC * 4 + tid * 16) = *reinterpret_cast<const floatx4*>(p.ln_t + c0out + tid * 4);
         }
     }
-    if (LN && tid < TP) {      // per-row (mean, rstd) of the tile's rows behind them
+    if (LN && p.ln_stats && tid < TP) {      // per-row (mean, rstd) of the tile's rows behind them
         int m = p0 + tid;
         m = m < p.M ? m : p.M - 1;
         *reinterpret_cast<float2*>(smem + 2 * STAGE + 1024 + 8 * TC + tid * 8) = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (size_t)m);
     }
+    // without a statistics kernel (p.ln_stats == nullptr): thread pair (2r, 2r + 1) accumulates row r of the tile from the k
+    // loop's LDS tiles — the same numbers in the same order as igemm_pers_tile.h (bit-identical statistics)
+    const bool ln_ink = LN && p.ln_stats == nullptr && tid < 2 * TP;
+    float ln_s1 = 0.f, ln_s2 = 0.f;
     prepare();
 #pragma unroll
     for (int i = 0; i < NL; ++i) load_piece(0, i);
@@ -350,6 +354,14 @@ void igemm_kernel(IGemmParams p) {
                 acc[i][j] = (g < NI) ? __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[i], b0[j], acc[i][j], 0, 0, 0)
                                     : __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], b1[j], acc[i][j], 0, 0, 0);
             if (more && g < NL) load_piece(cur ^ 1, g);
+            if (LN && g >= 2 && g < 6) {
+                if (ln_ink) {
+                    const int row = tid >> 1, hf = tid & 1;
+                    const half8 xv = *reinterpret_cast<const half8*>(xt + row * 128 + (((4 * hf + (g - 2)) ^ (row & 7)) << 4));
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const float f = (float)xv[k]; ln_s1 += f; ln_s2 = __builtin_fmaf(f, f, ln_s2); }
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -374,6 +386,15 @@ void igemm_kernel(IGemmParams p) {
                 *reinterpret_cast<floatx4*>(base + (size_t)m * p.Cout + c0out + wc * (16 * NI) + 16 * i + 4 * lg) = acc[i][j];
         }
         return;
+    }
+    if (LN && p.ln_stats == nullptr) {
+        const float t1 = ln_s1 + __shfl_xor(ln_s1, 1), t2 = ln_s2 + __shfl_xor(ln_s2, 1);
+        const float mean = t1 / (float)p.Cin;
+        float var = t2 / (float)p.Cin - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        if (ln_ink && (tid & 1) == 0)
+            *reinterpret_cast<float2*>(smem + 2 * STAGE + 1024 + 8 * TC + (tid >> 1) * 8) = float2{mean, rsqrtf(var + p.ln_eps)};
+        __syncthreads();
     }
     epilogue_lds<EPI, 128 * WC, TP, TC, NI, LN>(p, acc, smem, smem + 2 * STAGE, p0, c0out, wc, wp, l15, lg, OHW);
 }

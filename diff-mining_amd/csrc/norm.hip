@@ -75,54 +75,44 @@ __global__ void gn_stats_partial(const f16* __restrict__ X, const f16* __restric
     }
 }
 
-// one wavefront per (n, g): the per-chunk partial sums are combined in fp64 in a fixed order (lane-strided
-// sums, then an xor-shuffle tree: deterministic), then the per-channel affine of that group is emitted:
-//   y = x * a + b,  a = rstd * gamma[c],  b = beta[c] - mean * a      (ab[n][c] = {a, b})
-__global__ void gn_stats_final(const double* __restrict__ partial, int total, int chunks, int G, int C, double count,
-                               float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
-                               float* __restrict__ ab) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // n*G + g
-    if (i >= total) return;
-    const int n = i / G, g = i - n * G;
-    double ds = 0.0, dq = 0.0;
-    for (int c = lane; c < chunks; c += 64) {
-        const double* in = partial + (((size_t)n * chunks + c) * G + g) * 2;
-        ds += in[0]; dq += in[1];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
-    const double mean = ds / count;
-    double var = dq / count - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    const double rstd = 1.0 / sqrt(var + (double)eps);
-    const int cpg = C / G;
-    for (int k = lane; k < cpg; k += 64) {
-        const int c = g * cpg + k;
-        const double a = rstd * (double)gamma[c];
-        ab[((size_t)n * C + c) * 2 + 0] = (float)a;
-        ab[((size_t)n * C + c) * 2 + 1] = (float)((double)beta[c] - mean * a);
-    }
-}
-
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // grid (pixel chunks, N); thread = fixed 8-channel column (its affine lives in registers) x row group.
+// Prologue (r03: the former gn_stats_final launch, 61 per forward): the first G threads combine the per-chunk partial
+// sums of their group in fp64 in a fixed order (chunk ascending: deterministic, batch independent) into (mean, rstd) in
+// LDS; every thread then forms the per-channel affine of its 8 channels,
+//   y = x * a + b,  a = rstd * gamma[c],  b = beta[c] - mean * a      (fp64, rounded to fp32 once).
 __global__ void gn_apply_kernel(const f16* __restrict__ X, const f16* __restrict__ X2, int HW, int C, int C1, int R,
-                                int pix_per_block, const float* __restrict__ ab, int silu, f16* __restrict__ Y) {
+                                int pix_per_block, const double* __restrict__ partial, int chunks, int G, double count, float eps,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, int silu, f16* __restrict__ Y) {
+    __shared__ double sh_stat[2 * 64];          // (mean, rstd) per group, G <= 64
     const int cols = C >> 3;
     const int n = blockIdx.y;
     const int t = threadIdx.x;
+    if (t < G) {
+        double ds = 0.0, dq = 0.0;
+        const double* in = partial + ((size_t)n * chunks * G + t) * 2;
+        for (int c = 0; c < chunks; ++c) { ds += in[(size_t)c * G * 2]; dq += in[(size_t)c * G * 2 + 1]; }
+        const double mean = ds / count;
+        double var = dq / count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        sh_stat[2 * t] = mean;
+        sh_stat[2 * t + 1] = 1.0 / sqrt(var + (double)eps);
+    }
+    __syncthreads();
     const int col = t % cols;
     const int rg = t / cols;
     if (rg >= R) return;
     const int c = col * 8;
     const int C2 = C - C1;
+    const int cpg = C / G;
     float a[8], b[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        a[k] = ab[((size_t)n * C + c + k) * 2 + 0];
-        b[k] = ab[((size_t)n * C + c + k) * 2 + 1];
+        const int g = (c + k) / cpg;
+        const double ad = sh_stat[2 * g + 1] * (double)gamma[c + k];
+        a[k] = (float)ad;
+        b[k] = (float)((double)beta[c + k] - sh_stat[2 * g] * ad);
     }
     const int px0 = blockIdx.x * pix_per_block;
     const int px1 = min(HW, px0 + pix_per_block);
@@ -295,28 +285,26 @@ static void gn_geometry(int C, int* R, int* threads) {
     *R = r; *threads = ((cols * r + 63) / 64) * 64;
 }
 
-hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, float eps,
-                           const float* gamma, const float* beta, double* partial, float* ab, hipStream_t s) {
-    if (C % 8 || C % G || C1 % 8) return hipErrorInvalidValue;
+hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, double* partial, hipStream_t s) {
+    if (C % 8 || C % G || C1 % 8 || G > 64) return hipErrorInvalidValue;
     int R, threads; gn_geometry(C, &R, &threads);
     if (threads > 1024) return hipErrorInvalidValue;
     const int chunks = gn_stats_chunks(HW);
     const size_t lds = (size_t)R * C * 2 * sizeof(float);
     hipLaunchKernelGGL(gn_stats_partial, dim3(chunks, N), dim3(threads), lds, s, X, X2 ? X2 : X, HW, C, C1, G, R, gn_pix(HW), partial);
-    const int tot = N * G;
-    hipLaunchKernelGGL(gn_stats_final, dim3((tot + 3) / 4), dim3(256), 0, s, partial, tot, chunks, G, C,
-                       (double)HW * (double)(C / G), eps, gamma, beta, ab);
     return hipGetLastError();
 }
 
-hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, int C1, const float* ab, int silu,
-                           f16* Y, hipStream_t s) {
+hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, float eps, const float* gamma,
+                           const float* beta, const double* partial, int silu, f16* Y, hipStream_t s) {
+    if (C % 8 || C % G || C1 % 8 || G > 64) return hipErrorInvalidValue;
     int R, threads; gn_geometry(C, &R, &threads);
-    // enough blocks to fill the chip, few enough that the per-thread affine load amortises
+    if (threads < G) threads = 64;
+    // enough blocks to fill the chip, few enough that the per-block statistics prologue amortises
     int ppb = 256;
     while (ppb > 8 && (long long)N * ((HW + ppb - 1) / ppb) < 2048) ppb >>= 1;
     hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + ppb - 1) / ppb, N), dim3(threads), 0, s, X, X2 ? X2 : X, HW, C, C1, R,
-                       ppb, ab, silu, Y);
+                       ppb, partial, gn_stats_chunks(HW), G, (double)HW * (double)(C / G), eps, gamma, beta, silu, Y);
     return hipGetLastError();
 }
 

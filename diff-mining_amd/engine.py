@@ -25,6 +25,7 @@ SYMBOLS = [
     "dm_engine_load_vae_weight", "dm_engine_finalize_vae", "dm_vae_encode", "dm_op_attention512", "dm_patch_embed",
     "dm_engine_load_clip_weight", "dm_engine_finalize_clip", "dm_clip_encode", "dm_op_igemm_splitk",
     "dm_op_ln_stats", "dm_op_igemm_ln", "dm_reduce_typicality_batched", "dm_op_igemm_tile", "dm_op_igemm_head_rows", "dm_set_option",
+    "dm_engine_reserve", "dm_engine_stats",
 ]
 
 
@@ -87,6 +88,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_op_igemm_tile.argtypes = [i32, i32, i32, i32]
     lib.dm_set_option.argtypes = [C.c_char_p, i32]
     lib.dm_op_attention512.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float]
+    lib.dm_engine_reserve.argtypes = [vp, i32, i32, i32, i32, i32, vp]
+    lib.dm_engine_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     if path is None:
         _lib = lib
     return lib
@@ -471,6 +474,18 @@ class UNetEngine:
                                           C.byref(f)), "prof_read")
         return {"igemm_ms": a.value, "igemm_flops": b.value, "igemm_launches": c2.value,
                 "attn_ms": d.value, "attn_flops": e.value, "attn_launches": f.value}
+
+    def reserve(self, max_batch: int = 0, h: int = 0, w: int = 0, n_cond: int = 1, max_prompts: int = 0):
+        """Pre-size the workspace arena for U-Net batches of up to `max_batch` samples of h x w latents (n_cond > 1: the
+        `score_conds` schedule) and the K/V cache for `max_prompts` prompts: no call within those bounds allocates
+        afterwards (dm_engine_reserve)."""
+        self._check(self.lib.dm_engine_reserve(self._h, int(max_batch), int(h), int(w), int(n_cond), int(max_prompts),
+                                               self._stream()), "dm_engine_reserve")
+
+    def stats(self) -> dict:
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self.lib.dm_engine_stats(self._h, C.byref(a), C.byref(b)), "dm_engine_stats")
+        return {"device_allocs": a.value, "schedule_dry_runs": b.value}
 
     def memory(self) -> dict:
         a, b = C.c_size_t(), C.c_size_t()

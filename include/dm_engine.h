@@ -199,6 +199,18 @@ int dm_patch_embed(dm_engine* e, const void* feat_f32_dev, int C, int h, int w, 
  * the workspace arena (the per-prompt K/V cache, a few MB, is not included). */
 int dm_engine_memory(dm_engine* e, size_t* weights_bytes, size_t* arena_bytes);
 
+/* Steady-state contract ("no allocation on the steady-state path").  The engine allocates device memory in
+ * three places only: weights at finalize, the per-prompt K/V cache when more prompts are registered than it holds
+ * (capacity >= 16, doubling), and the workspace arena when a call needs more than it holds (exact peak from a dry run of
+ * the schedule, done once per (batch, shape) and cached).  dm_engine_reserve pre-sizes the latter two for the largest
+ * call the caller will make — a U-Net batch of up to `max_batch` samples (cut into DM_CHUNK-sized runs like the calls
+ * themselves) of h x w latents scored under n_cond prompts per draw (n_cond <= 1: dm_score / dm_unet_forward / dm_dift),
+ * and `max_prompts` registered prompts (call it before dm_engine_set_prompts: growing the cache drops its rows) — after
+ * which no call within those bounds allocates.  dm_engine_stats reports how many device allocations and schedule dry runs
+ * the engine has done so far, so a caller (tests/test_gpu_e2e.py::test_no_allocation_in_steady_state) can assert it. */
+int dm_engine_reserve(dm_engine* e, int max_batch, int max_h, int max_w, int n_cond, int max_prompts, void* stream);
+int dm_engine_stats(dm_engine* e, int64_t* device_allocs, int64_t* schedule_dry_runs);
+
 /* ---- operator-level entry points ------------------------------------------------------------------
  * The individual gfx950 kernels behind the U-Net, exposed so that every op can be parity-tested
  * against the matching torch.nn.functional op.  All buffers are device
@@ -216,8 +228,16 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
                 const void* res, void* Y, int N, int H, int W, int C1, int C2, int Cout, int OH, int OW,
                 int mode, int epi, int temb_ld);
 /* Runtime switches for A/B measurements (process-wide; each defaults to the measured best and is initialised from the
- * environment variable DM_<NAME>): "igemm_big" (-1 per shape / 0 / 1), "igemm_splitk", "ln_fold", "attn_pipe", "igemm_tail", "attn_cross", "ln_stats_g" (0 / 1).  None of them changes a result bit, except ln_fold (LayerNorm folded into the next GEMM).
- * Returns nonzero for an unknown name. */
+ * environment variable DM_<NAME>).  Returns nonzero for an unknown name.
+ *   bit-neutral (the same arithmetic in the same order, asserted by tests/test_gpu_ops.py): "igemm_big" (-1 per shape /
+ *     0 / 1: which tile geometry), "igemm_tail" (head / tail row split), "igemm_splitk" 0 vs 1 only for layers that
+ *     do not split (a split layer sums its k parts in fp32 in a different order than the unsplit k loop);
+ *   numerically equivalent but NOT bit-identical: "igemm_splitk" = 2 (four k parts instead of three tap-aligned ones),
+ *     "ln_fold" (LayerNorm folded into the next GEMM: the rounding moves from the LN output to the folded weights),
+ *     "attn_pipe" / "attn_cross" (pipelined / one-pass-softmax kernels vs the generic online-softmax kernel: different
+ *     rescaling points), "ln_stats_g" (different lane order of the row reductions), "gn_fused" (GroupNorm partial sums
+ *     taken in the producer's tile order);
+ *   "igemm_exp": experimental kernel paths of the current round (0 = shipped). */
 int dm_set_option(const char* name, int value);
 
 /* which tile geometry dm_op_igemm runs a shape on: 0 = 128-row tile (128x320 / 128x160), 1 = persistent 256x320 tile */

@@ -154,9 +154,16 @@ def _attention(p: _SD, name: str, x, ctx, heads, ac):
     q = q.view(B, T, heads, d).transpose(1, 2)
     k = k.view(B, kv.shape[1], heads, d).transpose(1, 2)
     v = v.view(B, kv.shape[1], heads, d).transpose(1, 2)
-    s = torch.matmul(q, k.transpose(-1, -2)) * (d ** -0.5)
-    pr = torch.softmax(s, dim=-1)            # fp32 softmax on fp32 scores (flash kernels)
-    o = _r(torch.matmul(_r(pr, ac), v), ac)  # P is fed to the PV matmul in fp16
+    kT = k.transpose(-1, -2)
+
+    def rows(qb):
+        s = torch.matmul(qb, kT) * (d ** -0.5)
+        pr = torch.softmax(s, dim=-1)            # fp32 softmax on fp32 scores (flash kernels)
+        return _r(torch.matmul(_r(pr, ac), v), ac)  # P is fed to the PV matmul in fp16
+    # the softmax is per query row, so blocks of query rows are independent: at 128 x 128 latents (16 384 tokens, the
+    # X-ray case) the full score tensor would be 8.6 GB per sample — keep it below 2^28 elements at a time
+    qc = max(1, (1 << 28) // max(1, B * heads * kv.shape[1]))
+    o = rows(q) if T <= qc else torch.cat([rows(q[:, :, i:i + qc]) for i in range(0, T, qc)], dim=2)
     o = o.transpose(1, 2).reshape(B, T, C)
     return _linear(p, name + ".to_out.0", o, ac)
 

@@ -69,7 +69,9 @@ def main():
     sched = PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000,
                           skip_prk_steps=True)
     out = {}
-    for (h, w, n_draws) in ((8, 8, 2), (16, 16, 1)):
+    # 8x8 / 16x16: the keys the tests read; 12x10 and 32x42 (cars: 256 x 341 px -> latent 32 x 42 -> 16x21 -> 8x11 -> 4x6): odd
+    # sizes, where the up path must honour `upsample_size` (dift.py:54-56,146-147); 32x48: the widest cars latent
+    for (h, w, n_draws) in ((8, 8, 2), (16, 16, 1), (12, 10, 1), (32, 42, 1), (32, 48, 1)):
         x, eps, t, c = (torch.from_numpy(a) for a in synth.synth_inputs(1, n_draws, h, w, latent_dtype=np.float32))
         nb, tb, cc = _tile(eps, t, c)
         with torch.no_grad():
@@ -109,8 +111,16 @@ def main():
         noisy = sched.add_noise(x.expand(2, -1, -1, -1), eps, tt)
         unet(noisy, tt, c[:1].float().expand(2, -1, -1))
     hook.remove()
-    np.savez_compressed(os.path.join(OUT, "dift_diffusers.npz"), diffusers_version=ver, noisy=noisy.numpy(), t=np.int64(161),
-                        prompt=c[:1].numpy(), feat_fp32=grabbed["ft"].numpy().astype(np.float16))
+    dift = dict(noisy=noisy.numpy(), t=np.int64(161), prompt=c[:1].numpy(), feat_fp32=grabbed["ft"].numpy().astype(np.float16))
+    # the same tap on an odd latent (12 x 10 -> 6 x 5 -> 3 x 3 -> 2 x 2; up_blocks[1] ends at 6 x 5 through upsample_size)
+    xo, eo, _, _ = (torch.from_numpy(a) for a in synth.synth_inputs(1, 2, 12, 10, latent_dtype=np.float32))
+    hook = unet.up_blocks[1].register_forward_hook(lambda m, i, o: grabbed.__setitem__("ft_odd", o))
+    with torch.no_grad():
+        noisy_o = sched.add_noise(xo.expand(2, -1, -1, -1), eo, tt)
+        unet(noisy_o, tt, c[:1].float().expand(2, -1, -1))
+    hook.remove()
+    dift.update(noisy_12x10=noisy_o.numpy(), feat_fp32_12x10=grabbed["ft_odd"].numpy().astype(np.float16))
+    np.savez_compressed(os.path.join(OUT, "dift_diffusers.npz"), diffusers_version=ver, **dift)
 
     # ---- VAE encoder moments (compute.py:91-93) ----------------------------------------------------------------
     vae = AutoencoderKL(**SD15_VAE_CONFIG).eval()

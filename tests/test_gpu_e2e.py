@@ -246,6 +246,29 @@ def test_against_real_diffusers_fixture(engine):
     rl = U.rel_l2(loss, torch.from_numpy(g["loss_autocast_cuda"] if "loss_autocast_cuda" in g else g["loss_fp32_cpu"]))
     print(f"vs diffusers {str(g['diffusers_version'])}: loss rel-L2 {rl:.2e}")
     assert rl < TOL_LOSS
+    for tag in ("16x16", "12x10", "32x42", "32x48"):              # odd latents (`upsample_size`) and the widest cars latent
+        if f"loss_fp32_cpu_{tag}" not in g:
+            continue
+        x, eps, t, c = (torch.from_numpy(g[f"{k}_{tag}"]) for k in ("x", "eps", "t", "c"))
+        nb, tb, cc, slots = _tile(eps, t, c)
+        engine.set_prompts(c)
+        loss = engine.score(x, nb, tb, slots, latent_dtype=torch.float32).cpu()
+        key = f"loss_autocast_cuda_{tag}" if f"loss_autocast_cuda_{tag}" in g else f"loss_fp32_cpu_{tag}"
+        rl = U.rel_l2(loss, torch.from_numpy(g[key]))
+        print(f"vs diffusers [{tag}]: loss rel-L2 {rl:.2e}")
+        assert rl < TOL_LOSS, tag
+    dp = os.path.join(GOLDEN, "dift_diffusers.npz")
+    if os.path.exists(dp):
+        d = np.load(dp)
+        for sfx in ("", "_12x10"):
+            if f"noisy{sfx}" not in d:
+                continue
+            noisy = torch.from_numpy(d[f"noisy{sfx}"])
+            engine.set_prompts(torch.from_numpy(d["prompt"]))
+            feat, _ = engine.dift(noisy.half(), torch.tensor(int(d["t"])), torch.zeros(noisy.shape[0], dtype=torch.int32), 1)
+            rf = U.rel_l2(feat.float().cpu(), torch.from_numpy(d[f"feat_fp32{sfx}"]).float())
+            print(f"vs diffusers DIFT tap{sfx}: rel-L2 {rf:.2e}")
+            assert rf < TOL_DIFT
 
 
 def test_golden_fixture(engine):
@@ -557,3 +580,109 @@ def test_two_engines_in_one_process(sd15_weights_f16):
             outs.append(e.score(x, nb, tb, slots).cpu())
         e.close()
     assert torch.equal(outs[0], outs[1])
+
+
+# ---- r03: the parity holes VERDICT r02 names (next #1a, #1d) -----------------------------------------------------------
+def test_xray_config4_vs_oracle(engine, sd15_weights_torch):
+    """BASELINE configs[4] (X-ray: 1024 px -> latent 128 x 128, 16 384-token self-attention) against the oracle: 2 draws x 2
+    prompts through dm_score in the reference's dtype flow, t from the X-ray range [0, 1000) (applications/xray/compute.py:
+    103) with one t < 10 (where sqrt(1 - acp) is smallest and the fp32-vs-fp16 scheduler arithmetic differs most), and the
+    per-pixel heat-map of `Typicallity.compute` (xray/compute.py:210-218: mean over latent C, bilinear to the image,
+    L_null - L_c, mean over N) against the oracle's reduction of the oracle's grid."""
+    h = w = 128
+    x, eps, _, c = _inputs(h, w, 2, flow="f32")
+    t = torch.tensor([3, 742])
+    nb, tb, cc, slots = _tile(eps, t, c)
+    engine.set_prompts(c)
+    loss = engine.score(x, nb, tb, slots, latent_dtype=torch.float32).cpu()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = R.compute_loss(sd15_weights_torch, x, nb, tb, cc, autocast=True, latent_dtype=torch.float32)
+    rl = U.rel_l2(loss, ref)
+    per_t = [U.rel_l2(loss[[i, 2 + i]], ref[[i, 2 + i]]) for i in range(2)]
+    T, T_ref = _T(loss, 2, h, w), _T(ref, 2, h, w)
+    dm = abs(T - T_ref) / ref.mean().item()
+    print(f"[128x128 f32] loss rel-L2 {rl:.2e} (t=3: {per_t[0]:.2e}, t=742: {per_t[1]:.2e}); T(x|c) engine {T:.6f} oracle {T_ref:.6f} "
+          f"mean loss {ref.mean():.4f}: |dT|/mean-loss {dm:.2e}")
+    assert torch.isfinite(loss).all() and rl < TOL_LOSS and max(per_t) < TOL_LOSS, (rl, per_t)
+    assert dm <= TOL_T_MEANLOSS, dm
+    # heat-maps: latent-grid map and the 1024 x 1024 per-pixel map, engine grid -> engine reduction vs oracle grid -> oracle reduction
+    from diff_mining_amd.typicality import TypicalityScorer
+    sc = TypicalityScorer(engine)
+    grid = loss.view(2, 2, 4, h, w).transpose(0, 1).contiguous()               # [N, n_cond, 4, h, w], fp32 like dm_score's output
+    grid_ref = ref.view(2, 2, 4, h, w).transpose(0, 1).contiguous()
+    hm = sc.heatmap(grid.to(engine.device)).cpu()
+    hm_ref = R.typicality_map(grid_ref)
+    px = sc.pixel_heatmap(grid.half().to(engine.device), (1024, 1024)).cpu()    # the reference reduces the stored fp16 grid
+    px_ref = R.load_typicality(grid_ref.half(), (1024, 1024), 1, 1)
+    # a heat-map pixel is a difference of two nearly equal losses: its error is stated against the loss scale it is made of
+    scale = ref.mean().item()
+    e_hm, e_px = (hm - hm_ref).abs().max().item() / scale, (px - px_ref).abs().max().item() / scale
+    c_hm = torch.corrcoef(torch.stack([hm.flatten(), hm_ref.flatten()]))[0, 1].item()
+    print(f"[128x128] heat-map max |d| / mean loss: latent grid {e_hm:.2e}, 1024 px {e_px:.2e}; correlation with the oracle's map {c_hm:.5f}; "
+          f"map std / mean loss {hm_ref.std().item() / scale:.2e}")
+    assert px.shape == (1024, 1024) and hm.shape == (h, w)
+    assert e_hm < 2e-2 and e_px < 2e-2 and c_hm > 0.99, (e_hm, e_px, c_hm)
+
+
+def test_single_condition_grid_vs_oracle(engine, sd15_weights_torch):
+    """The n_cond == 1 branch of `compute_losses` (typicality.py; D.compute_losses with a single embedding row): dm_score on
+    slot 0 instead of the shared-draw schedule."""
+    from diff_mining_amd.typicality import TypicalityScorer
+    sc = TypicalityScorer(engine, seed=42, N=3, t_min=0.1, t_max=0.7)
+    x, _, _, c = _inputs(16, 16, 1, flow="f32")
+    noises, ts = sc.draw(x.shape)
+    grid = sc.compute_losses(x, c[:1], noises=noises, timesteps=ts)
+    assert grid.shape == (3, 1, 4, 16, 16) and grid.dtype == torch.float16
+    ref = R.compute_losses(sd15_weights_torch, x, c[:1].float(), noises, ts, B=3)
+    r = U.rel_l2(grid.float(), ref.float())
+    print(f"n_cond = 1 grid rel-L2 {r:.2e}")
+    assert r < TOL_LOSS, r
+    # and it is the first column of the two-condition grid, bit for bit (a sample's loss does not depend on its batch)
+    both = sc.compute_losses(x, c, noises=noises, timesteps=ts)
+    assert torch.equal(both[:, :1], grid)
+
+
+@pytest.mark.parametrize("idx,shape", [(0, (1280, 4, 4)), (2, (640, 16, 16)), (3, (320, 16, 16))])
+def test_dift_other_taps_vs_oracle(engine, sd15_weights_torch, idx, shape):
+    """`up_ft_indices` other than the paper's 1 (dift.py:133-165): values, not only shapes, against the fp32 oracle
+    (up_blocks[0] and [2] include their upsampler, up_blocks[3] has none)."""
+    h = w = 16
+    ens = 2
+    x, eps, t, c = _inputs(h, w, ens)
+    noisy = R.add_noise(x.float().expand(ens, -1, -1, -1), eps.float(), torch.tensor(161), R.alphas_cumprod()).half()
+    engine.set_prompts(c[:1])
+    slots = torch.zeros(ens, dtype=torch.int32)
+    feat, mean = engine.dift(noisy, torch.tensor(161), slots, idx, ens)
+    ft_ref, mean_ref = R.dift_features(sd15_weights_torch, noisy.float(), 161, c[:1].float().expand(ens, -1, -1), idx)
+    assert tuple(feat.shape[1:]) == shape == tuple(ft_ref.shape[1:])
+    rf, rm = U.rel_l2(feat.float().cpu(), ft_ref), U.rel_l2(mean.cpu(), mean_ref)
+    print(f"dift up_ft_index {idx}: features rel-L2 {rf:.2e}, ensemble mean {rm:.2e}")
+    assert rf < TOL_DIFT and rm < TOL_DIFT
+
+
+def test_no_allocation_in_steady_state(engine):
+    """no allocation (and no host walk of the schedule) on the steady-state path.  A cars-like stream — latents of
+    32 x 40 ... 32 x 48 (256 px short side, varying width), 4 draws x 2 prompts each, prompt sets of varying size — after
+    dm_engine_reserve for the largest call: zero device allocations, and one schedule dry run per distinct shape only."""
+    from diff_mining_amd.typicality import TypicalityScorer
+    widths = [40, 42, 48, 45, 40, 48, 42, 44]
+    engine.reserve(max_batch=8, h=32, w=48, n_cond=2, max_prompts=12)
+    g = torch.Generator().manual_seed(1)
+    c_small, c_big = torch.randn(2, 77, 768, generator=g).half(), torch.randn(9, 77, 768, generator=g).half()
+    sc = TypicalityScorer(engine, seed=42, N=4, t_min=0.1, t_max=0.7)
+    for wd in sorted(set(widths)):                                   # warm-up: every shape once (its dry run)
+        sc.compute_losses(torch.randn(1, 4, 32, wd, generator=g), c_small, to_host=False)
+    torch.cuda.synchronize()
+    s0 = engine.stats()
+    outs = []
+    for i, wd in enumerate(widths * 2):
+        engine.set_prompts(c_big if i % 3 == 0 else c_small)        # a larger prompt set now and then
+        outs.append(sc.compute_losses(torch.randn(1, 4, 32, wd, generator=g), c_small, to_host=False))
+    torch.cuda.synchronize()
+    s1 = engine.stats()
+    print(f"steady state over {2 * len(widths)} images of {len(set(widths))} shapes: device allocations {s1['device_allocs'] - s0['device_allocs']}, "
+          f"schedule dry runs {s1['schedule_dry_runs'] - s0['schedule_dry_runs']} (before: {s0})")
+    assert s1["device_allocs"] == s0["device_allocs"]
+    assert s1["schedule_dry_runs"] == s0["schedule_dry_runs"]
+    assert all(torch.isfinite(o.float()).all() for o in outs)

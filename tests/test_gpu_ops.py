@@ -717,3 +717,81 @@ def test_attention_cross_fuzz():
             U.assert_close_fp16(o, o0.float().cpu(), f"cross fuzz it={it} D={D} B={B} Tq={Tq}", rel=3e-3, abs_frac=4e-3)
     finally:
         lib.dm_set_option(b"attn_cross", 1)
+
+
+def test_attention_self_16384_keys_vs_fp32_softmax():
+    """The X-ray case (BASELINE configs[4]: 1024 px -> latent 128 x 128 = 16 384 tokens, head_dim 40): the online softmax
+    over 256 key tiles against an exact fp32 softmax, on 640 sampled query rows per head (all rows would be a 8.6 GB score
+    tensor).  Scores are scaled so that the softmax is neither flat nor one-hot (row max ~ 5 sigma over 16 384 keys)."""
+    heads, D, T = 8, 40, 16384
+    Cc = heads * D
+    qkv = U.f16_randn(1, T, 3 * Cc, seed=41)
+    g = qkv.to(U.dev())
+    o = U.op_attention(g[..., :Cc], g[..., Cc:2 * Cc], g[..., 2 * Cc:], heads)
+    rows = torch.cat([torch.arange(0, 64), torch.randperm(T, generator=torch.Generator().manual_seed(3))[:512], torch.arange(T - 64, T)]).to(U.dev())
+    q = g[0, rows, :Cc].float().view(-1, heads, D).transpose(0, 1)              # [heads, R, D]
+    k = g[0, :, Cc:2 * Cc].float().view(T, heads, D).transpose(0, 1)
+    v = g[0, :, 2 * Cc:].float().view(T, heads, D).transpose(0, 1)
+    p = torch.softmax(q @ k.transpose(1, 2) * D ** -0.5, dim=-1)
+    ref = (p @ v).transpose(0, 1).reshape(len(rows), Cc)
+    got = o[0, rows].float()
+    r, m = U.assert_close_fp16(got, ref, "self-attn D=40 T=16384", rel=3e-3, abs_frac=6e-3)
+    print(f"self-attention 16 384 keys, D = 40, {len(rows)} sampled rows x 8 heads: rel-L2 {r:.2e}, max|err|/max|ref| {m:.2e}; "
+          f"largest softmax weight {p.max().item():.3f}")
+    assert not torch.isnan(o.float()).any()
+
+
+@pytest.mark.parametrize("M,C,Cout,epi", [(300, 320, 960, 0), (4096 + 3, 640, 1920, 0), (131072 + 6, 320, 2560, 1), (40960, 1280, 10240, 1),
+                                          (655360, 320, 320, 0)])
+def test_layernorm_statistics_inside_the_gemm(M, C, Cout, epi):
+    """r03: LN -> Linear with NO statistics kernel (dm_op_igemm_ln with stats = NULL): K = C, so the GEMM's own k loop carries
+    every channel of a row through LDS and accumulates (sum, sum of squares) there.  (1) against F.linear(F.layer_norm(x))
+    in fp32 on rows with a non-zero mean (one-pass variance: the cancellation case); (2) the 128-row tile and the persistent
+    256 x 320 tile add the same numbers in the same order: bit-identical; (3) against the statistics-kernel path: the two
+    differ only by the statistics' rounding (two-pass vs one-pass fp32), far below one fp16 ulp of the output on average."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    x = (U.f16_randn(M, C, seed=1).float() * 1.5 + 2.0 * U.f16_randn(M, 1, seed=2).float()).half()     # |mean| up to ~3 sigma of the row
+    w = U.f16_randn(Cout, C, seed=3, scale=C ** -0.5)
+    b = U.f16_randn(Cout, seed=4, scale=0.1)
+    gamma = (1 + 0.1 * U.f16_randn(C, seed=5).float()).half()
+    beta = (0.05 * U.f16_randn(C, seed=6).float()).half()
+    wq, bq = U.pack_geglu(w, b) if epi == 1 else (w, b)
+    wf = (wq.float() * gamma.float()[None]).half()
+    ln_s, ln_t = wf.float().sum(1), (wq.float() @ beta.float()) + bq.float()
+    xg, wfd, sd_, td_ = x.to(d), wf.to(d), ln_s.to(d), ln_t.to(d)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=d)
+    assert lib.dm_op_ln_stats(U.stream(), U.ptr(xg), M, C, 1e-5, U.ptr(stats)) == 0
+
+    def run(st):
+        y = torch.full((M, Cout // 2 if epi else Cout), float("nan"), dtype=torch.float16, device=d)
+        assert lib.dm_op_igemm_ln(U.stream(), U.ptr(xg), U.ptr(wfd), U.ptr(sd_), U.ptr(td_), U.ptr(st) if st is not None else None,
+                                  U.ptr(y), M, C, Cout, epi) == 0
+        torch.cuda.synchronize()
+        return y
+    try:
+        lib.dm_set_option(b"igemm_big", 0)
+        y_small = run(None)
+        lib.dm_set_option(b"igemm_big", 1)
+        y_big = run(None)
+        y_kernel = run(stats)
+    finally:
+        lib.dm_set_option(b"igemm_big", -1)
+    y_auto = run(None)                                         # per-shape choice incl. the head / tail row split
+    assert not torch.isnan(y_big.float()).any()
+    assert torch.equal(y_small, y_big) and torch.equal(y_auto, y_big)
+    rows = torch.arange(M) if M <= 8192 else torch.cat([torch.arange(0, 2048), torch.arange(M - 2048, M)])
+    xr = x[rows].float()
+    h = F.linear(F.layer_norm(xr, (C,), gamma.float(), beta.float(), 1e-5), w.float(), b.float())
+    if epi == 1:
+        hh = h.half().float()
+        ref = hh[:, :Cout // 2] * F.gelu(hh[:, Cout // 2:]).half().float()
+    else:
+        ref = h
+    r, m = U.assert_close_fp16(y_big[rows.to(d)], ref, f"in-GEMM LN statistics epi={epi}", rel=3e-3, abs_frac=4e-3)
+    diff = (y_big.float() - y_kernel.float()).abs()
+    frac = (diff > 0).float().mean().item()
+    print(f"in-GEMM LN statistics M={M} C={C} epi={epi}: rel-L2 vs fp32 {r:.2e}; outputs that differ from the statistics-kernel path: {frac:.2%}, "
+          f"max |d| {diff.max().item():.2e}")
+    assert frac < 0.05 and diff.max().item() <= 4e-3 * ref.abs().max().item()

@@ -225,3 +225,188 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                         env=env2, timeout=120)
     assert r2.returncode != 0 and "WORLD_SIZE=3" in r2.stderr
+
+
+# ---- r03: surface leftovers (VERDICT r02 "missing" 2, 3, 4, 6) -----------------------------------------
+def test_xray_prompt_template_has_a_non_empty_null_prompt():
+    """`Embed.embed_diseases` (applications/xray/compute.py:54-57): "Chest X-Ray with {c}." and the null prompt
+    "Chest X-Ray" — unlike every other dataset's ''."""
+    P = T.CategoryFeatures.prompts
+    assert P("xray", ["", "Cardiomegaly", "Pleural Effusion"]) == ["Chest X-Ray", "Chest X-Ray with Cardiomegaly.",
+                                                                  "Chest X-Ray with Pleural Effusion."]
+    assert P("cars", ["", "1970"]) == ["A car.", "A car at the 1970's."]            # compute.py:43-44
+    assert P("places", ["", "living_room"]) == ["", "Image of living room."]       # compute.py:45-46
+    assert P("geo", ["", "France"]) == ["", "France"] and P("ftt", ["1950"]) == ["1950"]
+
+
+class _FakeTokenizer:
+    model_max_length = 77
+
+    def __init__(self):
+        self.calls = []
+
+    def __call__(self, prompts, max_length, padding, truncation, return_tensors):
+        assert max_length == 77 and padding == "max_length" and truncation and return_tensors == "pt"
+        self.calls.append(list(prompts))
+        ids = torch.zeros(len(prompts), 77, dtype=torch.long)
+        for i, p in enumerate(prompts):
+            ids[i, : min(len(p), 77)] = torch.tensor([ord(ch) for ch in p[:77]])
+        return type("Enc", (), {"input_ids": ids})()
+
+
+class _FakeDiftEngine(_FakeEngine):
+    def __init__(self):
+        super().__init__()
+        self.clip_calls, self.dift_calls = [], []
+
+    def clip_encode(self, ids):
+        self.clip_calls.append(ids.clone())
+        return ids.float()[:, :, None].expand(-1, -1, 768).contiguous()
+
+    def dift(self, noisy, t, slots, up_ft_index, ensemble):
+        self.dift_calls.append((tuple(noisy.shape), int(t), up_ft_index, ensemble))
+        return None, noisy.float().mean(0, keepdim=True)
+
+
+def test_sdfeaturizer_forward_takes_a_prompt_string():
+    """`SDFeaturizer.forward(img_tensor, prompt: str, t, up_ft_index, ensemble_size)` (dift.py:214-228): the string goes
+    through the tokenizer (padding="max_length") and the engine's CLIP text tower, once per distinct string."""
+    from diff_mining_amd.dift import SDFeaturizer
+    eng, tok = _FakeDiftEngine(), _FakeTokenizer()
+    f = SDFeaturizer.__new__(SDFeaturizer)
+    SDFeaturizer.__init__(f, eng, tokenizer=tok)
+    lat = torch.randn(1, 4, 8, 8)
+    out = f.forward(lat, "A car from the 1970s.", t=161, up_ft_index=1, ensemble_size=8, noise=torch.zeros(8, 4, 8, 8))
+    assert out.shape == (1, 4, 8, 8)
+    assert tok.calls == [["A car from the 1970s."]] and len(eng.clip_calls) == 1 and eng.n_prompts == 1
+    assert eng.dift_calls == [((8, 4, 8, 8), 161, 1, 8)]
+    f.forward(lat, "A car from the 1970s.", t=161, noise=torch.zeros(8, 4, 8, 8))
+    assert len(tok.calls) == 1                                 # the category prompt is encoded once, not per patch
+    emb = torch.randn(1, 77, 768)
+    f.forward(lat, emb, noise=torch.zeros(8, 4, 8, 8))         # hidden states are still accepted
+    assert len(tok.calls) == 1
+    g = SDFeaturizer.__new__(SDFeaturizer)
+    SDFeaturizer.__init__(g, eng)
+    with pytest.raises(ValueError, match="tokenizer"):
+        g.forward(lat, "no tokenizer given")
+    with pytest.raises(TypeError):
+        g.forward(lat, 17)
+
+
+def test_unet_config_json_is_checked_by_key(tmp_path):
+    """compute.py:65-70: `from_pretrained(model_path)` builds the U-Net `unet/config.json` describes; the engine implements
+    SDv1.5's only, so any other architecture is refused with the offending keys named."""
+    import json
+    from diff_mining_amd import unet_spec as S
+    from diff_mining_amd.engine import EngineError, UNetEngine
+    good = dict(S.SD15_UNET_CONFIG, _class_name="UNet2DConditionModel", _diffusers_version="0.24.0", sample_size=64,
+                use_linear_projection=False, upcast_attention=False, class_embed_type=None, num_class_embeds=None,
+                only_cross_attention=False, dual_cross_attention=False, resnet_time_scale_shift="default")
+    S.check_unet_config(good)                                                   # SDv1.5's own file + later defaults
+    minimal = {k: v for k, v in S.SD15_UNET_CONFIG.items() if k not in ("mid_block_type", "center_input_sample", "mid_block_scale_factor")}
+    S.check_unet_config(minimal)
+    for key, val, frag in [("cross_attention_dim", 1024, "cross_attention_dim = 1024"),           # SD 2.x
+                           ("attention_head_dim", [5, 10, 20, 20], "attention_head_dim"),
+                           ("use_linear_projection", True, "use_linear_projection = True"),
+                           ("block_out_channels", [320, 640, 1280], "block_out_channels"),
+                           ("upcast_attention", True, "upcast_attention"),
+                           ("addition_embed_type", "text_time", "addition_embed_type"),               # SDXL
+                           ("transformer_layers_per_block", [1, 2, 10], "transformer_layers_per_block"),
+                           ("in_channels", 9, "in_channels = 9"),                                     # inpainting
+                           ("_class_name", "UNet2DModel", "_class_name")]:
+        with pytest.raises(ValueError, match=frag.replace("[", r"\[").replace("]", r"\]")):
+            S.check_unet_config(dict(good, **{key: val}))
+    bad = dict(good)
+    del bad["layers_per_block"]
+    with pytest.raises(ValueError, match="layers_per_block missing"):
+        S.check_unet_config(bad)
+    # the loader reads the config.json next to the safetensors first and names the file
+    d = tmp_path / "unet"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(dict(good, cross_attention_dim=1024)))
+    (d / "diffusion_pytorch_model.safetensors").write_bytes(b"")
+    e = UNetEngine.__new__(UNetEngine)
+    with pytest.raises(EngineError, match="config.json.*cross_attention_dim = 1024"):
+        e.load_safetensors(str(d / "diffusion_pytorch_model.safetensors"))
+
+
+def test_gather_world1_is_a_no_op_view():
+    """no Fill / index_put kernels in the timed region at world 1."""
+    s = torch.tensor([3.0, 1.0, 2.0])
+    assert T.gather_scores(s, 3, 0, 1) is s
+    g = torch.zeros(3, 2, 2, 4, 2, 2, dtype=torch.float16)
+    assert T.gather_grids(g, 3, 0, 1) is g
+
+
+class _FakeScoreEngine(_FakeEngine):
+    """A deterministic stand-in for the engine's scoring calls (CPU): the loss of a sample depends only on that
+    sample's (x, eps, t, prompt) — the property the draw split relies on."""
+
+    def set_prompts(self, ctx):
+        super().set_prompts(ctx)
+        self.ctx = ctx.float()
+
+    def _loss(self, x, eps, t, k):
+        return ((x.float() * 0.5 + eps.float()) * (1.0 + t.float().view(-1, 1, 1, 1) / 1000.0) - self.ctx[k].mean()) ** 2
+
+    def score_conds(self, x, eps, t, n_cond, x_index=None, latent_dtype=None):
+        return torch.cat([self._loss(x, eps, t, k) for k in range(n_cond)])
+
+    def score(self, x, eps, t, slots, x_index=None, latent_dtype=None):
+        return torch.cat([self._loss(x, eps[i:i + 1], t[i:i + 1], int(s)) for i, s in enumerate(slots)])
+
+    def reduce_typicality(self, grid):
+        m = (grid[:, -1].float().mean(1) - grid[:, 0].float().mean(1)).mean(0)
+        return m, m.mean().reshape(1)
+
+
+def _fake_scorer(N):
+    sc = T.TypicalityScorer(_FakeScoreEngine(), seed=42, N=N, t_min=0.1, t_max=0.7)
+    return sc
+
+
+def _split_worker(rank, world, port, n_img, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = _fake_scorer(7)                                        # 7 draws over 2 ranks: 4 + 3 (ragged)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(n_img, 4, 6, 5, generator=g)
+    emb = torch.randn(2, 77, 768, generator=g)
+    grids = T.score_images_sharded(sc, lat, emb, rank, world, mode="grids")
+    scal = T.score_images_sharded(sc, lat, emb, rank, world, mode="scalars")
+    torch.save((grids, scal), out + f".{rank}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_img", [1, 3])
+def test_sharded_scoring_world2_is_bit_equal_to_one_rank(tmp_path, n_img):
+    """SURVEY 8e: n_img >= world -> images r::world and ONE all-gather (scalars or fp16 grids); n_img < world -> the draws
+    of an image are split over the ranks and the grids gathered.  Either way every rank ends with exactly the
+    single-rank result (compute.py:300-341 shards by image; the draw split is the fallback 8e names)."""
+    out = str(tmp_path / "res.pt")
+    port = 29500 + (os.getpid() % 2000) + 17 + n_img
+    mp.spawn(_split_worker, args=(2, port, n_img, out), nprocs=2, join=True)
+    sc = _fake_scorer(7)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(n_img, 4, 6, 5, generator=g)
+    emb = torch.randn(2, 77, 768, generator=g)
+    want_g = torch.stack([sc.compute_losses(lat[i:i + 1], emb, to_host=False) for i in range(n_img)])
+    want_s = torch.cat([sc.typicality_scalar(x).reshape(1) for x in want_g])
+    assert want_g.shape == (n_img, 7, 2, 4, 6, 5) and want_g.dtype == torch.float16
+    for r in range(2):
+        grids, scal = torch.load(out + f".{r}")
+        assert torch.equal(grids, want_g), f"rank {r}: gathered grids differ from the single-rank grids"
+        assert torch.equal(scal, want_s)
+    assert T.draw_shard(7, 0, 2) == [0, 2, 4, 6] and T.draw_shard(7, 1, 2) == [1, 3, 5]
+
+
+def test_persistent_tile_refuses_tensors_beyond_32_bit_offsets():
+    """the persistent 256 x 320 kernel keeps activation offsets (row * channels) in 32 bits; shapes whose source
+    tensor reaches 2^31 elements must fall back to the 128-row tile (64-bit addressing)."""
+    from diff_mining_amd.engine import load_library
+    lib = load_library()
+    rows_ok = (1 << 31) // 1280 - 256
+    assert lib.dm_op_igemm_tile(rows_ok - rows_ok % 256, 1280, 320, 0) == 1
+    assert lib.dm_op_igemm_tile((1 << 31) // 1280 + 256, 1280, 320, 0) == 0
+    assert lib.dm_op_igemm_head_rows((1 << 31) // 1280 + 256, 1, 1280, 320, 0) == 0
