@@ -546,7 +546,13 @@ struct Fwd {
     // LayerNorm folded into the following Linear: per-row (mean, rstd), then the GEMM on the raw tokens with
     // the correction in its epilogue (saves writing and re-reading the normalised token matrix)
     int ln_dense(const LnFold& f, const Tensor& x, int epi, Tensor* y) {
-        if (option(OPT_LN_INKERNEL)) {      // the GEMM takes the row statistics itself (no statistics kernel, no extra read of x)
+        // ln_inkernel: 0 = statistics kernel + GEMM; 2 = the GEMM takes the row statistics itself everywhere; 1 = where that is
+        // cheaper: every channel tile of a row re-derives the statistics (N / 320 tiles x C / 64 k steps of extra LDS reads
+        // and dot2s against one C-wide read by the statistics kernel), measured per shape at the bench batch (tools/ab_igemm.py
+        // ln_inkernel 0 1): to_q 0.96, to_q/k/v 0.93 / 0.99 / 1.04 (C = 320 / 640 / 1280), GEGLU projection 0.98 / 1.04 / 1.08
+        // => in the GEMM up to N = 2560
+        const int ink = option(OPT_LN_INKERNEL);
+        if (ink == 2 || (ink == 1 && f.w.cout <= 2560)) {
             return igemm(f.w, IG_DENSE, x, nullptr, x.H, x.W, nullptr, 0, nullptr, epi, y, &f, nullptr);
         }
         size_t soff; void* sp;

@@ -12,6 +12,7 @@ namespace dm {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 ln_half2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -359,7 +360,11 @@ void igemm_kernel(IGemmParams p) {
                     const int row = tid >> 1, hf = tid & 1;
                     const half8 xv = *reinterpret_cast<const half8*>(xt + row * 128 + (((4 * hf + (g - 2)) ^ (row & 7)) << 4));
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { const float f = (float)xv[k]; ln_s1 += f; ln_s2 = __builtin_fmaf(f, f, ln_s2); }
+                    for (int k = 0; k < 8; k += 2) {          // v_dot2_f32_f16: two exact fp16 products + the fp32 accumulator per instruction
+                        const ln_half2 v2 = ln_half2{xv[k], xv[k + 1]};
+                        ln_s1 = __builtin_amdgcn_fdot2(v2, ln_half2{(_Float16)1.0f, (_Float16)1.0f}, ln_s1, false);
+                        ln_s2 = __builtin_amdgcn_fdot2(v2, v2, ln_s2, false);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -622,7 +622,8 @@ def test_xray_config4_vs_oracle(engine, sd15_weights_torch):
     print(f"[128x128] heat-map max |d| / mean loss: latent grid {e_hm:.2e}, 1024 px {e_px:.2e}; correlation with the oracle's map {c_hm:.5f}; "
           f"map std / mean loss {hm_ref.std().item() / scale:.2e}")
     assert px.shape == (1024, 1024) and hm.shape == (h, w)
-    assert e_hm < 2e-2 and e_px < 2e-2 and c_hm > 0.99, (e_hm, e_px, c_hm)
+    # measured r03: 5.05e-3 / 5.02e-3, correlation 0.99997 (the map's own std is 0.136 of the mean loss)
+    assert e_hm < 1e-2 and e_px < 1e-2 and c_hm > 0.9999, (e_hm, e_px, c_hm)
 
 
 def test_single_condition_grid_vs_oracle(engine, sd15_weights_torch):
