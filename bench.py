@@ -234,12 +234,14 @@ def hbm_traffic_per_launch(launches_per_step):
     of them two kernel dispatches) from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950
     correction, + WRITE_SIZE): family bytes per step / launches per step.  rocprofv3 cannot run inside this process,
     so the number is the recorded one for this kernel build, or None when no record exists."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_final_pmc.json")) as f:
-            k = json.load(f)["kernels"]["igemm_family"]
-        return round((k["fetch_GB_per_step"] + k["write_GB_per_step"]) * 1e9 / launches_per_step)
-    except Exception:
-        return None
+    for tag in ("r03_final", "r02_final"):          # the newest record of this kernel build that is committed
+        try:
+            with open(os.path.join(ROOT, "profiles", tag + "_pmc.json")) as f:
+                k = json.load(f)["kernels"]["igemm_family"]
+            return round((k["fetch_GB_per_step"] + k["write_GB_per_step"]) * 1e9 / launches_per_step)
+        except Exception:
+            continue
+    return None
 
 
 def side_workload(args, eng, dev, sd):

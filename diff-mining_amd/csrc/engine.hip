@@ -126,6 +126,8 @@ struct Tensor {            // NHWC activation in the arena
     size_t off = (size_t)-1;
     f16* p = nullptr;
     int N = 0, H = 0, W = 0, C = 0;
+    bool view = false;     // a pre-placed window into another tensor (first_slot()): producers write it in place, free() ignores it
+                           // (explicit: in the dry run every pointer is null, so "p set, off unset" cannot mark a view)
     long long rows() const { return (long long)N * H * W; }
 };
 
@@ -467,7 +469,7 @@ struct Fwd {
         *p = e->arena_base + *off;
         return 0;
     }
-    void free(Tensor& t) { if (t.off != (size_t)-1) { e->arena.release(t.off); t.off = (size_t)-1; t.p = nullptr; } }
+    void free(Tensor& t) { if (!t.view && t.off != (size_t)-1) { e->arena.release(t.off); t.off = (size_t)-1; t.p = nullptr; } }
     void free_raw(size_t off) { e->arena.release(off); }
 
     int prof_begin(int kind, double flops, int M = 0, int N = 0, int K = 0, int mode = 0) {
@@ -494,7 +496,7 @@ struct Fwd {
         const int cin = x.C + (x2 ? x2->C : 0);
         if (cin != cv.cin) DM_FAIL(e, "igemm: channel mismatch %d vs %d", cin, cv.cin);
         const int cout_y = (epi == EPI_GEGLU) ? cv.cout / 2 : cv.cout;
-        if (y->p && y->off == (size_t)-1) {            // pre-placed output (first_slot() of a stacked tensor): write in place
+        if (y->view) {                                 // pre-placed output (first_slot() of a stacked tensor): write in place
             if (y->N != x.N || y->H != OH || y->W != OW || y->C != cout_y) DM_FAIL(e, "igemm: pre-placed output has the wrong shape");
         } else DM_TRY(alloc(y, x.N, OH, OW, cout_y));
         IGemmParams p;
@@ -673,7 +675,7 @@ struct Fwd {
     // n_cond stacked copies of a [U, ...] tensor, out[k*U + i] = in[i], without copying slot 0: the producer writes the
     // first slot of the stacked tensor in place (first_slot() as its output), fill_slots() copies it to the others
     static Tensor first_slot(const Tensor& stacked, int n_cond) {
-        Tensor v; v.p = stacked.p; v.off = (size_t)-1; v.N = stacked.N / n_cond; v.H = stacked.H; v.W = stacked.W; v.C = stacked.C;
+        Tensor v; v.p = stacked.p; v.off = (size_t)-1; v.view = true; v.N = stacked.N / n_cond; v.H = stacked.H; v.W = stacked.W; v.C = stacked.C;
         return v;
     }
     int fill_slots(const Tensor& stacked, int n_cond) {

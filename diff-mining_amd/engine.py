@@ -88,8 +88,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_op_igemm_tile.argtypes = [i32, i32, i32, i32]
     lib.dm_set_option.argtypes = [C.c_char_p, i32]
     lib.dm_op_attention512.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float]
-    lib.dm_engine_reserve.argtypes = [vp, i32, i32, i32, i32, i32, vp]
-    lib.dm_engine_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    if hasattr(lib, "dm_engine_reserve"):        # absent only from older A/B libraries loaded through DM_ENGINE_LIB
+        lib.dm_engine_reserve.argtypes = [vp, i32, i32, i32, i32, i32, vp]
+        lib.dm_engine_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     if path is None:
         _lib = lib
     return lib

@@ -235,8 +235,8 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
  *   numerically equivalent but NOT bit-identical: "igemm_splitk" = 2 (four k parts instead of three tap-aligned ones),
  *     "ln_fold" (LayerNorm folded into the next GEMM: the rounding moves from the LN output to the folded weights),
  *     "attn_pipe" / "attn_cross" (pipelined / one-pass-softmax kernels vs the generic online-softmax kernel: different
- *     rescaling points), "ln_stats_g" (different lane order of the row reductions), "gn_fused" (GroupNorm partial sums
- *     taken in the producer's tile order);
+ *     rescaling points), "ln_stats_g" (different lane order of the row reductions), "ln_inkernel" (0 / 1 / 2: LayerNorm
+ *     statistics from a statistics kernel (two-pass) or inside the folded GEMM (one-pass fp32 sums; 1 = where cheaper));
  *   "igemm_exp": experimental kernel paths of the current round (0 = shipped). */
 int dm_set_option(const char* name, int value);
 

@@ -2,7 +2,7 @@
 # Regenerate the judged artifacts of a round on the GPU box:  bash tools/profile_round.sh <tag>
 # (run through gpurun; outputs land in gpurun_out/<tag>/, copy the summaries into profiles/).
 set -u
-TAG=${1:-r02_final}
+TAG=${1:-r03_final}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -19,6 +19,15 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
     i=$((i+1))
 done
 python tools/pmc_to_json.py $OUT 4 > $OUT/pmc.json    # a pass runs 4 steps: 1 warm-up + 1 timed + 2 of the grid-D2H leg
+# per-shape HBM traffic of the igemm family (cold caches per launch)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/pmcs_fetch -o pmc -- python tools/pmc_shapes.py run > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $OUT/pmcs_write -o pmc -- python tools/pmc_shapes.py run > /dev/null 2>&1
+python tools/pmc_shapes.py parse $OUT/pmcs_fetch $OUT/pmcs_write > $OUT/pmc_shapes.txt 2> $OUT/pmc_shapes.err
+rm -rf $OUT/pmcs_fetch $OUT/pmcs_write
+# the side workloads (BASELINE configs[3], [4]) with the same keys as the graded line, and the cost of the live events
+for w in dift xray; do python bench.py --workload $w --steps 5 --warmup 2 >> $OUT/side_workloads.jsonl 2>> $OUT/bench.err; done
+for w in vae pixels; do python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline >> $OUT/side_workloads.jsonl 2>> $OUT/bench.err; done
+DM_BENCH_NOPROF=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_noprof.json 2>> $OUT/bench.err
 find $OUT/stats -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
 # raw traces are large; keep only the summaries
 rm -rf $OUT/pmc_[0-9] $OUT/stats
