@@ -94,9 +94,12 @@ __device__ __forceinline__ void epilogue_lds(const IGemmParams& p, floatx4 (&acc
             for (int i = 0; i < NI; ++i) {
                 const int cl = wc * (16 * NI) + 16 * i + 4 * lg;              // tile-local channel
                 float v0, v1, v2, v3;
-                if (LN) {
-                    v0 = rs[j] * (acc[i][j][0] - mu[j] * sz[i][0]) + bz[i][0]; v1 = rs[j] * (acc[i][j][1] - mu[j] * sz[i][1]) + bz[i][1];
-                    v2 = rs[j] * (acc[i][j][2] - mu[j] * sz[i][2]) + bz[i][2]; v3 = rs[j] * (acc[i][j][3] - mu[j] * sz[i][3]) + bz[i][3];
+                if (LN) {          // fma(rstd, acc, fma(-rstd mean, s, t)): the same form as igemm_pers_tile.h
+                    const float nrm = -(rs[j] * mu[j]);
+                    v0 = __builtin_fmaf(rs[j], acc[i][j][0], __builtin_fmaf(nrm, sz[i][0], bz[i][0]));
+                    v1 = __builtin_fmaf(rs[j], acc[i][j][1], __builtin_fmaf(nrm, sz[i][1], bz[i][1]));
+                    v2 = __builtin_fmaf(rs[j], acc[i][j][2], __builtin_fmaf(nrm, sz[i][2], bz[i][2]));
+                    v3 = __builtin_fmaf(rs[j], acc[i][j][3], __builtin_fmaf(nrm, sz[i][3], bz[i][3]));
                 } else {
                     v0 = acc[i][j][0] + bz[i][0]; v1 = acc[i][j][1] + bz[i][1];
                     v2 = acc[i][j][2] + bz[i][2]; v3 = acc[i][j][3] + bz[i][3];
