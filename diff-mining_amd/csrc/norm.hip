@@ -86,18 +86,30 @@ __global__ void gn_apply_kernel(const f16* __restrict__ X, const f16* __restrict
                                 int pix_per_block, const double* __restrict__ partial, int chunks, int G, double count, float eps,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, int silu, f16* __restrict__ Y) {
     __shared__ double sh_stat[2 * 64];          // (mean, rstd) per group, G <= 64
+    __shared__ double sh_part[2 * 1024];        // one (sum, sum of squares) per thread: slice s = t / G of group t % G
     const int cols = C >> 3;
     const int n = blockIdx.y;
     const int t = threadIdx.x;
-    if (t < G) {
+    {
+        // all threads fetch (one round trip instead of `chunks` dependent ones): slice s of group g adds the chunks
+        // s, s + S, ... (S = blockDim / G slices); the S slices are then added in order — a fixed tree per (C, HW)
+        const int S = (int)blockDim.x / G, g = t % G, sl = t / G;
         double ds = 0.0, dq = 0.0;
-        const double* in = partial + ((size_t)n * chunks * G + t) * 2;
-        for (int c = 0; c < chunks; ++c) { ds += in[(size_t)c * G * 2]; dq += in[(size_t)c * G * 2 + 1]; }
-        const double mean = ds / count;
-        double var = dq / count - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        sh_stat[2 * t] = mean;
-        sh_stat[2 * t + 1] = 1.0 / sqrt(var + (double)eps);
+        if (sl < S) {
+            const double* in = partial + ((size_t)n * chunks * G + g) * 2;
+            for (int c = sl; c < chunks; c += S) { ds += in[(size_t)c * G * 2]; dq += in[(size_t)c * G * 2 + 1]; }
+            sh_part[2 * t] = ds; sh_part[2 * t + 1] = dq;
+        }
+        __syncthreads();
+        if (t < G) {
+            ds = 0.0; dq = 0.0;
+            for (int k = 0; k < S; ++k) { ds += sh_part[2 * (k * G + t)]; dq += sh_part[2 * (k * G + t) + 1]; }
+            const double mean = ds / count;
+            double var = dq / count - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            sh_stat[2 * t] = mean;
+            sh_stat[2 * t + 1] = 1.0 / sqrt(var + (double)eps);
+        }
     }
     __syncthreads();
     const int col = t % cols;
