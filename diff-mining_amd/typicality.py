@@ -302,10 +302,9 @@ def _all_gather_padded(local: torch.Tensor, per: int, world: int) -> torch.Tenso
     import torch.distributed as dist
     buf = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     buf[: local.shape[0]] = local
-    out = torch.empty((world,) + tuple(buf.shape), dtype=buf.dtype, device=buf.device)
-    dist.all_gather_into_tensor(out.view(-1), buf.view(-1)) if hasattr(dist, "all_gather_into_tensor") and buf.is_cuda \
-        else dist.all_gather(list(out.unbind(0)), buf)
-    return out
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)                      # the same call on RCCL and on gloo (the CPU tests exercise exactly this path)
+    return torch.stack(out, 0)
 
 
 def gather_scores(local_scores: torch.Tensor, n_items: int, rank: int, world: int) -> torch.Tensor:
