@@ -133,6 +133,12 @@ def main():
             last["loss"] = loss
             return gather_scores(scores, n_img * world, rank, world)     # world 1: the tensor itself (no kernel)
 
+    if eng is not None and os.environ.get("DM_GRAPH", "0") not in ("", "0"):
+        # hipGraph replay (diagnostic, with DM_BENCH_NOPROF=1: a replay carries no per-launch events): the legacy default
+        # stream cannot be captured, so the steps run on a stream of their own
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(side)
     for _ in range(args.warmup):
         step()
     if eng is not None:
@@ -220,6 +226,8 @@ def main():
                           "bytes_per_step": n_img * N_DRAWS * N_COND * 4 * LAT * LAT * 2}),
             "scores_checksum": float(all_scores.double().sum().item()),
         }
+        if eng is not None:
+            out["engine_stats"] = eng.stats()
         if STUB:
             out["data"] = "stub (DM_BENCH_STUB=1: launcher / gather path only, no engine)"
         if not args.no_cpu_baseline and world == 1 and not STUB:

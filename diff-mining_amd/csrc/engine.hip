@@ -180,6 +180,14 @@ struct dm_engine {
     long long n_dry_runs = 0;
     int kv_capacity = 0;                                   // prompts the K/V cache buffers hold
     int* tile_ctr = nullptr;                               // tile hand-out counters of the persistent igemm (this engine's own)
+    // hipGraph replay of a whole U-Net run (option "graph"): one executable graph per (schedule key, every pointer argument),
+    // captured on the second call with that key (the first one sets function attributes and sizes the arena, which a capture
+    // cannot contain); dropped when the arena or the K/V cache move
+    struct GraphEntry { std::vector<long long> key; hipGraphExec_t exec; unsigned long long stamp; };
+    std::vector<GraphEntry> graphs;
+    std::map<std::vector<long long>, int> graph_seen;
+    unsigned long long graph_stamp = 0;
+    long long n_graph_launches = 0, n_graph_captures = 0;
 
     // profiling
     bool prof = false;
@@ -952,6 +960,11 @@ int run_clip(dm_engine* e, const int32_t* ids, int n, f16* out16, float* out32, 
     return 0;
 }
 
+void drop_graphs(dm_engine* e) {
+    for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
+    e->graphs.clear();
+}
+
 // Workspace for one schedule run.  The exact peak comes from a dry run of the schedule against an unbounded virtual
 // arena; it depends only on `key` (which schedule, batch, shape, options), so it is computed once per key and cached:
 // the steady-state path does no host walk of the schedule and — once the largest shape has been seen or reserved
@@ -974,6 +987,7 @@ int ensure_arena_for(dm_engine* e, hipStream_t s, const std::vector<long long>& 
     }
     if (need > e->arena_cap) {
         DM_HIP(e, hipStreamSynchronize(s));
+        drop_graphs(e);
         if (e->arena_base) DM_HIP(e, hipFree(e->arena_base));
         e->arena_base = nullptr; e->arena_cap = 0;
         const size_t cap = need + (need >> 4);
@@ -1000,6 +1014,7 @@ int reserve_prompts(dm_engine* e, int n_prompts, hipStream_t s) {
     int cap = e->kv_capacity > 0 ? 2 * e->kv_capacity : 16;
     if (cap < n_prompts) cap = n_prompts;
     DM_HIP(e, hipStreamSynchronize(s));
+    drop_graphs(e);
     for (int l = 0; l < e->n_tf; ++l) {
         if (e->kv_cache[l]) DM_HIP(e, hipFree(e->kv_cache[l]));
         e->kv_cache[l] = nullptr;
@@ -1007,6 +1022,48 @@ int reserve_prompts(dm_engine* e, int n_prompts, hipStream_t s) {
     }
     e->kv_capacity = cap;
     e->n_prompts = 0;                      // the old rows are gone
+    return 0;
+}
+
+// One U-Net run on the stream: straight launches, or — option "graph", no per-launch profiling — the replay of a captured
+// hipGraph.  A graph bakes in every pointer, so the key is the schedule key plus all pointer arguments; the
+// host-side arena allocator is deterministic, so a replay uses the same workspace addresses as the capture did.
+int run_forward_graphed(dm_engine* e, const FwdArgs& A, hipStream_t s) {
+    // (the legacy default stream cannot be captured: callers that want graphs run on a stream of their own)
+    if (!option(OPT_GRAPH) || e->prof || s == nullptr) return run_forward(e, A, s, false);
+    std::vector<long long> key = fwd_key(A);
+    for (const void* q : {A.x, (const void*)A.x_index, A.eps, (const void*)A.t, (const void*)A.slots, (const void*)A.loss,
+                          (const void*)A.pred, (const void*)A.feat, (const void*)A.feat_mean, (const void*)s})
+        key.push_back((long long)(size_t)q);
+    for (long long v : {(long long)A.latent_f32, (long long)A.out_stride, (long long)A.out_off, (long long)A.ensemble, (long long)e->n_prompts})
+        key.push_back(v);
+    for (auto& g : e->graphs)
+        if (g.key == key) {
+            g.stamp = ++e->graph_stamp;
+            ++e->n_graph_launches;
+            DM_HIP(e, hipGraphLaunch(g.exec, s));
+            return 0;
+        }
+    if (e->graph_seen[key]++ == 0) return run_forward(e, A, s, false);      // first sight: plain run (function attributes, warm caches)
+    hipGraph_t graph = nullptr;
+    DM_HIP(e, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = run_forward(e, A, s, false);
+    const hipError_t ec = hipStreamEndCapture(s, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ec != hipSuccess || !graph) DM_FAIL(e, "hipStreamEndCapture failed: %s", hipGetErrorString(ec));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) DM_FAIL(e, "hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+    if (e->graphs.size() >= 8) {                                           // keep the eight most recently used
+        size_t old = 0;
+        for (size_t i = 1; i < e->graphs.size(); ++i) if (e->graphs[i].stamp < e->graphs[old].stamp) old = i;
+        (void)hipGraphExecDestroy(e->graphs[old].exec);
+        e->graphs.erase(e->graphs.begin() + old);
+    }
+    e->graphs.push_back({key, exec, ++e->graph_stamp});
+    ++e->n_graph_captures; ++e->n_graph_launches;
+    DM_HIP(e, hipGraphLaunch(exec, s));
     return 0;
 }
 
@@ -1027,7 +1084,7 @@ namespace {
 struct OptDef { const char* name; const char* env; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
-    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1},
+    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<int> g_opt_init{0};
@@ -1101,6 +1158,7 @@ void dm_engine_destroy(dm_engine* e) {
     if (e->sa32_tab) (void)hipFree(e->sa32_tab);
     if (e->sb32_tab) (void)hipFree(e->sb32_tab);
     for (auto p : e->kv_cache) if (p) (void)hipFree(p);
+    for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto& ev : e->prof_ev) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     delete e;
@@ -1577,7 +1635,7 @@ static int run_chunked(dm_engine* e, FwdArgs A, int n_x, void* stream) {
         if (A.feat) C.feat = A.feat + (size_t)b0 * fc * fh * fw;
         if (A.feat_mean) C.feat_mean = A.feat_mean + (size_t)(b0 / A.ensemble) * fc * fh * fw;
         DM_TRY(ensure_arena(e, C, s));
-        DM_TRY(run_forward(e, C, s, false));
+        DM_TRY(run_forward_graphed(e, C, s));
     }
     (void)n_x;
     return 0;
@@ -1624,7 +1682,7 @@ int dm_score_conds(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, 
             DM_FAIL(e, "dm_score_conds: use dm_score for n_cond == 1");
         }
         DM_TRY(ensure_arena(e, A, s));
-        DM_TRY(run_forward(e, A, s, false));
+        DM_TRY(run_forward_graphed(e, A, s));
     }
     return 0;
 }
@@ -1732,10 +1790,11 @@ int dm_prof_read(dm_engine* e, double* igemm_ms, double* igemm_flops, int64_t* i
     return 0;
 }
 
-int dm_engine_stats(dm_engine* e, int64_t* device_allocs, int64_t* schedule_dry_runs) {
+int dm_engine_stats(dm_engine* e, int64_t* device_allocs, int64_t* schedule_dry_runs, int64_t* graph_launches) {
     if (!e) return 1;
     if (device_allocs) *device_allocs = e->n_device_allocs;
     if (schedule_dry_runs) *schedule_dry_runs = e->n_dry_runs;
+    if (graph_launches) *graph_launches = e->n_graph_launches;
     return 0;
 }
 

@@ -90,7 +90,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_op_attention512.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float]
     if hasattr(lib, "dm_engine_reserve"):        # absent only from older A/B libraries loaded through DM_ENGINE_LIB
         lib.dm_engine_reserve.argtypes = [vp, i32, i32, i32, i32, i32, vp]
-        lib.dm_engine_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+        lib.dm_engine_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     if path is None:
         _lib = lib
     return lib
@@ -484,9 +484,9 @@ class UNetEngine:
                                                self._stream()), "dm_engine_reserve")
 
     def stats(self) -> dict:
-        a, b = C.c_int64(), C.c_int64()
-        self._check(self.lib.dm_engine_stats(self._h, C.byref(a), C.byref(b)), "dm_engine_stats")
-        return {"device_allocs": a.value, "schedule_dry_runs": b.value}
+        a, b, g = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.lib.dm_engine_stats(self._h, C.byref(a), C.byref(b), C.byref(g)), "dm_engine_stats")
+        return {"device_allocs": a.value, "schedule_dry_runs": b.value, "graph_launches": g.value}
 
     def memory(self) -> dict:
         a, b = C.c_size_t(), C.c_size_t()

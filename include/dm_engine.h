@@ -207,9 +207,12 @@ int dm_engine_memory(dm_engine* e, size_t* weights_bytes, size_t* arena_bytes);
  * themselves) of h x w latents scored under n_cond prompts per draw (n_cond <= 1: dm_score / dm_unet_forward / dm_dift),
  * and `max_prompts` registered prompts (call it before dm_engine_set_prompts: growing the cache drops its rows) — after
  * which no call within those bounds allocates.  dm_engine_stats reports how many device allocations and schedule dry runs
- * the engine has done so far, so a caller (tests/test_gpu_e2e.py::test_no_allocation_in_steady_state) can assert it. */
+ * the engine has done so far, so a caller (tests/test_gpu_e2e.py::test_no_allocation_in_steady_state) can assert it, and how many
+ * U-Net runs were replays of a captured hipGraph (option "graph" = 1: a run whose schedule key and pointer arguments repeat is
+ * captured on its second occurrence and replayed from then on; needs a caller stream other than the legacy default stream and is
+ * bypassed while dm_prof_enable is on, because a replay carries no per-launch events). */
 int dm_engine_reserve(dm_engine* e, int max_batch, int max_h, int max_w, int n_cond, int max_prompts, void* stream);
-int dm_engine_stats(dm_engine* e, int64_t* device_allocs, int64_t* schedule_dry_runs);
+int dm_engine_stats(dm_engine* e, int64_t* device_allocs, int64_t* schedule_dry_runs, int64_t* graph_launches);
 
 /* ---- operator-level entry points ------------------------------------------------------------------
  * The individual gfx950 kernels behind the U-Net, exposed so that every op can be parity-tested
@@ -237,6 +240,7 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
  *     "attn_pipe" / "attn_cross" (pipelined / one-pass-softmax kernels vs the generic online-softmax kernel: different
  *     rescaling points), "ln_stats_g" (different lane order of the row reductions), "ln_inkernel" (0 / 1 / 2: LayerNorm
  *     statistics from a statistics kernel (two-pass) or inside the folded GEMM (one-pass fp32 sums; 1 = where cheaper));
+ *   "graph" (0 / 1): replay whole U-Net runs as captured hipGraphs (bit-identical: the same kernels with the same arguments);
  *   "igemm_exp": experimental kernel paths of the current round (0 = shipped). */
 int dm_set_option(const char* name, int value);
 

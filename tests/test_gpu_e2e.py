@@ -687,3 +687,42 @@ def test_no_allocation_in_steady_state(engine):
     assert s1["device_allocs"] == s0["device_allocs"]
     assert s1["schedule_dry_runs"] == s0["schedule_dry_runs"]
     assert all(torch.isfinite(o.float()).all() for o in outs)
+
+
+def test_hipgraph_replay_is_bit_identical(engine):
+    """Option "graph" (SURVEY §7 step 7): a U-Net run whose schedule key and pointer arguments repeat is captured as a hipGraph
+    on its second occurrence and replayed afterwards — the same kernels with the same arguments, so the same bits; prompts may
+    change between replays (the K/V cache is read, not captured)."""
+    lib = engine.lib
+    x, eps, t, c = _inputs(16, 16, 3, flow="f32")
+    dev = engine.device
+    xd, ed, td = x.to(dev), eps.to(dev), t.to(dev)
+    engine.set_prompts(c)
+    want = engine.score_conds(xd, ed, td, 2, latent_dtype=torch.float32).clone()
+    c2 = torch.flip(c, dims=[0]).contiguous()
+    engine.set_prompts(c2)
+    want2 = engine.score_conds(xd, ed, td, 2, latent_dtype=torch.float32).clone()
+    assert not torch.equal(want, want2)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    g0 = engine.stats()["graph_launches"]
+    try:
+        assert lib.dm_set_option(b"graph", 1) == 0
+        with torch.cuda.stream(side):
+            engine.set_prompts(c)
+            outs = []
+            for i in range(4):
+                got = engine.score_conds(xd, ed, td, 2, latent_dtype=torch.float32)
+                side.synchronize()
+                outs.append(got.clone())
+                del got                                   # the caching allocator hands the same block to the next call
+            engine.set_prompts(c2)
+            got2 = engine.score_conds(xd, ed, td, 2, latent_dtype=torch.float32).clone()
+            side.synchronize()
+    finally:
+        lib.dm_set_option(b"graph", 0)
+    launches = engine.stats()["graph_launches"] - g0
+    print(f"graph launches {launches} of 5 calls")
+    assert launches >= 2, launches
+    assert all(torch.equal(o, want) for o in outs)
+    assert torch.equal(got2, want2)
