@@ -34,7 +34,7 @@ inline int device_cu_count() {
 
 // Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of
 // the same name in upper case with a DM_ prefix (DM_IGEMM_PERSIST=0 ...), changeable through dm_set_option().
-enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_COUNT };
+enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_COUNT };
 int option(Option o);                       // engine.hip
 int set_option(const char* name, int value);   // 0 on success
 
@@ -72,6 +72,11 @@ struct IGemmParams {
     // process-wide set per device, valid only while the launches of a device are serialised on one stream (the
     // operator-level entry points of the parity tests).
     int* tile_ctr = nullptr;
+    // GroupNorm folded into a 1x1 convolution (r03, Transformer2D.norm -> proj_in): per-SAMPLE weights Wp + n * w_sample_stride
+    // (= fp16(W diag(a_n)), a_n the sample's per-channel GroupNorm scale) and a per-sample fp32 bias row ln_t + n * Cout
+    // (= W b_n + bias), n = row / rows_per_sample; dense mode only, every tile inside one sample, epilogue y = fp16(acc + t)
+    long long w_sample_stride = 0;
+    int rows_per_sample = 0;
 };
 constexpr int IGEMM_TILE_CTR_INTS = 8 * 32 + 32;
 hipError_t launch_igemm(const IGemmParams& p, hipStream_t s);
@@ -120,6 +125,12 @@ hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, in
 int gn_stats_chunks(int HW);
 hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, float eps, const float* gamma,
                            const float* beta, const double* partial, int silu, f16* Y, hipStream_t s);
+// GroupNorm (no activation) folded into the following 1x1 convolution W [Cout][C], bias [Cout]: from the same partial sums,
+// Wn [N][Cout][C] = fp16(W[o][c] * a[n][c]) and tn [N][Cout] = bias[o] + sum_c W[o][c] * b[n][c]  (fp32), y = x * a + b being the
+// normalisation's per-(sample, channel) affine.  The convolution then runs on the RAW x with per-sample weights: the
+// normalised tensor is never written or read.
+hipError_t launch_gn_fold(const double* partial, int N, int HW, int C, int G, float eps, const float* gamma, const float* beta,
+                          const f16* W, const f16* bias, int Cout, f16* Wn, float* tn, hipStream_t s);
 hipError_t launch_layernorm(const f16* X, int rows, int C, const float* gamma, const float* beta,
                             float eps, f16* Y, hipStream_t s);
 // per-row (mean, rstd) of X [rows][C] -> stats [rows][2] fp32 (the statistics half of LayerNorm)

@@ -553,6 +553,39 @@ struct Fwd {
         free_raw(poff);
         return 0;
     }
+    // GroupNorm (no activation) folded into the following 1x1 convolution (Transformer2D.norm -> proj_in): statistics as in
+    // groupnorm(), then per-sample weights W diag(a_n) and bias rows W b_n + bias, then the GEMM on the RAW x — the normalised
+    // tensor (one write + one read of the residual stream) never exists.  Pays while the per-sample weights (N x C x C) are
+    // small next to the tensor: the 64x64 and 32x32 levels (C = 320, 640); at C = 1280 they would be 524 MB per launch.
+    bool gn_fold_ok(const Tensor& x, const ConvW& cv) const {
+        const int HW = x.H * x.W;
+        return option(OPT_GN_FOLD) != 0 && cv.k == 1 && cv.cin == x.C && x.C <= 640 && cv.cout % 160 == 0 && HW % 128 == 0 &&
+               (long long)x.C * cv.cout * 8 <= (long long)HW * x.C;      // weights per sample <= 1/8 of the sample's activations
+    }
+    int gn_dense(const NormW& nw, const ConvW& cv, const Tensor& x, float eps, Tensor* y) {
+        const int C = x.C, HW = x.H * x.W;
+        const int chunks = gn_stats_chunks(HW);
+        size_t poff, woff, toff; void *pp, *wp, *tp;
+        DM_TRY(alloc_raw((size_t)x.N * chunks * GROUPS * 2 * sizeof(double), &poff, &pp));
+        DM_TRY(alloc_raw((size_t)x.N * cv.cout * C * sizeof(f16), &woff, &wp));
+        DM_TRY(alloc_raw((size_t)x.N * cv.cout * sizeof(float), &toff, &tp));
+        DM_TRY(alloc(y, x.N, x.H, x.W, cv.cout));
+        if (!dry) {
+            DM_HIP(e, launch_gn_stats(x.p, nullptr, x.N, HW, C, C, GROUPS, (double*)pp, s));
+            DM_HIP(e, launch_gn_fold((const double*)pp, x.N, HW, C, GROUPS, eps, nw.g, nw.b, cv.w, cv.b, cv.cout, (f16*)wp, (float*)tp, s));
+            IGemmParams p;
+            p.X = x.p; p.X2 = nullptr; p.Wp = (const f16*)wp; p.bias = nullptr; p.temb = nullptr; p.res = nullptr; p.Y = y->p;
+            p.M = (int)x.rows(); p.Cout = cv.cout; p.Cin = C; p.C1 = C; p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M;
+            p.mode = IG_DENSE; p.epi = EPI_PLAIN; p.ldy = cv.cout; p.ldres = 0; p.temb_ld = 0;
+            p.ln_s = (const float*)tp; p.ln_t = (const float*)tp; p.w_sample_stride = (long long)cv.cout * C; p.rows_per_sample = HW;
+            p.tile_ctr = e->tile_ctr;
+            DM_TRY(prof_begin(0, 2.0 * (double)p.M * cv.cout * C, p.M, cv.cout, C, 0));
+            DM_HIP(e, launch_igemm(p, s));
+            DM_TRY(prof_end());
+        }
+        free_raw(poff); free_raw(woff); free_raw(toff);
+        return 0;
+    }
     // LayerNorm folded into the following Linear: per-row (mean, rstd), then the GEMM on the raw tokens with
     // the correction in its epilogue (saves writing and re-reading the normalised token matrix)
     int ln_dense(const LnFold& f, const Tensor& x, int epi, Tensor* y) {
@@ -618,9 +651,12 @@ struct Fwd {
     int transformer_pre(const TfmW& t, const Tensor& x, Tensor* t1) {
         const int C = t.c, T = x.H * x.W, B = x.N;
         Tensor n, t0, ln, qkv, a;
-        DM_TRY(groupnorm(t.gn, x, nullptr, ATTN_GN_EPS, false, &n));
-        DM_TRY(dense(t.proj_in, n, nullptr, nullptr, EPI_PLAIN, &t0));
-        free(n);
+        if (gn_fold_ok(x, t.proj_in)) DM_TRY(gn_dense(t.gn, t.proj_in, x, ATTN_GN_EPS, &t0));
+        else {
+            DM_TRY(groupnorm(t.gn, x, nullptr, ATTN_GN_EPS, false, &n));
+            DM_TRY(dense(t.proj_in, n, nullptr, nullptr, EPI_PLAIN, &t0));
+            free(n);
+        }
         if (ln_fold_enabled()) DM_TRY(ln_dense(t.qkv_ln, t0, EPI_PLAIN, &qkv));
         else {
             DM_TRY(layernorm(t.ln1, t0, &ln));
@@ -1000,7 +1036,7 @@ int ensure_arena_for(dm_engine* e, hipStream_t s, const std::vector<long long>& 
 
 std::vector<long long> fwd_key(const FwdArgs& A) {
     return {0, A.B, A.H, A.W, A.n_cond, A.up_ft_index, A.add_noise ? 1 : 0, A.loss ? 1 : 0, A.pred ? 1 : 0, A.feat ? 1 : 0,
-            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL)};
+            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD)};
 }
 
 int ensure_arena(dm_engine* e, const FwdArgs& A, hipStream_t s) {
@@ -1084,7 +1120,7 @@ namespace {
 struct OptDef { const char* name; const char* env; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
-    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0},
+    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<int> g_opt_init{0};
@@ -1880,6 +1916,29 @@ int dm_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, 
     if (r == hipSuccess) r = launch_gn_apply((const f16*)X, (const f16*)X2, N, HW, C, C1, G, eps, gamma, beta, partial, silu, (f16*)Y, s);
     (void)hipStreamSynchronize(s);
     (void)hipFree(partial);
+    return r == hipSuccess ? 0 : 1;
+}
+
+int dm_op_groupnorm_conv1x1(void* stream, const void* X, int N, int HW, int C, int G, float eps, const float* gamma,
+                            const float* beta, const void* W, const void* bias, int Cout, void* Y) {
+    hipStream_t s = (hipStream_t)stream;
+    double* partial = nullptr; f16* wn = nullptr; float* tn = nullptr;
+    const int chunks = gn_stats_chunks(HW);
+    if (hipMalloc((void**)&partial, (size_t)N * chunks * G * 2 * sizeof(double)) != hipSuccess) return 1;
+    if (hipMalloc((void**)&wn, (size_t)N * Cout * C * sizeof(f16)) != hipSuccess) { (void)hipFree(partial); return 1; }
+    if (hipMalloc((void**)&tn, (size_t)N * Cout * sizeof(float)) != hipSuccess) { (void)hipFree(partial); (void)hipFree(wn); return 1; }
+    hipError_t r = launch_gn_stats((const f16*)X, nullptr, N, HW, C, C, G, partial, s);
+    if (r == hipSuccess) r = launch_gn_fold(partial, N, HW, C, G, eps, gamma, beta, (const f16*)W, (const f16*)bias, Cout, wn, tn, s);
+    if (r == hipSuccess) {
+        IGemmParams p;
+        p.X = (const f16*)X; p.X2 = nullptr; p.Wp = wn; p.bias = nullptr; p.temb = nullptr; p.res = nullptr; p.Y = (f16*)Y;
+        p.M = N * HW; p.Cout = Cout; p.Cin = C; p.C1 = C; p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M;
+        p.mode = IG_DENSE; p.epi = EPI_PLAIN; p.ldy = Cout; p.ldres = 0; p.temb_ld = 0;
+        p.ln_s = tn; p.ln_t = tn; p.w_sample_stride = (long long)Cout * C; p.rows_per_sample = HW;
+        r = launch_igemm(p, s);
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(partial); (void)hipFree(wn); (void)hipFree(tn);
     return r == hipSuccess ? 0 : 1;
 }
 

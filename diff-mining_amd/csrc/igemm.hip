@@ -33,6 +33,8 @@ hipError_t launch_igemm_pers(const IGemmParams& p, hipStream_t s);     // igemm_
 hipError_t launch_igemm_pers_ln(const IGemmParams& p, hipStream_t s);  // igemm_pers_ln.hip
 hipError_t launch_igemm_pers_partial(const IGemmParams& p, hipStream_t s);   // igemm_pers_part.hip (split-K units, fp32 partials)
 hipError_t launch_splitk_reduce(const IGemmParams& p, hipStream_t s);         // igemm_splitk.hip
+hipError_t launch_igemm_pers_ws(const IGemmParams& p, hipStream_t s);         // igemm_pers_ws.hip: per-sample weights (GroupNorm fold)
+hipError_t launch_igemm_tile_ws(const IGemmParams& p, hipStream_t s);         // igemm_ws.hip
 
 // Shape -> tile choice, measured per shape on one box with both arms interleaved (tools/ab_igemm.py, r02): the
 // persistent 256 x 320 tile (igemm_pers_tile.h: 13.8 instead of 21.9 LDS-DMA bytes per kMAC, no per-tile prologue, stores
@@ -176,6 +178,15 @@ hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
         if (!splitk_on_pers(p)) return launch_igemm_splitk(p, s);
         const hipError_t rc = launch_igemm_pers_partial(p, s);
         return rc != hipSuccess ? rc : launch_splitk_reduce(p, s);
+    }
+    if (p.w_sample_stride) {
+        // GroupNorm folded into a 1x1 convolution: per-sample weights.  The persistent tile when a sample is whole 256-row tiles
+        // and the launch has >= 2 rounds of them (or igemm_big forces it), else the 128-row tile; no head / tail cut (both give
+        // the same bits, so which one runs is a matter of time only)
+        const bool pers = p.Cout % 320 == 0 && p.rows_per_sample % 256 == 0 &&
+                          (option(OPT_IGEMM_BIG) >= 0 ? option(OPT_IGEMM_BIG) != 0
+                                                      : (long long)(p.M / 256) * (p.Cout / 320) >= 2LL * device_cu_count());
+        return pers ? launch_igemm_pers_ws(p, s) : launch_igemm_tile_ws(p, s);
     }
     if (p.ln_s) {
         if (!p.ln_t || p.Cout % 160 != 0 || p.mode != IG_DENSE || p.C1 != p.Cin) return hipErrorInvalidValue;

@@ -126,7 +126,11 @@ constexpr int EPI_PARTIAL = 2;
 
 // 8 waves (2 per SIMD), wave tile 64 px x 160 ch in two 80-channel halves, <= 256 registers.  (A 16-wave form of the
 // same block tile — 64 x 80 wave tiles, <= 128 registers — was measured 1-5 % slower in r02: DESIGN.md §4b.)
-template <int EPI, bool LN, int EXTRA>
+// WS (r03): per-SAMPLE weights and bias row — GroupNorm folded into a 1x1 convolution (IGemmParams::w_sample_stride): a tile
+// lies inside one sample n (rows_per_sample % 256 == 0), reads its weight rows at Wp + n * w_sample_stride and its fp32 bias
+// row at ln_t + n * Cout, and the epilogue is the folded-LayerNorm one with (mean, rstd) = (0, 1): y = fp16(acc + t).  A
+// compile-time variant in a translation unit of its own (igemm_pers_ws.hip): the other instantiations do not change by a byte.
+template <int EPI, bool LN, int EXTRA, bool WS = false>
 __global__ __launch_bounds__(512, 2)
 void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
     constexpr int WC = 2, CH = 2, NW = 8;
@@ -209,6 +213,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
         const int ln = hw_lane();
         const int lrow = ln >> 3, lchunk = ((ln & 7) ^ lrow) * 8;
         woff = (unsigned)((size_t)(lc0 + wid * 8 + lrow) * Ktot + lchunk) + (unsigned)(tap0 * p.Cin);
+        if constexpr (WS) woff += (unsigned)((long long)(lp0 / p.rows_per_sample) * p.w_sample_stride);
         ld_tap = tap0; ld_cc = 0;
 #pragma unroll
         for (int k = 0; k < XI; ++k) xpk[k] = pack_row(lp0 + (wid + k * NW) * 8 + lrow);
@@ -284,12 +289,13 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
             const char* s;
             if (part < 2) {
                 const float* v = (part == 0 ? p.ln_s : p.ln_t) + lc0;
+                if constexpr (WS) v = p.ln_t + (size_t)(lp0 / p.rows_per_sample) * p.Cout + lc0;     // the sample's bias row (also as the unused s)
                 const int f = half * 256 + lane * 4;
                 s = (f < TC) ? reinterpret_cast<const char*>(v + f) : zp;
             } else {
                 int row = lp0 + half * 128 + lane * 2;               // two (mean, rstd) pairs per lane
                 row = row < p.M - 1 ? row : p.M - 2;
-                s = p.ln_stats ? reinterpret_cast<const char*>(p.ln_stats + 2 * (size_t)row) : zp;     // in-kernel statistics: the slot is written after the k loop
+                s = (p.ln_stats && !WS) ? reinterpret_cast<const char*>(p.ln_stats + 2 * (size_t)row) : zp;     // in-kernel statistics: the slot is written after the k loop
             }
             __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(ax + AUX_LNS + (wid - 2) * 1024), 16, 0, 0);
         }
@@ -302,7 +308,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
     // VALU work in the shadow of the MFMAs — and after the k loop the pair is combined into (mean, rstd) in the tile's
     // vector slot.  The order depends on the row only, never on the tile geometry or the batch (igemm_tile.h adds the same
     // numbers in the same order).
-    const bool ln_ink = LN && p.ln_stats == nullptr;
+    const bool ln_ink = LN && !WS && p.ln_stats == nullptr;
     float ln_s1 = 0.f, ln_s2 = 0.f;
 
     // one k step on stage `cur`, with the LDS-DMA of the following k tile of the stream into the other stage interleaved
@@ -421,7 +427,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
                 // operations per value instead of mul / sub / mul / add (r03: 4 of ~37 VALU instructions per GEGLU quad), and one
                 // rounding less; the 128-row tile (igemm_tile.h) uses the same form
                 float nrm = 0.f, rs = 1.f;
-                if (LN) {
+                if (LN && !WS) {
                     const float2 st = *reinterpret_cast<const float2*>(ax + AUX_STATS + pr * 8);
                     rs = st.y; nrm = -(st.y * st.x);
                 }
@@ -623,6 +629,26 @@ static hipError_t launch_igemm_pers_t(const IGemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, LN, PX_NONE>), g, b, lds, s, p, ntiles, cset);
     return hipGetLastError();
 }
+
+// the per-sample-weights variant (GroupNorm folded into proj_in); only igemm_pers_ws.hip defines DM_IGEMM_PERS_WS
+#ifdef DM_IGEMM_PERS_WS
+static hipError_t launch_igemm_pers_ws_t(const IGemmParams& p, hipStream_t s) {
+    constexpr int TP = 256, TC = 320;
+    constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 2 * AUX_BYTES;
+    if (p.mode != IG_DENSE || p.epi != EPI_PLAIN || !p.ln_t || p.w_sample_stride <= 0 || p.rows_per_sample <= 0 ||
+        p.rows_per_sample % TP != 0 || p.M % p.rows_per_sample != 0 || p.Cout % TC != 0 || p.res || p.temb) return hipErrorInvalidValue;
+    const int ntiles = (p.M / TP) * (p.Cout / TC);
+    const int n_cu = device_cu_count();
+    const int grid = ntiles < n_cu ? ntiles : n_cu;
+    static std::atomic<uint64_t> attr_seen{0};
+    if (first_use_on_device(attr_seen))
+        (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, true, PX_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static std::atomic<unsigned> launch_no{0};
+    const int cset = (int)(launch_no.fetch_add(1) % CSETS);
+    hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, true, PX_NONE, true>), dim3(grid), dim3(512), lds, s, p, ntiles, cset);
+    return hipGetLastError();
+}
+#endif
 
 // split-K form: units = tiles * ksplit, fp32 partials (see EPI_PARTIAL); the caller runs the reduction afterwards
 static hipError_t launch_igemm_pers_partial_t(const IGemmParams& p, hipStream_t s) {

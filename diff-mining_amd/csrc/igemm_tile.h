@@ -167,7 +167,9 @@ __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int WC, int EPI, int NI, bool SPLIT = false, bool LN = false>
+// WS: per-sample weights and bias row (GroupNorm folded into a 1x1 convolution), the 128-row partner of igemm_pers_tile.h's WS
+// variant: the same arithmetic (y = fp16(acc + t), the folded-LayerNorm epilogue with (mean, rstd) = (0, 1)).
+template <int WC, int EPI, int NI, bool SPLIT = false, bool LN = false, bool WS = false>
 __global__ __launch_bounds__(128 * WC, 2)
 void igemm_kernel(IGemmParams p) {
     constexpr int WP = 2;
@@ -219,7 +221,8 @@ void igemm_kernel(IGemmParams p) {
     const f16* wsrc[WI];
 #pragma unroll
     for (int k = 0; k < WI; ++k)
-        wsrc[k] = p.Wp + (size_t)(c0out + (wid + k * NW) * 8 + lrow) * Ktot + lchunk + (SPLIT ? kt_begin * BK : 0);
+        wsrc[k] = p.Wp + (size_t)(c0out + (wid + k * NW) * 8 + lrow) * Ktot + lchunk + (SPLIT ? kt_begin * BK : 0) +
+                  (WS ? (size_t)(p0 / p.rows_per_sample) * (size_t)p.w_sample_stride : (size_t)0);
     int xn[XI], xoh[XI], xow[XI];
 #pragma unroll
     for (int k = 0; k < XI; ++k) {
@@ -317,18 +320,20 @@ void igemm_kernel(IGemmParams p) {
         if (p.bias) bv = *reinterpret_cast<const half4*>(p.bias + c0out + tid * 4);
         *reinterpret_cast<half4*>(smem + 2 * STAGE + tid * 8) = bv;
         if (LN) {      // ln_s, ln_t of the tile's channels (fp32) behind the 1 KB bias slot
-            *reinterpret_cast<floatx4*>(smem + 2 * STAGE + 1024 + tid * 16) = *reinterpret_cast<const floatx4*>(p.ln_s + c0out + tid * 4);
-            *reinterpret_cast<floatx4*>(smem + 2 * STAGE + 1024 + TC * 4 + tid * 16) = *reinterpret_cast<const floatx4*>(p.ln_t + c0out + tid * 4);
+            const float* lt = p.ln_t + (WS ? (size_t)(p0 / p.rows_per_sample) * p.Cout : (size_t)0);      // WS: the sample's bias row
+            *reinterpret_cast<floatx4*>(smem + 2 * STAGE + 1024 + tid * 16) = *reinterpret_cast<const floatx4*>((WS ? lt : p.ln_s) + c0out + tid * 4);
+            *reinterpret_cast<floatx4*>(smem + 2 * STAGE + 1024 + TC * 4 + tid * 16) = *reinterpret_cast<const floatx4*>(lt + c0out + tid * 4);
         }
     }
-    if (LN && p.ln_stats && tid < TP) {      // per-row (mean, rstd) of the tile's rows behind them
+    if (LN && WS && tid < TP) *reinterpret_cast<float2*>(smem + 2 * STAGE + 1024 + 8 * TC + tid * 8) = float2{0.f, 1.f};
+    if (LN && !WS && p.ln_stats && tid < TP) {      // per-row (mean, rstd) of the tile's rows behind them
         int m = p0 + tid;
         m = m < p.M ? m : p.M - 1;
         *reinterpret_cast<float2*>(smem + 2 * STAGE + 1024 + 8 * TC + tid * 8) = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (size_t)m);
     }
     // without a statistics kernel (p.ln_stats == nullptr): thread pair (2r, 2r + 1) accumulates row r of the tile from the k
     // loop's LDS tiles — the same numbers in the same order as igemm_pers_tile.h (bit-identical statistics)
-    const bool ln_ink = LN && p.ln_stats == nullptr && tid < 2 * TP;
+    const bool ln_ink = LN && !WS && p.ln_stats == nullptr && tid < 2 * TP;
     float ln_s1 = 0.f, ln_s2 = 0.f;
     prepare();
 #pragma unroll
@@ -395,7 +400,7 @@ void igemm_kernel(IGemmParams p) {
         }
         return;
     }
-    if (LN && p.ln_stats == nullptr) {
+    if (LN && !WS && p.ln_stats == nullptr) {
         const float t1 = ln_s1 + __shfl_xor(ln_s1, 1), t2 = ln_s2 + __shfl_xor(ln_s2, 1);
         const float mean = t1 / (float)p.Cin;
         float var = t2 / (float)p.Cin - mean * mean;
@@ -409,7 +414,7 @@ void igemm_kernel(IGemmParams p) {
 
 }  // namespace
 
-template <int WC, int NI, bool LN = false>
+template <int WC, int NI, bool LN = false, bool WS = false>
 static hipError_t launch_t(const IGemmParams& p, hipStream_t s) {
     constexpr int TP = 128, TC = 16 * NI * WC;
     constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 1024 + (LN ? 8 * TC + 8 * TP : 0);      // operand stages + bias (+ ln_s, ln_t, row stats)
@@ -418,13 +423,13 @@ static hipError_t launch_t(const IGemmParams& p, hipStream_t s) {
     dim3 grid(tiles_p * tiles_c), block(128 * WC);
     static std::atomic<uint64_t> attr_seen{0};      // hipFuncSetAttribute is per DEVICE, not per process
     if (first_use_on_device(attr_seen)) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_PLAIN, NI, false, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_GEGLU, NI, false, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_PLAIN, NI, false, LN, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_GEGLU, NI, false, LN, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     if (p.epi == EPI_GEGLU)
-        hipLaunchKernelGGL((igemm_kernel<WC, EPI_GEGLU, NI, false, LN>), grid, block, lds, s, p);
+        hipLaunchKernelGGL((igemm_kernel<WC, EPI_GEGLU, NI, false, LN, WS>), grid, block, lds, s, p);
     else
-        hipLaunchKernelGGL((igemm_kernel<WC, EPI_PLAIN, NI, false, LN>), grid, block, lds, s, p);
+        hipLaunchKernelGGL((igemm_kernel<WC, EPI_PLAIN, NI, false, LN, WS>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 

@@ -143,6 +143,82 @@ __global__ void gn_apply_kernel(const f16* __restrict__ X, const f16* __restrict
     }
 }
 
+
+// GroupNorm folded into the following 1x1 convolution (see launch_gn_fold in dm_kernels.h).  grid (Cout / ROWS, N), 256 threads.
+// Prologue = gn_apply_kernel's (the same reduction order: identical (mean, rstd)); then a[c], b[c] of the sample in LDS, and
+// per output row: the scaled weights (one rounding, like folding LayerNorm's gamma) and the fp32 bias row entry (wave-level
+// sum in a fixed order).
+constexpr int GNF_ROWS = 8;
+__global__ __launch_bounds__(256)
+void gn_fold_kernel(const double* __restrict__ partial, int chunks, int G, int C, double count, float eps,
+                    const float* __restrict__ gamma, const float* __restrict__ beta, const f16* __restrict__ W,
+                    const f16* __restrict__ bias, int Cout, f16* __restrict__ Wn, float* __restrict__ tn) {
+    __shared__ double sh_stat[2 * 64];
+    __shared__ double sh_part[2 * 256];
+    __shared__ float sh_a[2560], sh_b[2560];
+    __shared__ float sh_red[4][GNF_ROWS];
+    const int n = blockIdx.y, t = threadIdx.x;
+    {
+        const int S = 256 / G, g = t % G, sl = t / G;
+        double ds = 0.0, dq = 0.0;
+        if (sl < S) {
+            const double* in = partial + ((size_t)n * chunks * G + g) * 2;
+            for (int c = sl; c < chunks; c += S) { ds += in[(size_t)c * G * 2]; dq += in[(size_t)c * G * 2 + 1]; }
+            sh_part[2 * t] = ds; sh_part[2 * t + 1] = dq;
+        }
+        __syncthreads();
+        if (t < G) {
+            ds = 0.0; dq = 0.0;
+            for (int k = 0; k < S; ++k) { ds += sh_part[2 * (k * G + t)]; dq += sh_part[2 * (k * G + t) + 1]; }
+            const double mean = ds / count;
+            double var = dq / count - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            sh_stat[2 * t] = mean;
+            sh_stat[2 * t + 1] = 1.0 / sqrt(var + (double)eps);
+        }
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    for (int c = t; c < C; c += 256) {
+        const int g = c / cpg;
+        const double ad = sh_stat[2 * g + 1] * (double)gamma[c];
+        sh_a[c] = (float)ad;
+        sh_b[c] = (float)((double)beta[c] - sh_stat[2 * g] * ad);
+    }
+    __syncthreads();
+    const int o0 = blockIdx.x * GNF_ROWS;
+    const int lane = t & 63, wv = t >> 6;
+    float acc[GNF_ROWS];
+#pragma unroll
+    for (int r = 0; r < GNF_ROWS; ++r) acc[r] = 0.f;
+    for (int c8 = t * 8; c8 < C; c8 += 256 * 8) {
+#pragma unroll
+        for (int r = 0; r < GNF_ROWS; ++r) {
+            const int o = o0 + r;
+            if (o >= Cout) break;
+            const half8 w = *reinterpret_cast<const half8*>(W + (size_t)o * C + c8);
+            half8 wn;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float wf = (float)w[k];
+                wn[k] = (f16)(wf * sh_a[c8 + k]);
+                acc[r] = fmaf(wf, sh_b[c8 + k], acc[r]);
+            }
+            *reinterpret_cast<half8*>(Wn + ((size_t)n * Cout + o) * C + c8) = wn;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < GNF_ROWS; ++r) {
+        float v = acc[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) sh_red[wv][r] = v;
+    }
+    __syncthreads();
+    if (t < GNF_ROWS && o0 + t < Cout)
+        tn[(size_t)n * Cout + o0 + t] = ((sh_red[0][t] + sh_red[1][t]) + (sh_red[2][t] + sh_red[3][t])) + (bias ? (float)bias[o0 + t] : 0.f);
+}
+
 // LayerNorm: one wavefront per row, the row lives in registers (C <= 1280 -> <= 3 vectors/lane),
 // two-pass (mean, then centred variance) with wavefront xor-shuffles.
 template <int NV>
@@ -317,6 +393,14 @@ hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, in
     while (ppb > 8 && (long long)N * ((HW + ppb - 1) / ppb) < 2048) ppb >>= 1;
     hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + ppb - 1) / ppb, N), dim3(threads), 0, s, X, X2 ? X2 : X, HW, C, C1, R,
                        ppb, partial, gn_stats_chunks(HW), G, (double)HW * (double)(C / G), eps, gamma, beta, silu, Y);
+    return hipGetLastError();
+}
+
+hipError_t launch_gn_fold(const double* partial, int N, int HW, int C, int G, float eps, const float* gamma, const float* beta,
+                          const f16* W, const f16* bias, int Cout, f16* Wn, float* tn, hipStream_t s) {
+    if (C % 8 || C % G || C > 2560 || G > 64 || 256 % G) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_fold_kernel, dim3((Cout + GNF_ROWS - 1) / GNF_ROWS, N), dim3(256), 0, s, partial, gn_stats_chunks(HW), G, C,
+                       (double)HW * (double)(C / G), eps, gamma, beta, W, bias, Cout, Wn, tn);
     return hipGetLastError();
 }
 

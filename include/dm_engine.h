@@ -240,6 +240,8 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
  *     "attn_pipe" / "attn_cross" (pipelined / one-pass-softmax kernels vs the generic online-softmax kernel: different
  *     rescaling points), "ln_stats_g" (different lane order of the row reductions), "ln_inkernel" (0 / 1 / 2: LayerNorm
  *     statistics from a statistics kernel (two-pass) or inside the folded GEMM (one-pass fp32 sums; 1 = where cheaper));
+ *   "gn_fold" (1 / 0): Transformer2D.norm folded into proj_in at the 320- / 640-channel levels (per-sample weights; the rounding
+ *     moves from the normalised activations to the scaled weights) — numerically equivalent, not bit-identical to 0;
  *   "graph" (0 / 1): replay whole U-Net runs as captured hipGraphs (bit-identical: the same kernels with the same arguments);
  *   "igemm_exp": experimental kernel paths of the current round (0 = shipped). */
 int dm_set_option(const char* name, int value);
@@ -271,6 +273,11 @@ int dm_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, 
                     const float* gamma, const float* beta, int silu, void* Y);
 int dm_op_layernorm(void* stream, const void* X, int rows, int C, const float* gamma, const float* beta, float eps,
                     void* Y);
+/* GroupNorm(G, eps) (no activation) folded into the following 1x1 convolution W [Cout][C] + bias (Transformer2DModel.norm ->
+ * proj_in): statistics of X [N][HW][C], per-sample weights fp16(W diag(a_n)) and fp32 bias rows W b_n + bias, then the GEMM on
+ * the raw X — Y [N][HW][Cout] fp16.  HW must be a multiple of 128, C of 64, Cout of 160. */
+int dm_op_groupnorm_conv1x1(void* stream, const void* X, int N, int HW, int C, int G, float eps, const float* gamma,
+                            const float* beta, const void* W, const void* bias, int Cout, void* Y);
 
 #ifdef __cplusplus
 }

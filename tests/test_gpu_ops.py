@@ -796,3 +796,46 @@ def test_layernorm_statistics_inside_the_gemm(M, C, Cout, epi):
     print(f"in-GEMM LN statistics M={M} C={C} epi={epi}: rel-L2 vs fp32 {r:.2e}; outputs that differ from the statistics-kernel path: {frac:.2%}, "
           f"max |d| {diff.max().item():.2e}")
     assert frac < 0.05 and diff.max().item() <= 4e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("N,H,W,C,Cout", [(3, 16, 16, 320, 320), (2, 32, 32, 640, 640), (160, 64, 64, 320, 320), (5, 16, 8, 64, 160)])
+def test_groupnorm_folded_into_conv1x1(N, H, W, C, Cout):
+    """r03: `Transformer2DModel.norm` (GroupNorm 32, eps 1e-6, no activation) folded into `proj_in` (1x1 convolution): per-sample
+    weights fp16(W diag(a_n)) + fp32 bias rows, the GEMM on the raw tensor (dm_op_groupnorm_conv1x1) vs
+    F.conv2d(F.group_norm(x)) in fp32; and the persistent 256 x 320 tile against the 128-row tile: bit-identical."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    G = 32
+    g = torch.Generator().manual_seed(C + N)
+    x = (torch.randn(N, C, H, W, generator=g) * (1.0 + torch.rand(N, C, 1, 1, generator=g)) + torch.randn(N, C, 1, 1, generator=g)).half()
+    w = U.f16_randn(Cout, C, seed=2, scale=C ** -0.5)
+    b = U.f16_randn(Cout, seed=3, scale=0.1)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).float()
+    beta = (0.1 * torch.randn(C, generator=g)).float()
+    ref = F.conv2d(F.group_norm(x.float(), G, gamma, beta, 1e-6), w.float()[:, :, None, None], b.float())
+    xg = U.to_nhwc(x).to(d)
+    wg, bg, gg, be = w.to(d), b.to(d), gamma.to(d), beta.to(d)
+
+    def run():
+        y = torch.full((N, H, W, Cout), float("nan"), dtype=torch.float16, device=d)
+        assert lib.dm_op_groupnorm_conv1x1(U.stream(), U.ptr(xg), N, H * W, C, G, 1e-6, U.ptr(gg), U.ptr(be), U.ptr(wg), U.ptr(bg), Cout, U.ptr(y)) == 0
+        torch.cuda.synchronize()
+        return y
+    try:
+        lib.dm_set_option(b"igemm_big", 0)
+        y0 = run()
+        lib.dm_set_option(b"igemm_big", 1)
+        y1 = run() if (Cout % 320 == 0 and (H * W) % 256 == 0) else y0
+    finally:
+        lib.dm_set_option(b"igemm_big", -1)
+    ya = run()
+    assert not torch.isnan(y0.float()).any()
+    assert torch.equal(y0, y1) and torch.equal(ya, y0)
+    sel = slice(None) if N <= 8 else [0, N // 2, N - 1]
+    r, m = U.assert_close_fp16(U.to_nchw(y0[sel].cpu()), ref[sel], "GroupNorm folded into conv1x1", rel=3e-3, abs_frac=4e-3)
+    # the unfused pair (GroupNorm kernel -> fp16 -> igemm) on the same data, for scale
+    yn = U.op_groupnorm(xg, gg, be, G, 1e-6, False)
+    yu = U.op_igemm(yn, wg, bg)
+    r_u = U.rel_l2(U.to_nchw(yu[sel].cpu()), ref[sel])
+    print(f"GN folded into conv1x1 N={N} {H}x{W} C={C}: rel-L2 vs fp32 {r:.2e} (unfused pair: {r_u:.2e}), max|err|/max|ref| {m:.2e}")
