@@ -750,6 +750,9 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
     const int NC = A.n_cond > 1 ? A.n_cond : 1;
     const int U = B / NC;                 // distinct (x, t, eps) draws; every draw is scored under NC prompts
     F.slot_div = (NC > 1) ? U : 0;
+    // the persistent igemm kernel leaves its tile hand-out counters at zero — unless a launch faulted or was aborted; a run
+    // starts from a known state either way (1 KB, stream-ordered)
+    if (!dry && e->tile_ctr) DM_HIP(e, hipMemsetAsync(e->tile_ctr, 0, IGEMM_TILE_CTR_INTS * sizeof(int), s));
     // ---- time embedding: sinusoid row -> MLP -> SiLU -> all 22 time_emb_proj in one GEMM --------
     Tensor te0, e1, e1s, emb, embs, tprojU, tproj;
     DM_TRY(F.alloc(&te0, 1, 1, U, BOC[0]));
