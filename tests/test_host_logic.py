@@ -410,3 +410,11 @@ def test_persistent_tile_refuses_tensors_beyond_32_bit_offsets():
     assert lib.dm_op_igemm_tile(rows_ok - rows_ok % 256, 1280, 320, 0) == 1
     assert lib.dm_op_igemm_tile((1 << 31) // 1280 + 256, 1280, 320, 0) == 0
     assert lib.dm_op_igemm_head_rows((1 << 31) // 1280 + 256, 1, 1280, 320, 0) == 0
+
+
+def test_load_pipeline_dir_names_what_is_missing(tmp_path):
+    """`StableDiffusionPipeline.from_pretrained(model_path)` stand-in: a directory without unet safetensors is refused by path."""
+    from diff_mining_amd.engine import EngineError, UNetEngine
+    e = UNetEngine.__new__(UNetEngine)
+    with pytest.raises(EngineError, match="unet.*diffusion_pytorch_model.safetensors not found"):
+        e.load_pipeline_dir(str(tmp_path))
