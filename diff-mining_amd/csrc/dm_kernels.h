@@ -34,7 +34,7 @@ inline int device_cu_count() {
 
 // Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of
 // the same name in upper case with a DM_ prefix (DM_IGEMM_PERSIST=0 ...), changeable through dm_set_option().
-enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_COUNT };
+enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_COUNT };
 int option(Option o);                       // engine.hip
 int set_option(const char* name, int value);   // 0 on success
 
@@ -77,6 +77,12 @@ struct IGemmParams {
     // (= W b_n + bias), n = row / rows_per_sample; dense mode only, every tile inside one sample, epilogue y = fp16(acc + t)
     long long w_sample_stride = 0;
     int rows_per_sample = 0;
+    // ResNet shortcut folded into conv2 (r03): after the nine taps of the 3x3 convolution (source X, Cin channels) the k loop
+    // continues with Csc / 64 steps of a 1x1 convolution on a SECOND tensor pair cat([X3, X4]) (the block's input, C3 + (Csc - C3)
+    // channels, same spatial size) — weight rows are [9 * Cin | Csc], the bias is the sum of both.  mode IG_CONV3, no residual.
+    const f16* X3 = nullptr;
+    const f16* X4 = nullptr;
+    int C3 = 0, Csc = 0;
 };
 constexpr int IGEMM_TILE_CTR_INTS = 8 * 32 + 32;
 hipError_t launch_igemm(const IGemmParams& p, hipStream_t s);

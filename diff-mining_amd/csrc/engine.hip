@@ -48,9 +48,9 @@ struct HostTensor {
 };
 
 // packed device-side parameter handles (offsets into one weight slab, resolved to pointers)
-struct ConvW { const f16* w = nullptr; const f16* b = nullptr; int cin = 0, cout = 0, k = 0; };
+struct ConvW { const f16* w = nullptr; const f16* b = nullptr; int cin = 0, cout = 0, k = 0; int csc = 0; };   // csc: channels of a folded shortcut
 struct NormW { const float* g = nullptr; const float* b = nullptr; int c = 0; };
-struct ResW { NormW n1, n2; ConvW c1, c2, sc; bool has_sc = false; int temb_off = 0; int cin = 0, cout = 0; };
+struct ResW { NormW n1, n2; ConvW c1, c2, sc, c2sc; bool has_sc = false; int temb_off = 0; int cin = 0, cout = 0; };
 struct LnFold { ConvW w; const float* s = nullptr; const float* t = nullptr; };   // Linear with the preceding LayerNorm folded in
 struct TfmW {
     NormW gn, ln1, ln2, ln3;
@@ -401,6 +401,26 @@ int pack_resnet(Packer& P, const std::string& name, int cin, int cout, ResW* r, 
     DM_TRY(pack_conv3(P, name + ".conv2", cout, cout, &r->c2));
     r->has_sc = (cin != cout);
     if (r->has_sc) DM_TRY(pack_dense(P, name + ".conv_shortcut", cout, cin, true, true, &r->sc));
+    if (r->has_sc && cin % 64 == 0) {
+        // conv2 with the shortcut folded in (igemm_pers_tile.h, SC): weight rows [9 * cout (tap, c) | cin], bias = b2 + b_sc
+        HostTensor* w2 = P.get(name + ".conv2.weight", {cout, cout, 3, 3});
+        HostTensor* b2 = P.get(name + ".conv2.bias", {cout});
+        HostTensor* ws = P.get(name + ".conv_shortcut.weight", {cout, cin, 1, 1});
+        HostTensor* bs = P.get(name + ".conv_shortcut.bias", {cout});
+        if (!w2 || !b2 || !ws || !bs) return 1;
+        const size_t K = (size_t)9 * cout + cin;
+        std::vector<f16> pk((size_t)cout * K), pb(cout);
+        for (int co = 0; co < cout; ++co) {
+            for (int ci = 0; ci < cout; ++ci)
+                for (int tap = 0; tap < 9; ++tap)
+                    pk[(size_t)co * K + (size_t)tap * cout + ci] = w2->data[((size_t)co * cout + ci) * 9 + tap];
+            memcpy(pk.data() + (size_t)co * K + (size_t)9 * cout, ws->data.data() + (size_t)co * cin, (size_t)cin * 2);
+            pb[co] = (f16)((float)b2->data[co] + (float)bs->data[co]);
+        }
+        r->c2sc.w = as_ptr(P.put(pk.data(), pk.size() * 2));
+        r->c2sc.b = as_ptr(P.put(pb.data(), pb.size() * 2));
+        r->c2sc.cin = cout; r->c2sc.cout = cout; r->c2sc.k = 3; r->c2sc.csc = cin;
+    }
     return 0;
 }
 
@@ -446,6 +466,7 @@ void rebase_conv(ConvW& c, char* base) { rebase(c.w, base); rebase(c.b, base); }
 void rebase_norm(NormW& n, char* base) { rebase(n.g, base); rebase(n.b, base); }
 void rebase_res(ResW& r, char* base) {
     rebase_norm(r.n1, base); rebase_norm(r.n2, base); rebase_conv(r.c1, base); rebase_conv(r.c2, base); rebase_conv(r.sc, base);
+    rebase_conv(r.c2sc, base);
 }
 void rebase_tfm(TfmW& t, char* base) {
     rebase_norm(t.gn, base); rebase_norm(t.ln1, base); rebase_norm(t.ln2, base); rebase_norm(t.ln3, base);
@@ -500,7 +521,7 @@ struct Fwd {
     // Y = igemm(X [, X2]) with fused epilogue.  Output spatial dims given by (OH, OW).
     int igemm(const ConvW& cv, int mode, const Tensor& x, const Tensor* x2, int OH, int OW,
               const f16* temb, int temb_ld, const Tensor* res, int epi, Tensor* y, const LnFold* ln = nullptr,
-              const float* ln_stats = nullptr) {
+              const float* ln_stats = nullptr, const Tensor* x3 = nullptr, const Tensor* x4 = nullptr) {
         const int cin = x.C + (x2 ? x2->C : 0);
         if (cin != cv.cin) DM_FAIL(e, "igemm: channel mismatch %d vs %d", cin, cv.cin);
         const int cout_y = (epi == EPI_GEGLU) ? cv.cout / 2 : cv.cout;
@@ -515,9 +536,13 @@ struct Fwd {
         if (mode == IG_DENSE) { p.M = (int)x.rows(); p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M; }
         else { p.M = x.N * OH * OW; p.H = x.H; p.W = x.W; p.OH = OH; p.OW = OW; }
         if (ln) { p.ln_stats = ln_stats; p.ln_s = ln->s; p.ln_t = ln->t; p.ln_eps = LN_EPS; }
+        if (x3) {             // a ResNet block's conv_shortcut folded into this conv2: extra k steps on cat([x3, x4])
+            if (cv.csc != x3->C + (x4 ? x4->C : 0) || mode != IG_CONV3 || res || temb) DM_FAIL(e, "igemm: bad folded shortcut");
+            p.X3 = x3->p; p.X4 = x4 ? x4->p : nullptr; p.C3 = x3->C; p.Csc = cv.csc;
+        }
         p.tile_ctr = e->tile_ctr;
         // small-M layers: split-K through an fp32 workspace (also accounted for in the dry run)
-        const int parts = ln ? 1 : igemm_splitk_parts(p, OH * OW);
+        const int parts = (ln || x3) ? 1 : igemm_splitk_parts(p, OH * OW);
         size_t poff = (size_t)-1;
         if (parts > 1) {
             void* pp;
@@ -525,8 +550,8 @@ struct Fwd {
             p.ksplit = parts; p.partial = (float*)pp;
         }
         if (!dry) {
-            const double flops = 2.0 * (double)p.M * cv.cout * (double)((mode == IG_DENSE ? 1 : 9) * cin);
-            DM_TRY(prof_begin(0, flops, p.M, cv.cout, (mode == IG_DENSE ? 1 : 9) * cin, mode + 10 * epi));
+            const double flops = 2.0 * (double)p.M * cv.cout * (double)((mode == IG_DENSE ? 1 : 9) * cin + p.Csc);
+            DM_TRY(prof_begin(0, flops, p.M, cv.cout, (mode == IG_DENSE ? 1 : 9) * cin + p.Csc, mode + 10 * epi));
             DM_HIP(e, launch_igemm(p, s));
             DM_TRY(prof_end());
         }
@@ -621,6 +646,13 @@ struct Fwd {
         free(n1);
         DM_TRY(groupnorm(r.n2, h1, nullptr, res_eps, true, &n2));
         free(h1);
+        // conv_shortcut folded into conv2 (extra k steps on the block's input instead of a GEMM whose output conv2 reads back as its
+        // residual) wherever conv2 runs unsplit (more than 64 positions per sample: the split-K layers keep the pair)
+        if (r.has_sc && r.c2sc.w && option(OPT_SC_FOLD) && x.H * x.W > 64) {
+            DM_TRY(igemm(r.c2sc, IG_CONV3, n2, nullptr, x.H, x.W, nullptr, 0, nullptr, EPI_PLAIN, out, nullptr, nullptr, &x, x2));
+            free(n2);
+            return 0;
+        }
         const Tensor* resid = &x;
         if (r.has_sc) { DM_TRY(dense(r.sc, x, x2, nullptr, EPI_PLAIN, &sc)); resid = &sc; }
         else if (x2) DM_FAIL(e, "resnet: concat input without shortcut conv");
@@ -1039,7 +1071,7 @@ int ensure_arena_for(dm_engine* e, hipStream_t s, const std::vector<long long>& 
 
 std::vector<long long> fwd_key(const FwdArgs& A) {
     return {0, A.B, A.H, A.W, A.n_cond, A.up_ft_index, A.add_noise ? 1 : 0, A.loss ? 1 : 0, A.pred ? 1 : 0, A.feat ? 1 : 0,
-            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD)};
+            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD)};
 }
 
 int ensure_arena(dm_engine* e, const FwdArgs& A, hipStream_t s) {
@@ -1123,7 +1155,7 @@ namespace {
 struct OptDef { const char* name; const char* env; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
-    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1},
+    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<int> g_opt_init{0};
@@ -1920,6 +1952,16 @@ int dm_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, 
     (void)hipStreamSynchronize(s);
     (void)hipFree(partial);
     return r == hipSuccess ? 0 : 1;
+}
+
+int dm_op_igemm_shortcut(void* stream, const void* X, const void* X3, const void* X4, const void* Wp, const void* bias, void* Y,
+                         int N, int H, int W, int Cin, int C3, int C4, int Cout) {
+    IGemmParams p;
+    p.X = (const f16*)X; p.X2 = nullptr; p.Wp = (const f16*)Wp; p.bias = (const f16*)bias; p.temb = nullptr; p.res = nullptr;
+    p.Y = (f16*)Y; p.Cout = Cout; p.Cin = Cin; p.C1 = Cin; p.mode = IG_CONV3; p.epi = EPI_PLAIN;
+    p.ldy = Cout; p.ldres = 0; p.temb_ld = 0; p.M = N * H * W; p.H = H; p.W = W; p.OH = H; p.OW = W;
+    p.X3 = (const f16*)X3; p.X4 = (const f16*)X4; p.C3 = C3; p.Csc = C3 + C4;
+    return launch_igemm(p, (hipStream_t)stream) == hipSuccess ? 0 : 1;
 }
 
 int dm_op_groupnorm_conv1x1(void* stream, const void* X, int N, int HW, int C, int G, float eps, const float* gamma,

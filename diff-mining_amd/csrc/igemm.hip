@@ -35,6 +35,8 @@ hipError_t launch_igemm_pers_partial(const IGemmParams& p, hipStream_t s);   // 
 hipError_t launch_splitk_reduce(const IGemmParams& p, hipStream_t s);         // igemm_splitk.hip
 hipError_t launch_igemm_pers_ws(const IGemmParams& p, hipStream_t s);         // igemm_pers_ws.hip: per-sample weights (GroupNorm fold)
 hipError_t launch_igemm_tile_ws(const IGemmParams& p, hipStream_t s);         // igemm_ws.hip
+hipError_t launch_igemm_pers_sc(const IGemmParams& p, hipStream_t s);         // igemm_pers_sc.hip: conv_shortcut folded into conv2
+hipError_t launch_igemm_tile_sc(const IGemmParams& p, hipStream_t s);         // igemm_sc.hip
 
 // Shape -> tile choice, measured per shape on one box with both arms interleaved (tools/ab_igemm.py, r02): the
 // persistent 256 x 320 tile (igemm_pers_tile.h: 13.8 instead of 21.9 LDS-DMA bytes per kMAC, no per-tile prologue, stores
@@ -107,6 +109,8 @@ static IGemmParams row_range(const IGemmParams& p, int r0, int r1) {
         const size_t n0 = (size_t)r0 / ((size_t)p.OH * p.OW), src = (size_t)p.H * p.W;
         q.X = p.X + n0 * src * p.C1;
         if (p.X2) q.X2 = p.X2 + n0 * src * C2;
+        if (p.X3) q.X3 = p.X3 + n0 * src * p.C3;
+        if (p.X4) q.X4 = p.X4 + n0 * src * (p.Csc - p.C3);
         if (p.temb) q.temb = p.temb + n0 * p.temb_ld;
     }
     return q;
@@ -169,6 +173,7 @@ int igemm_head_rows(const IGemmParams& p) {
 }
 
 static hipError_t launch_small(const IGemmParams& p, hipStream_t s) {
+    if (p.X3) return launch_igemm_tile_sc(p, s);
     if (p.ln_s) return launch_igemm_tile_ln(p, s);
     return (p.Cout % 320 == 0) ? launch_t<4, 5>(p, s) : launch_t<2, 5>(p, s);
 }
@@ -198,7 +203,7 @@ hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
     const int head = head_rows(p);
     if (head <= 0) return launch_small(p, s);
     const IGemmParams h = head < p.M ? row_range(p, 0, head) : p;
-    const hipError_t rc = p.ln_s ? launch_igemm_pers_ln(h, s) : launch_igemm_pers(h, s);
+    const hipError_t rc = p.X3 ? launch_igemm_pers_sc(h, s) : p.ln_s ? launch_igemm_pers_ln(h, s) : launch_igemm_pers(h, s);
     if (rc != hipSuccess || head >= p.M) return rc;
     return launch_small(row_range(p, head, p.M), s);
 }

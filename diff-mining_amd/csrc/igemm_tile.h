@@ -169,7 +169,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // WS: per-sample weights and bias row (GroupNorm folded into a 1x1 convolution), the 128-row partner of igemm_pers_tile.h's WS
 // variant: the same arithmetic (y = fp16(acc + t), the folded-LayerNorm epilogue with (mean, rstd) = (0, 1)).
-template <int WC, int EPI, int NI, bool SPLIT = false, bool LN = false, bool WS = false>
+// SC: a ResNet block's conv_shortcut folded into its conv2 as extra k steps on a second tensor pair (igemm_pers_tile.h): the
+// same k order and arithmetic as the persistent tile's SC variant -> bit-identical tiles.
+template <int WC, int EPI, int NI, bool SPLIT = false, bool LN = false, bool WS = false, bool SC = false>
 __global__ __launch_bounds__(128 * WC, 2)
 void igemm_kernel(IGemmParams p) {
     constexpr int WP = 2;
@@ -209,10 +211,11 @@ void igemm_kernel(IGemmParams p) {
     const int C2 = p.Cin - C1;
     const int ntaps = (p.mode == IG_DENSE) ? 1 : 9;
     const int cpt = p.Cin / BK;
-    const int nk_all = ntaps * cpt;
+    const int cpt_sc = SC ? p.Csc / BK : 0;
+    const int nk_all = ntaps * cpt + cpt_sc;
     const int kt_begin = SPLIT ? split * (nk_all / p.ksplit) : 0;          // ksplit divides nk_all (launcher)
     const int nk = SPLIT ? nk_all / p.ksplit : nk_all;
-    const int Ktot = ntaps * p.Cin;
+    const int Ktot = ntaps * p.Cin + (SC ? p.Csc : 0);
     const int OHW = p.OH * p.OW;
 
     const int lrow = lane >> 3;
@@ -274,6 +277,21 @@ void igemm_kernel(IGemmParams p) {
     int ld_tap = SPLIT ? kt_begin / cpt : 0, ld_cc = SPLIT ? kt_begin % cpt : 0;
     bool first_prepare = true;
     auto prepare = [&]() {                                   // pointers for the next tile to load
+        if constexpr (SC) {
+            if (ld_tap == 9) {                               // the folded shortcut: centre tap on cat([X3, X4])
+                if (ld_cc == 0) {
+                    set_tap(4);
+#pragma unroll
+                    for (int k = 0; k < XI; ++k) if (xpix[k] >= 0) xsrc[k] = p.X3 + xpix[k] * p.C3 + lchunk;
+                } else if (ld_cc * BK == p.C3) {
+#pragma unroll
+                    for (int k = 0; k < XI; ++k) if (xpix[k] >= 0) xsrc[k] = p.X4 + xpix[k] * (p.Csc - p.C3) + lchunk;
+                }
+                first_prepare = false;
+                if (++ld_cc == cpt_sc) { ld_cc = 0; ++ld_tap; }
+                return;
+            }
+        }
         if (SPLIT && first_prepare && ld_cc != 0) {
             // a part may start in the middle of a tap: set the tap, then move to the right channel slab
             set_tap(ld_tap);
@@ -414,7 +432,7 @@ void igemm_kernel(IGemmParams p) {
 
 }  // namespace
 
-template <int WC, int NI, bool LN = false, bool WS = false>
+template <int WC, int NI, bool LN = false, bool WS = false, bool SC = false>
 static hipError_t launch_t(const IGemmParams& p, hipStream_t s) {
     constexpr int TP = 128, TC = 16 * NI * WC;
     constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 1024 + (LN ? 8 * TC + 8 * TP : 0);      // operand stages + bias (+ ln_s, ln_t, row stats)
@@ -423,13 +441,13 @@ static hipError_t launch_t(const IGemmParams& p, hipStream_t s) {
     dim3 grid(tiles_p * tiles_c), block(128 * WC);
     static std::atomic<uint64_t> attr_seen{0};      // hipFuncSetAttribute is per DEVICE, not per process
     if (first_use_on_device(attr_seen)) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_PLAIN, NI, false, LN, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_GEGLU, NI, false, LN, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_PLAIN, NI, false, LN, WS, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_GEGLU, NI, false, LN, WS, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     if (p.epi == EPI_GEGLU)
-        hipLaunchKernelGGL((igemm_kernel<WC, EPI_GEGLU, NI, false, LN, WS>), grid, block, lds, s, p);
+        hipLaunchKernelGGL((igemm_kernel<WC, EPI_GEGLU, NI, false, LN, WS, SC>), grid, block, lds, s, p);
     else
-        hipLaunchKernelGGL((igemm_kernel<WC, EPI_PLAIN, NI, false, LN, WS>), grid, block, lds, s, p);
+        hipLaunchKernelGGL((igemm_kernel<WC, EPI_PLAIN, NI, false, LN, WS, SC>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 

@@ -25,7 +25,7 @@ SYMBOLS = [
     "dm_engine_load_vae_weight", "dm_engine_finalize_vae", "dm_vae_encode", "dm_op_attention512", "dm_patch_embed",
     "dm_engine_load_clip_weight", "dm_engine_finalize_clip", "dm_clip_encode", "dm_op_igemm_splitk",
     "dm_op_ln_stats", "dm_op_igemm_ln", "dm_reduce_typicality_batched", "dm_op_igemm_tile", "dm_op_igemm_head_rows", "dm_set_option",
-    "dm_engine_reserve", "dm_engine_stats", "dm_op_groupnorm_conv1x1",
+    "dm_engine_reserve", "dm_engine_stats", "dm_op_groupnorm_conv1x1", "dm_op_igemm_shortcut",
 ]
 
 
@@ -88,6 +88,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_op_igemm_tile.argtypes = [i32, i32, i32, i32]
     lib.dm_set_option.argtypes = [C.c_char_p, i32]
     lib.dm_op_attention512.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float]
+    if hasattr(lib, "dm_op_igemm_shortcut"):
+        lib.dm_op_igemm_shortcut.argtypes = [vp] * 7 + [i32] * 7
     if hasattr(lib, "dm_op_groupnorm_conv1x1"):
         lib.dm_op_groupnorm_conv1x1.argtypes = [vp, vp, i32, i32, i32, i32, C.c_float, vp, vp, vp, vp, i32, vp]
     if hasattr(lib, "dm_engine_reserve"):        # absent only from older A/B libraries loaded through DM_ENGINE_LIB

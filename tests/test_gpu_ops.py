@@ -839,3 +839,55 @@ def test_groupnorm_folded_into_conv1x1(N, H, W, C, Cout):
     yu = U.op_igemm(yn, wg, bg)
     r_u = U.rel_l2(U.to_nchw(yu[sel].cpu()), ref[sel])
     print(f"GN folded into conv1x1 N={N} {H}x{W} C={C}: rel-L2 vs fp32 {r:.2e} (unfused pair: {r_u:.2e}), max|err|/max|ref| {m:.2e}")
+
+
+@pytest.mark.parametrize("N,H,W,C3,C4,Cout", [(2, 9, 7, 128, 64, 320), (160, 32, 32, 1280, 640, 640), (161, 16, 16, 640, 0, 1280), (3, 16, 16, 320, 0, 640)])
+def test_conv_shortcut_folded_into_conv2(N, H, W, C3, C4, Cout):
+    """r03: `ResnetBlock2D` output = conv_shortcut(x) + conv2(h), with the 1x1 shortcut on the (possibly concatenated) block
+    input folded into conv2's k loop (dm_op_igemm_shortcut: weight rows [9 * Cout (tap, c) | C3 + C4], bias = b2 + b_sc), against
+    F.conv2d + F.conv2d in fp32 on sampled images; the persistent 256 x 320 tile against the 128-row tile: bit-identical (ragged
+    last tile included); and against the unfused pair (shortcut GEMM -> fp16 -> residual of conv2)."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    g = torch.Generator(device="cuda").manual_seed(5)
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g, device=d, dtype=torch.float32) * scale).half()
+    Cin = Cout                                          # conv2: Cout -> Cout
+    h = rnd(N, H, W, Cin)
+    x3 = rnd(N, H, W, C3)
+    x4 = rnd(N, H, W, C4, scale=0.5) if C4 else None
+    w2 = U.f16_randn(Cout, Cin, 3, 3, seed=6, scale=(9 * Cin) ** -0.5)
+    ws = U.f16_randn(Cout, C3 + C4, seed=7, scale=(C3 + C4) ** -0.5)
+    b2, bs = U.f16_randn(Cout, seed=8, scale=0.1), U.f16_randn(Cout, seed=9, scale=0.1)
+    wp = torch.cat([U.pack_conv3(w2), ws], dim=1).contiguous().to(d)
+    bias = (b2.float() + bs.float()).half().to(d)
+
+    def run():
+        y = torch.full((N, H, W, Cout), float("nan"), dtype=torch.float16, device=d)
+        assert lib.dm_op_igemm_shortcut(U.stream(), U.ptr(h), U.ptr(x3), U.ptr(x4), U.ptr(wp), U.ptr(bias), U.ptr(y), N, H, W, Cin, C3, C4, Cout) == 0
+        torch.cuda.synchronize()
+        return y
+    try:
+        lib.dm_set_option(b"igemm_big", 0)
+        y0 = run()
+        lib.dm_set_option(b"igemm_big", 1)
+        y1 = run() if Cout % 320 == 0 else y0
+    finally:
+        lib.dm_set_option(b"igemm_big", -1)
+    ya = run()
+    assert not torch.isnan(y0.float()).any()
+    assert torch.equal(y0, y1) and torch.equal(ya, y0)
+    for n in sorted({0, N // 2, N - 1}):
+        xin = x3[n:n + 1] if x4 is None else torch.cat([x3[n:n + 1], x4[n:n + 1]], 3)
+        ref = F.conv2d(U.to_nchw(h[n:n + 1].cpu().float()), w2.float(), b2.float(), padding=1) + \
+            F.conv2d(U.to_nchw(xin.cpu().float()), ws.float()[:, :, None, None], bs.float())
+        r, m = U.assert_close_fp16(U.to_nchw(y0[n:n + 1].cpu()), ref, f"conv2 + folded shortcut n={n}")
+    # the unfused pair on the same data
+    sc = U.op_igemm(x3, ws.to(d), bs.to(d), X2=x4, mode=0)
+    yu = U.op_igemm(h, U.pack_conv3(w2).to(d), b2.to(d), res=sc, mode=1)
+    diff = (yu.float() - y0.float()).abs()
+    print(f"conv2 + folded shortcut N={N} {H}x{W} {C3}+{C4}->{Cout}: rel-L2 vs fp32 {r:.2e}; vs the unfused pair: {(diff > 0).float().mean().item():.1%} of the outputs differ, "
+          f"max |d| {diff.max().item():.2e}")
+    assert diff.max().item() <= 4e-3 * y0.float().abs().max().item()
