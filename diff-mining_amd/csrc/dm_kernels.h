@@ -34,7 +34,7 @@ inline int device_cu_count() {
 
 // Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of
 // the same name in upper case with a DM_ prefix (DM_IGEMM_PERSIST=0 ...), changeable through dm_set_option().
-enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_COUNT };
+enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_COUNT };
 int option(Option o);                       // engine.hip
 int set_option(const char* name, int value);   // 0 on success
 

@@ -55,6 +55,8 @@ struct LnFold { ConvW w; const float* s = nullptr; const float* t = nullptr; }; 
 struct TfmW {
     NormW gn, ln1, ln2, ln3;
     ConvW proj_in, proj_out, qkv, o1, q2, kv2, o2, ff1, ff2;
+    ConvW ffp;                          // ff.net.2 + residual + proj_out as ONE GEMM: rows [(Wp W2)[o][:4C] | Wp[o][:C]], bias Wp b2 + bp
+    size_t w2t_off = 0;                 // (finalize) W2^T [4C][C] in the blob: the operand the product Wp W2 is computed from on the GPU
     LnFold qkv_ln, q2_ln, ff1_ln;       // LN1 -> to_q/k/v, LN2 -> to_q (cross), LN3 -> GEGLU projection
     int c = 0; int layer = 0;
 };
@@ -452,6 +454,31 @@ int pack_tfm(Packer& P, const std::string& name, int c, TfmW* t, dm_engine* e) {
     DM_TRY(pack_geglu(P, b + ".ff.net.0.proj", c, &t->ff1));
     DM_TRY(pack_dense(P, b + ".ff.net.2", c, 4 * c, false, true, &t->ff2));
     DM_TRY(pack_dense(P, name + ".proj_out", c, c, true, true, &t->proj_out));
+    {
+        // ff.net.2 -> (+ residual) -> proj_out is a linear chain: out = Wp (W2 f + b2 + t2) + bp + x = (Wp W2) f + Wp t2 + (Wp b2 + bp) + x.
+        // One GEMM over [f | t2] with weight rows [(Wp W2)[o] | Wp[o]] (igemm SC variant, dense mode).  The product is formed on
+        // the GPU at finalize from W2^T (fp32 accumulation, one rounding to fp16); here: W2^T, Wp's columns, the bias.
+        HostTensor* w2 = P.get(b + ".ff.net.2.weight", {c, 4 * c});
+        HostTensor* b2 = P.get(b + ".ff.net.2.bias", {c});
+        HostTensor* wp = P.get(name + ".proj_out.weight", {c, c, 1, 1});
+        HostTensor* bp = P.get(name + ".proj_out.bias", {c});
+        if (!w2 || !b2 || !wp || !bp) return 1;
+        std::vector<f16> w2t((size_t)4 * c * c);
+        for (int o = 0; o < c; ++o)
+            for (int j = 0; j < 4 * c; ++j) w2t[(size_t)j * c + o] = w2->data[(size_t)o * 4 * c + j];
+        t->w2t_off = P.put(w2t.data(), w2t.size() * 2);
+        const size_t K = (size_t)5 * c;
+        std::vector<f16> pk((size_t)c * K, (f16)0.f), pb(c);
+        for (int o = 0; o < c; ++o) {
+            memcpy(pk.data() + (size_t)o * K + (size_t)4 * c, wp->data.data() + (size_t)o * c, (size_t)c * 2);
+            double acc = (double)(float)bp->data[o];
+            for (int k = 0; k < c; ++k) acc += (double)(float)wp->data[(size_t)o * c + k] * (double)(float)b2->data[k];
+            pb[o] = (f16)(float)acc;
+        }
+        t->ffp.w = as_ptr(P.put(pk.data(), pk.size() * 2));
+        t->ffp.b = as_ptr(P.put(pb.data(), pb.size() * 2));
+        t->ffp.cin = 4 * c; t->ffp.cout = c; t->ffp.k = 1; t->ffp.csc = c;
+    }
     // the three LayerNorm -> Linear pairs, folded (the unfused weights above stay for DM_LN_FOLD=0)
     DM_TRY(pack_ln_fold(P, b + ".norm1", {b + ".attn1.to_q", b + ".attn1.to_k", b + ".attn1.to_v"}, c, c, "", false, &t->qkv_ln));
     DM_TRY(pack_ln_fold(P, b + ".norm2", {b + ".attn2.to_q"}, c, c, "", false, &t->q2_ln));
@@ -472,6 +499,7 @@ void rebase_tfm(TfmW& t, char* base) {
     rebase_norm(t.gn, base); rebase_norm(t.ln1, base); rebase_norm(t.ln2, base); rebase_norm(t.ln3, base);
     rebase_conv(t.proj_in, base); rebase_conv(t.proj_out, base); rebase_conv(t.qkv, base); rebase_conv(t.o1, base);
     rebase_conv(t.q2, base); rebase_conv(t.kv2, base); rebase_conv(t.o2, base); rebase_conv(t.ff1, base); rebase_conv(t.ff2, base);
+    rebase_conv(t.ffp, base);
     for (LnFold* f : {&t.qkv_ln, &t.q2_ln, &t.ff1_ln}) { rebase_conv(f->w, base); rebase(f->s, base); rebase(f->t, base); }
 }
 
@@ -537,7 +565,7 @@ struct Fwd {
         else { p.M = x.N * OH * OW; p.H = x.H; p.W = x.W; p.OH = OH; p.OW = OW; }
         if (ln) { p.ln_stats = ln_stats; p.ln_s = ln->s; p.ln_t = ln->t; p.ln_eps = LN_EPS; }
         if (x3) {             // a ResNet block's conv_shortcut folded into this conv2: extra k steps on cat([x3, x4])
-            if (cv.csc != x3->C + (x4 ? x4->C : 0) || mode != IG_CONV3 || res || temb) DM_FAIL(e, "igemm: bad folded shortcut");
+            if (cv.csc != x3->C + (x4 ? x4->C : 0) || (mode != IG_CONV3 && mode != IG_DENSE) || temb) DM_FAIL(e, "igemm: bad folded second GEMM");
             p.X3 = x3->p; p.X4 = x4 ? x4->p : nullptr; p.C3 = x3->C; p.Csc = cv.csc;
         }
         p.tile_ctr = e->tile_ctr;
@@ -736,6 +764,12 @@ struct Fwd {
             DM_TRY(layernorm(t.ln3, t2, &ln));
             DM_TRY(dense(t.ff1, ln, nullptr, nullptr, EPI_GEGLU, &ff));
             free(ln);
+        }
+        if (option(OPT_FF_FOLD) && t.ffp.w) {
+            // ff.net.2 + residual + proj_out as one GEMM over [ff | t2] (+ x): the [tokens x C] intermediate is never written or read
+            DM_TRY(igemm(t.ffp, IG_DENSE, ff, nullptr, x.H, x.W, nullptr, 0, &x, EPI_PLAIN, out, nullptr, nullptr, &t2, nullptr));
+            free(ff); free(t2);
+            return 0;
         }
         DM_TRY(dense(t.ff2, ff, nullptr, &t2, EPI_PLAIN, &t3));
         free(ff); free(t2);
@@ -1071,7 +1105,7 @@ int ensure_arena_for(dm_engine* e, hipStream_t s, const std::vector<long long>& 
 
 std::vector<long long> fwd_key(const FwdArgs& A) {
     return {0, A.B, A.H, A.W, A.n_cond, A.up_ft_index, A.add_noise ? 1 : 0, A.loss ? 1 : 0, A.pred ? 1 : 0, A.feat ? 1 : 0,
-            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD)};
+            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD), option(OPT_FF_FOLD)};
 }
 
 int ensure_arena(dm_engine* e, const FwdArgs& A, hipStream_t s) {
@@ -1155,7 +1189,7 @@ namespace {
 struct OptDef { const char* name; const char* env; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
-    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1},
+    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<int> g_opt_init{0};
@@ -1346,6 +1380,15 @@ int dm_engine_finalize(dm_engine* e) {
         rebase_conv(e->up[i].up, base);
     }
     rebase_res(e->mid_res[0], base); rebase_res(e->mid_res[1], base); rebase_tfm(e->mid_tf, base);
+    // (Wp W2) of every transformer block into the first 4C columns of its fused rows: Y[o][j] = sum_c Wp[o][c] W2^T[j][c]
+    for (TfmW* t : e->tfs) {
+        IGemmParams p;
+        p.X = t->proj_out.w; p.X2 = nullptr; p.Wp = reinterpret_cast<const f16*>(base + t->w2t_off); p.bias = nullptr; p.temb = nullptr;
+        p.res = nullptr; p.Y = const_cast<f16*>(t->ffp.w); p.M = t->c; p.Cout = 4 * t->c; p.Cin = t->c; p.C1 = t->c;
+        p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M; p.mode = IG_DENSE; p.epi = EPI_PLAIN; p.ldy = 5 * t->c; p.ldres = 0; p.temb_ld = 0;
+        DM_HIP(e, launch_igemm(p, nullptr));
+    }
+    DM_HIP(e, hipDeviceSynchronize());
     e->host.clear();
 
     // scheduler + sinusoid tables
@@ -1954,12 +1997,14 @@ int dm_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, 
     return r == hipSuccess ? 0 : 1;
 }
 
-int dm_op_igemm_shortcut(void* stream, const void* X, const void* X3, const void* X4, const void* Wp, const void* bias, void* Y,
-                         int N, int H, int W, int Cin, int C3, int C4, int Cout) {
+int dm_op_igemm_shortcut(void* stream, const void* X, const void* X3, const void* X4, const void* Wp, const void* bias, const void* res,
+                         void* Y, int N, int H, int W, int Cin, int C3, int C4, int Cout, int mode) {
+    if (mode != IG_CONV3 && mode != IG_DENSE) return 1;
     IGemmParams p;
-    p.X = (const f16*)X; p.X2 = nullptr; p.Wp = (const f16*)Wp; p.bias = (const f16*)bias; p.temb = nullptr; p.res = nullptr;
-    p.Y = (f16*)Y; p.Cout = Cout; p.Cin = Cin; p.C1 = Cin; p.mode = IG_CONV3; p.epi = EPI_PLAIN;
-    p.ldy = Cout; p.ldres = 0; p.temb_ld = 0; p.M = N * H * W; p.H = H; p.W = W; p.OH = H; p.OW = W;
+    p.X = (const f16*)X; p.X2 = nullptr; p.Wp = (const f16*)Wp; p.bias = (const f16*)bias; p.temb = nullptr; p.res = (const f16*)res;
+    p.Y = (f16*)Y; p.Cout = Cout; p.Cin = Cin; p.C1 = Cin; p.mode = mode; p.epi = EPI_PLAIN;
+    p.ldy = Cout; p.ldres = Cout; p.temb_ld = 0; p.M = N * H * W;
+    if (mode == IG_DENSE) { p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M; } else { p.H = H; p.W = W; p.OH = H; p.OW = W; }
     p.X3 = (const f16*)X3; p.X4 = (const f16*)X4; p.C3 = C3; p.Csc = C3 + C4;
     return launch_igemm(p, (hipStream_t)stream) == hipSuccess ? 0 : 1;
 }

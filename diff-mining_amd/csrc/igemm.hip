@@ -104,6 +104,8 @@ static IGemmParams row_range(const IGemmParams& p, int r0, int r1) {
     if (p.mode == IG_DENSE) {
         q.X = p.X + (size_t)r0 * p.C1;
         if (p.X2) q.X2 = p.X2 + (size_t)r0 * C2;
+        if (p.X3) q.X3 = p.X3 + (size_t)r0 * p.C3;
+        if (p.X4) q.X4 = p.X4 + (size_t)r0 * (p.Csc - p.C3);
         q.W = q.OW = q.M;
     } else {
         const size_t n0 = (size_t)r0 / ((size_t)p.OH * p.OW), src = (size_t)p.H * p.W;

@@ -130,9 +130,10 @@ constexpr int EPI_PARTIAL = 2;
 // lies inside one sample n (rows_per_sample % 256 == 0), reads its weight rows at Wp + n * w_sample_stride and its fp32 bias
 // row at ln_t + n * Cout, and the epilogue is the folded-LayerNorm one with (mean, rstd) = (0, 1): y = fp16(acc + t).  A
 // compile-time variant in a translation unit of its own (igemm_pers_ws.hip): the other instantiations do not change by a byte.
-// SC (r03): `conv_shortcut` of a ResNet block folded into its conv2 — the k loop runs the nine taps of the 3x3 convolution on
-// X and then Csc / 64 more steps of a 1x1 convolution on cat([X3, X4]) (IGemmParams::X3): the shortcut tensor is never written
-// or read back as a residual, its MACs run at the convolution's rate, and the sum is rounded once.  Template variant in a
+// SC (r03): a second GEMM on another tensor folded into the k loop — after its own taps on X the loop runs Csc / 64 more steps of a
+// 1x1 convolution on cat([X3, X4]) (IGemmParams::X3).  Two users: a ResNet block's `conv_shortcut` inside its conv2 (the shortcut
+// tensor is never written or read back as a residual, its MACs run at the convolution's rate, the sum is rounded once), and the
+// transformer blocks' `ff.net.2` + residual + `proj_out` chain as one GEMM (dense mode: (Wp W2) ff + Wp t2 + x).  Template variant in a
 // translation unit of its own (igemm_pers_sc.hip).
 template <int EPI, bool LN, int EXTRA, bool WS = false, bool SC = false>
 __global__ __launch_bounds__(512, 2)
@@ -257,9 +258,10 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
     };
     auto prepare = [&]() __attribute__((always_inline)) {    // sources of the next k tile to load
         if constexpr (SC) {
-            if (ld_tap == 9) {                               // the shortcut: centre tap on the block's input (two concat sources)
-                if (ld_cc == 0) { xbase = p.X3; set_src(4, p.C3); }
-                else if (ld_cc * BK == p.C3) { xbase = p.X4; set_src(4, p.Csc - p.C3); }
+            if (ld_tap == ntaps) {                           // the folded second GEMM: centre tap (dense: the row itself) on cat([X3, X4])
+                const int ctap = (p.mode == IG_DENSE) ? 0 : 4;
+                if (ld_cc == 0) { xbase = p.X3; set_src(ctap, p.C3); }
+                else if (ld_cc * BK == p.C3) { xbase = p.X4; set_src(ctap, p.Csc - p.C3); }
                 if (++ld_cc == cpt_sc) { ld_cc = 0; ++ld_tap; }
                 return;
             }
@@ -648,17 +650,20 @@ static hipError_t launch_igemm_pers_t(const IGemmParams& p, hipStream_t s) {
 static hipError_t launch_igemm_pers_sc_t(const IGemmParams& p, hipStream_t s) {
     constexpr int TP = 256, TC = 320;
     constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 2 * AUX_BYTES;
-    if (p.mode != IG_CONV3 || p.epi != EPI_PLAIN || p.ln_s || p.res || p.temb || p.X2 || !p.X3 || p.Csc <= 0 || p.Csc % BK || p.C3 % BK ||
-        (p.C3 < p.Csc && !p.X4) || p.Cout % TC != 0 || p.ksplit > 1) return hipErrorInvalidValue;
+    if ((p.mode != IG_CONV3 && p.mode != IG_DENSE) || p.epi != EPI_PLAIN || p.ln_s || p.temb || p.X2 || !p.X3 || p.Csc <= 0 || p.Csc % BK ||
+        p.C3 % BK || (p.C3 < p.Csc && !p.X4) || p.Cout % TC != 0 || p.ksplit > 1) return hipErrorInvalidValue;
     const int ntiles = ((p.M + TP - 1) / TP) * (p.Cout / TC);
     const int n_cu = device_cu_count();
     const int grid = ntiles < n_cu ? ntiles : n_cu;
     static std::atomic<uint64_t> attr_seen{0};
-    if (first_use_on_device(attr_seen))
+    if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, false, PX_NONE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, false, PX_RES, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     static std::atomic<unsigned> launch_no{0};
     const int cset = (int)(launch_no.fetch_add(1) % CSETS);
-    hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_NONE, false, true>), dim3(grid), dim3(512), lds, s, p, ntiles, cset);
+    if (p.res) hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_RES, false, true>), dim3(grid), dim3(512), lds, s, p, ntiles, cset);
+    else hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_NONE, false, true>), dim3(grid), dim3(512), lds, s, p, ntiles, cset);
     return hipGetLastError();
 }
 #endif

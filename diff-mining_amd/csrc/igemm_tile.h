@@ -278,9 +278,9 @@ void igemm_kernel(IGemmParams p) {
     bool first_prepare = true;
     auto prepare = [&]() {                                   // pointers for the next tile to load
         if constexpr (SC) {
-            if (ld_tap == 9) {                               // the folded shortcut: centre tap on cat([X3, X4])
+            if (ld_tap == ntaps) {                           // the folded second GEMM: centre tap (dense: the row) on cat([X3, X4])
                 if (ld_cc == 0) {
-                    set_tap(4);
+                    set_tap(p.mode == IG_DENSE ? 0 : 4);
 #pragma unroll
                     for (int k = 0; k < XI; ++k) if (xpix[k] >= 0) xsrc[k] = p.X3 + xpix[k] * p.C3 + lchunk;
                 } else if (ld_cc * BK == p.C3) {

@@ -89,7 +89,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_set_option.argtypes = [C.c_char_p, i32]
     lib.dm_op_attention512.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float]
     if hasattr(lib, "dm_op_igemm_shortcut"):
-        lib.dm_op_igemm_shortcut.argtypes = [vp] * 7 + [i32] * 7
+        lib.dm_op_igemm_shortcut.argtypes = [vp] * 8 + [i32] * 8
     if hasattr(lib, "dm_op_groupnorm_conv1x1"):
         lib.dm_op_groupnorm_conv1x1.argtypes = [vp, vp, i32, i32, i32, i32, C.c_float, vp, vp, vp, vp, i32, vp]
     if hasattr(lib, "dm_engine_reserve"):        # absent only from older A/B libraries loaded through DM_ENGINE_LIB

@@ -244,6 +244,8 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
  *     moves from the normalised activations to the scaled weights) — numerically equivalent, not bit-identical to 0;
  *   "sc_fold" (1 / 0): the ResNet blocks' conv_shortcut folded into conv2 as extra k steps wherever conv2 runs unsplit (one
  *     rounding of the sum instead of three) — numerically equivalent, not bit-identical to 0;
+ *   "ff_fold" (1 / 0): ff.net.2 + residual + proj_out of a transformer block as one GEMM with the pre-multiplied weights Wp W2
+ *     (the [tokens x C] intermediate and its fp16 rounding disappear) — numerically equivalent, not bit-identical to 0;
  *   "graph" (0 / 1): replay whole U-Net runs as captured hipGraphs (bit-identical: the same kernels with the same arguments);
  *   "igemm_exp": experimental kernel paths of the current round (0 = shipped). */
 int dm_set_option(const char* name, int value);
@@ -275,11 +277,13 @@ int dm_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, 
                     const float* gamma, const float* beta, int silu, void* Y);
 int dm_op_layernorm(void* stream, const void* X, int rows, int C, const float* gamma, const float* beta, float eps,
                     void* Y);
-/* A ResNet block's conv2 with its conv_shortcut folded in (ResnetBlock2D: out = conv_shortcut(x) + conv2(h)): after the nine taps on
- * X [N,H,W,Cin] the k loop runs a 1x1 convolution on cat([X3 (C3 channels), X4 (C4 channels)]) (same N, H, W).  Wp [Cout][9*Cin + C3 + C4]:
- * conv2's row (k = (tap, cin)) followed by the shortcut's row; bias = the sum of both.  Cout % 160 == 0, Cin, C3, C4 multiples of 64. */
-int dm_op_igemm_shortcut(void* stream, const void* X, const void* X3, const void* X4, const void* Wp, const void* bias, void* Y,
-                         int N, int H, int W, int Cin, int C3, int C4, int Cout);
+/* A GEMM with a second GEMM on another tensor folded into its k loop: after its own taps on X [N,H,W,Cin] (mode 1: 3x3 stride 1;
+ * mode 0: dense) the loop runs a 1x1 convolution on cat([X3 (C3 channels), X4 (C4 channels)]) (same N, H, W).  Wp [Cout][taps*Cin + C3 + C4]:
+ * the first GEMM's row (k = (tap, cin)) followed by the second's; bias = the sum of both; res = optional residual [M][Cout].
+ * Used for ResnetBlock2D (out = conv_shortcut(x) + conv2(h)) and for ff.net.2 + residual + proj_out as one GEMM
+ * ((Wp W2) f + Wp t2 + x).  Cout % 160 == 0; Cin, C3, C4 multiples of 64. */
+int dm_op_igemm_shortcut(void* stream, const void* X, const void* X3, const void* X4, const void* Wp, const void* bias, const void* res,
+                         void* Y, int N, int H, int W, int Cin, int C3, int C4, int Cout, int mode);
 /* GroupNorm(G, eps) (no activation) folded into the following 1x1 convolution W [Cout][C] + bias (Transformer2DModel.norm ->
  * proj_in): statistics of X [N][HW][C], per-sample weights fp16(W diag(a_n)) and fp32 bias rows W b_n + bias, then the GEMM on
  * the raw X — Y [N][HW][Cout] fp16.  HW must be a multiple of 128, C of 64, Cout of 160. */

@@ -866,7 +866,7 @@ def test_conv_shortcut_folded_into_conv2(N, H, W, C3, C4, Cout):
 
     def run():
         y = torch.full((N, H, W, Cout), float("nan"), dtype=torch.float16, device=d)
-        assert lib.dm_op_igemm_shortcut(U.stream(), U.ptr(h), U.ptr(x3), U.ptr(x4), U.ptr(wp), U.ptr(bias), U.ptr(y), N, H, W, Cin, C3, C4, Cout) == 0
+        assert lib.dm_op_igemm_shortcut(U.stream(), U.ptr(h), U.ptr(x3), U.ptr(x4), U.ptr(wp), U.ptr(bias), None, U.ptr(y), N, H, W, Cin, C3, C4, Cout, 1) == 0
         torch.cuda.synchronize()
         return y
     try:
@@ -891,3 +891,47 @@ def test_conv_shortcut_folded_into_conv2(N, H, W, C3, C4, Cout):
     print(f"conv2 + folded shortcut N={N} {H}x{W} {C3}+{C4}->{Cout}: rel-L2 vs fp32 {r:.2e}; vs the unfused pair: {(diff > 0).float().mean().item():.1%} of the outputs differ, "
           f"max |d| {diff.max().item():.2e}")
     assert diff.max().item() <= 4e-3 * y0.float().abs().max().item()
+
+
+@pytest.mark.parametrize("M,C", [(4096 + 5, 320), (163840, 640), (40960, 1280)])
+def test_ff2_residual_proj_out_as_one_gemm(M, C):
+    """r03: out = proj_out(ff.net.2(f) + t2) + x is a linear chain, = (Wp W2) f + Wp t2 + (Wp b2 + bp) + x: ONE GEMM over [f | t2]
+    with the pre-multiplied weights (dm_op_igemm_shortcut, dense mode, residual x) against the two F.linear calls in fp32, and
+    against the unfused pair of GEMMs (which rounds the intermediate to fp16); both tiles bit-identical."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    g = torch.Generator(device="cuda").manual_seed(9)
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g, device=d, dtype=torch.float32) * scale).half()
+    f, t2, x = rnd(M, 4 * C, scale=0.7), rnd(M, C), rnd(M, C)
+    w2 = rnd(C, 4 * C, scale=(4 * C) ** -0.5)
+    wp = rnd(C, C, scale=C ** -0.5)
+    b2, bp = rnd(C, scale=0.1), rnd(C, scale=0.1)
+    wm = torch.cat([(wp.float() @ w2.float()).half(), wp], dim=1).contiguous()
+    bm = (wp.float() @ b2.float() + bp.float()).half()
+
+    def run():
+        y = torch.full((M, C), float("nan"), dtype=torch.float16, device=d)
+        assert lib.dm_op_igemm_shortcut(U.stream(), U.ptr(f), U.ptr(t2), None, U.ptr(wm), U.ptr(bm), U.ptr(x), U.ptr(y), 1, 1, M, 4 * C, C, 0, C, 0) == 0
+        torch.cuda.synchronize()
+        return y
+    try:
+        lib.dm_set_option(b"igemm_big", 0)
+        y0 = run()
+        lib.dm_set_option(b"igemm_big", 1)
+        y1 = run() if C % 320 == 0 else y0
+    finally:
+        lib.dm_set_option(b"igemm_big", -1)
+    ya = run()
+    assert not torch.isnan(y0.float()).any()
+    assert torch.equal(y0, y1) and torch.equal(ya, y0)
+    rows = torch.arange(M, device=d) if M <= 8192 else torch.cat([torch.arange(0, 2048, device=d), torch.arange(M - 2048, M, device=d)])
+    t3 = F.linear(f[rows].float(), w2.float(), b2.float()) + t2[rows].float()
+    ref = F.linear(t3, wp.float(), bp.float()) + x[rows].float()
+    r, m = U.assert_close_fp16(y0[rows], ref, "ff2 + residual + proj_out as one GEMM", rel=3e-3, abs_frac=4e-3)
+    t3u = U.op_igemm(f.view(1, 1, M, 4 * C), w2, b2, res=t2.view(1, 1, M, C), mode=0)
+    yu = U.op_igemm(t3u, wp, bp, res=x.view(1, 1, M, C), mode=0).view(M, C)
+    ru = U.rel_l2(yu[rows], ref)
+    print(f"ff2 + proj_out as one GEMM M={M} C={C}: rel-L2 vs fp32 {r:.2e} (the unfused pair: {ru:.2e}), max|err|/max|ref| {m:.2e}")
