@@ -50,6 +50,13 @@ SHAPES = [
     ("q2 1280->1280 @16 ln", 5, 0, 16, 16, 1280, 0, 1280, 0, "ln"),
     ("shortcut 1x1 cat 1280+1280->1280 @16", 2, 0, 16, 16, 1280, 1280, 1280, 0, ""),
     ("shortcut 1x1 640->1280 @16", 1, 0, 16, 16, 640, 0, 1280, 0, ""),
+    # r03 merged layers (dm_op_igemm_shortcut): extra = "sc:<C3>:<C4>[:res]" — a second GEMM on cat([X3, X4]) as extra k steps
+    ("ff2+proj_out [ff|t2] 1280+320->320 @64", 5, 0, 64, 64, 1280, 0, 320, 0, "sc:320:0:res"),
+    ("ff2+proj_out [ff|t2] 2560+640->640 @32", 5, 0, 32, 32, 2560, 0, 640, 0, "sc:640:0:res"),
+    ("ff2+proj_out [ff|t2] 5120+1280->1280 @16", 5, 0, 16, 16, 5120, 0, 1280, 0, "sc:1280:0:res"),
+    ("conv2+shortcut 3x3 640 + cat 640+320 ->640 @32", 1, 1, 32, 32, 640, 0, 640, 0, "sc:640:320"),
+    ("conv2+shortcut 3x3 320 + cat 320+320 ->320 @64", 2, 1, 64, 64, 320, 0, 320, 0, "sc:320:320"),
+    ("conv2+shortcut 3x3 1280 + cat 1280+1280 ->1280 @16", 2, 1, 16, 16, 1280, 0, 1280, 0, "sc:1280:1280"),
 ]
 
 
@@ -78,7 +85,18 @@ def main():
         res = torch.randn(B, OH, OW, Cout, device=d, generator=g).half() if extra == "res" else None
         y = torch.empty(B, OH, OW, Cout // 2 if epi else Cout, device=d, dtype=torch.float16)
         st = U.stream()
-        if extra == "ln":
+        if extra.startswith("sc:"):
+            f = extra.split(":")
+            C3, C4 = int(f[1]), int(f[2])
+            x3 = (torch.randn(B, H, W, C3, device=d, generator=g) * 0.5).half()
+            x4 = (torch.randn(B, H, W, C4, device=d, generator=g) * 0.5).half() if C4 else None
+            w = (torch.randn(Cout, taps * Cin + C3 + C4, device=d, generator=g) * (taps * Cin + C3 + C4) ** -0.5).half()
+            res = torch.randn(B, OH, OW, Cout, device=d, generator=g).half() if f[-1] == "res" else None
+
+            def run():
+                assert lib.dm_op_igemm_shortcut(st, U.ptr(x), U.ptr(x3), U.ptr(x4), U.ptr(w), U.ptr(bias), U.ptr(res), U.ptr(y),
+                                                B, H, W, Cin, C3, C4, Cout, mode) == 0
+        elif extra == "ln":
             stats = torch.empty(M, 2, dtype=torch.float32, device=d)
             assert lib.dm_op_ln_stats(st, U.ptr(x), M, Cin, 1e-5, U.ptr(stats)) == 0
             ln_s, ln_t = w.float().sum(1).contiguous(), torch.zeros(Cout, device=d)
@@ -112,7 +130,7 @@ def main():
                 cur_val[0] = v
                 assert lib.dm_set_option(opt.encode(), v) == 0
                 best[k] = min(best[k], timeit())
-        flops = 2.0 * M * Cout * taps * Cin
+        flops = 2.0 * M * Cout * (taps * Cin + (int(extra.split(":")[1]) + int(extra.split(":")[2]) if extra.startswith("sc:") else 0))
         tot[0] += n * best[0]
         tot[1] += n * best[1]
         print(f"{name:36s} x{n}  A {best[0]:7.3f} ms {flops / best[0] / 1e9:7.1f} TF/s   B {best[1]:7.3f} ms {flops / best[1] / 1e9:7.1f} TF/s   "
