@@ -1142,6 +1142,7 @@ int run_forward_graphed(dm_engine* e, const FwdArgs& A, hipStream_t s) {
         key.push_back((long long)(size_t)q);
     for (long long v : {(long long)A.latent_f32, (long long)A.out_stride, (long long)A.out_off, (long long)A.ensemble, (long long)e->n_prompts})
         key.push_back(v);
+    for (int o = 0; o < OPT_COUNT; ++o) key.push_back(option((Option)o));      // a graph bakes in the kernel choice of every switch
     for (auto& g : e->graphs)
         if (g.key == key) {
             g.stamp = ++e->graph_stamp;
