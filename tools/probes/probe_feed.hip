@@ -86,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void feed_vgpr_kernel(const _Float16* __res
 // wave.  RD / MF = 0 removes that activity (operands then come from registers).
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
-template <int DMA, int RD, int MF, int ROT = 0>
+template <int DMA, int RD, int MF, int ROT = 0, int XR = 0>
 __global__ __launch_bounds__(512, 2) void mix_kernel(const _Float16* __restrict__ Wp, const _Float16* __restrict__ X, int K, int C, int nk,
                                                      int tiles_c, unsigned* sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -107,6 +107,9 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const _Float16* __restrict_
         const char* cur = smem + (kt & 1) * (TP + TC) * 128;
         const int ko = ((kt + 1) * 64) % C;
         int piece = 0;
+        // XR: horizontal tap reuse of a 3x3 convolution — the activation stage (288 rows with halos) is fetched once per three
+        // k steps, 2 + 2 + 1 pieces per wave, beside the 5 weight pieces of every step (6.7 pieces per step instead of 9)
+        const int npieces = XR ? WI + ((kt % 3) == 2 ? 1 : 2) : NL;
 #pragma unroll
         for (int g = 0; g < 20; ++g) {
             if (RD) {          // 28 fragment reads per step: one per group + 8 extra
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const _Float16* __restrict_
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[(g % 5) * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc[(g % 5) * 4 + j], 0, 0, 0);
             }
-            if (DMA && piece < NL && (g & 1) == 0) {
+            if (DMA && piece < npieces && (g & 1) == 0) {
                 const int i = piece++;
                 // ROT: every block walks the weight k slabs from its own starting point, so the CUs of an XCD do not ask
                 // the L2 for the same weight lines at the same moment
@@ -227,6 +230,11 @@ int main() {
     runm("MFMA + DMA", mix_kernel<1, 0, 1>);
     runm("fragment reads + DMA", mix_kernel<1, 1, 0>);
     runm("MFMA + fragment reads + DMA", mix_kernel<1, 1, 1>);
+    runm("tap reuse (6.7 pieces/step): DMA only", mix_kernel<1, 0, 0, 0, 1>);
+    runm("tap reuse: MFMA + DMA", mix_kernel<1, 0, 1, 0, 1>);
+    runm("tap reuse: MFMA + fragment reads + DMA", mix_kernel<1, 1, 1, 0, 1>);
+    runm("MFMA + fragment reads + DMA (again)", mix_kernel<1, 1, 1>);
+    runm("tap reuse: MFMA + fragment reads + DMA (again)", mix_kernel<1, 1, 1, 0, 1>);
     runm("DMA only, weight k order rotated per block (+7)", mix_kernel<1, 0, 0, 7>);
     runm("MFMA + reads + DMA, rotated (+7)", mix_kernel<1, 1, 1, 7>);
     runm("MFMA + reads + DMA, rotated (+1)", mix_kernel<1, 1, 1, 1>);
