@@ -34,7 +34,7 @@ inline int device_cu_count() {
 
 // Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of
 // the same name in upper case with a DM_ prefix (DM_IGEMM_PERSIST=0 ...), changeable through dm_set_option().
-enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_COUNT };
+enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_TAP_REUSE, OPT_COUNT };
 int option(Option o);                       // engine.hip
 int set_option(const char* name, int value);   // 0 on success
 
@@ -108,6 +108,16 @@ inline bool igemm_pers_ok(const IGemmParams& p) {
     if (p.ln_s && (p.M & 1)) return false;
     if (p.ln_s && (p.mode != IG_DENSE || p.C1 != p.Cin)) return false;
     return true;
+}
+
+// Layers whose k steps run (dy, 64-channel slab, dx) so that the persistent tile can reuse one activation stage for the three
+// horizontal taps (igemm_pers_tr.hip; the 128-row tile has the same k order as its KO variant, igemm_ko.hip): plain 3x3 stride-1
+// convolutions on 16 / 32 / 64 pixel wide images whose samples are whole 256-row tiles.  A property of the LAYER and the sample
+// geometry, never of the batch: a sample's bits do not depend on the batch it rides in.
+inline bool igemm_ko_layer(const IGemmParams& p) {
+    return p.mode == IG_CONV3 && p.epi == EPI_PLAIN && !p.ln_s && p.ksplit <= 1 && !p.X3 && !p.w_sample_stride &&
+           p.H == p.OH && p.W == p.OW && (p.W == 16 || p.W == 32 || p.W == 64) && (p.H * p.W) % 256 == 0 &&
+           p.Cout % 160 == 0 && p.Cin % 64 == 0 && p.C1 % 64 == 0;
 }
 
 // ---- K4/K5: flash attention (self and cross), head_dim 40/80/160 ------------------------------

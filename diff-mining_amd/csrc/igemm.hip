@@ -37,6 +37,9 @@ hipError_t launch_igemm_pers_ws(const IGemmParams& p, hipStream_t s);         //
 hipError_t launch_igemm_tile_ws(const IGemmParams& p, hipStream_t s);         // igemm_ws.hip
 hipError_t launch_igemm_pers_sc(const IGemmParams& p, hipStream_t s);         // igemm_pers_sc.hip: conv_shortcut folded into conv2
 hipError_t launch_igemm_tile_sc(const IGemmParams& p, hipStream_t s);         // igemm_sc.hip
+hipError_t launch_igemm_pers_tr(const IGemmParams& p, hipStream_t s);         // igemm_pers_tr.hip: 3x3 convolutions with horizontal tap reuse
+bool igemm_pers_tr_ok(const IGemmParams& p);
+hipError_t launch_igemm_tile_ko(const IGemmParams& p, hipStream_t s);         // igemm_ko.hip: the same k order on the 128-row tile
 
 // Shape -> tile choice, measured per shape on one box with both arms interleaved (tools/ab_igemm.py, r02): the
 // persistent 256 x 320 tile (igemm_pers_tile.h: 13.8 instead of 21.9 LDS-DMA bytes per kMAC, no per-tile prologue, stores
@@ -174,8 +177,17 @@ int igemm_head_rows(const IGemmParams& p) {
     return head_rows(p);
 }
 
+// The (dy, slab, dx) k order + horizontal tap reuse (igemm_pers_tr.hip / igemm_ko.hip).  Option tap_reuse: 1 = the 64-pixel-wide
+// layers (-4..-6 % per launch at the bench batch), 2 = also the 32- and 16-pixel-wide ones (+-0 / +1..6 %: the out-of-order walk of
+// their larger weights costs what the activation reuse saves; kept for A/B), 0 = off.  A property of the layer, never of the batch.
+static bool tap_reuse_layer(const IGemmParams& p) {
+    const int on = option(OPT_TAP_REUSE);
+    return on != 0 && igemm_ko_layer(p) && (on == 2 || p.W == 64);
+}
+
 static hipError_t launch_small(const IGemmParams& p, hipStream_t s) {
     if (p.X3) return launch_igemm_tile_sc(p, s);
+    if (tap_reuse_layer(p)) return launch_igemm_tile_ko(p, s);
     if (p.ln_s) return launch_igemm_tile_ln(p, s);
     return (p.Cout % 320 == 0) ? launch_t<4, 5>(p, s) : launch_t<2, 5>(p, s);
 }
@@ -205,7 +217,8 @@ hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
     const int head = head_rows(p);
     if (head <= 0) return launch_small(p, s);
     const IGemmParams h = head < p.M ? row_range(p, 0, head) : p;
-    const hipError_t rc = p.X3 ? launch_igemm_pers_sc(h, s) : p.ln_s ? launch_igemm_pers_ln(h, s) : launch_igemm_pers(h, s);
+    if (tap_reuse_layer(p) && !igemm_pers_tr_ok(h)) return launch_small(p, s);     // (32-bit offsets: the whole launch on the 128-row tile)
+    const hipError_t rc = p.X3 ? launch_igemm_pers_sc(h, s) : p.ln_s ? launch_igemm_pers_ln(h, s) : tap_reuse_layer(h) ? launch_igemm_pers_tr(h, s) : launch_igemm_pers(h, s);
     if (rc != hipSuccess || head >= p.M) return rc;
     return launch_small(row_range(p, head, p.M), s);
 }

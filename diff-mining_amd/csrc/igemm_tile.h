@@ -171,7 +171,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // variant: the same arithmetic (y = fp16(acc + t), the folded-LayerNorm epilogue with (mean, rstd) = (0, 1)).
 // SC: a ResNet block's conv_shortcut folded into its conv2 as extra k steps on a second tensor pair (igemm_pers_tile.h): the
 // same k order and arithmetic as the persistent tile's SC variant -> bit-identical tiles.
-template <int WC, int EPI, int NI, bool SPLIT = false, bool LN = false, bool WS = false, bool SC = false>
+// KO: the (dy, 64-channel slab, dx) k order of a 3x3 stride-1 convolution (weights still [Cout][tap][Cin], visited in that order):
+// the 128-row partner of igemm_pers_tr.h, whose three dx steps of a (dy, slab) share one activation stage -> bit-identical tiles.
+template <int WC, int EPI, int NI, bool SPLIT = false, bool LN = false, bool WS = false, bool SC = false, bool KO = false>
 __global__ __launch_bounds__(128 * WC, 2)
 void igemm_kernel(IGemmParams p) {
     constexpr int WP = 2;
@@ -276,7 +278,43 @@ void igemm_kernel(IGemmParams p) {
     };
     int ld_tap = SPLIT ? kt_begin / cpt : 0, ld_cc = SPLIT ? kt_begin % cpt : 0;
     bool first_prepare = true;
+    int ld_dx = 0, xlr = 0, w_adv = BK;                      // KO: ld_tap counts dy; xpix[] = centre pixel (dx = 1) of the row's dy line
+    auto set_rows = [&](int dy) {                            // KO: centre pixels of the line dy, validity of the left / right neighbour
+        xlr = 0;
+#pragma unroll
+        for (int k = 0; k < XI; ++k) {
+            long long pix = -1;
+            if (xn[k] >= 0) {
+                const int ih = xoh[k] + dy - 1, iw = xow[k];
+                if (ih >= 0 && ih < p.H) {
+                    pix = ((long long)xn[k] * p.H + ih) * p.W + iw;
+                    xlr |= ((iw >= 1) ? 1 : 0) << (2 * k);
+                    xlr |= ((iw + 1 < p.W) ? 2 : 0) << (2 * k);
+                }
+            }
+            xpix[k] = pix;
+        }
+    };
+    auto prepare_ko = [&]() {
+        if (ld_cc == 0 && ld_dx == 0) set_rows(ld_tap);
+        const int ch = ld_cc * BK;
+        const bool second = ch >= C1;
+        const f16* base = second ? p.X2 : p.X;
+        const long long cs = second ? C2 : C1;
+        const int cho = second ? ch - C1 : ch;
+#pragma unroll
+        for (int k = 0; k < XI; ++k) {
+            const bool ok = xpix[k] >= 0 && (ld_dx == 1 || ((xlr >> (2 * k + (ld_dx >> 1))) & 1) != 0);
+            xsrc[k] = ok ? base + (xpix[k] + ld_dx - 1) * cs + cho + lchunk : zero;
+            xinc[k] = 0;
+        }
+        // weight offset of the NEXT k step relative to this one: dx + 1 = the next tap (+ Cin); after dx = 2 back to the first
+        // tap of the line at the next slab (+ 64 - 2 Cin); after the last slab the next line starts 64 further
+        w_adv = (ld_dx < 2) ? p.Cin : ((ld_cc == cpt - 1) ? BK : BK - 2 * p.Cin);
+        if (++ld_dx == 3) { ld_dx = 0; if (++ld_cc == cpt) { ld_cc = 0; ++ld_tap; } }
+    };
     auto prepare = [&]() {                                   // pointers for the next tile to load
+        if constexpr (KO) { prepare_ko(); return; }
         if constexpr (SC) {
             if (ld_tap == ntaps) {                           // the folded second GEMM: centre tap (dense: the row) on cat([X3, X4])
                 if (ld_cc == 0) {
@@ -311,7 +349,7 @@ void igemm_kernel(IGemmParams p) {
         char* wt = smem + buf * STAGE;
         if (idx < WI) {
             __builtin_amdgcn_global_load_lds((gptr_t)wsrc[idx], (lptr_t)(wt + (wid + idx * NW) * 1024), 16, 0, 0);
-            wsrc[idx] += BK;
+            wsrc[idx] += KO ? w_adv : BK;
         } else {
             const int k = idx - WI;
             __builtin_amdgcn_global_load_lds((gptr_t)xsrc[k], (lptr_t)(wt + WBYTES + (wid + k * NW) * 1024), 16, 0, 0);
@@ -432,7 +470,7 @@ void igemm_kernel(IGemmParams p) {
 
 }  // namespace
 
-template <int WC, int NI, bool LN = false, bool WS = false, bool SC = false>
+template <int WC, int NI, bool LN = false, bool WS = false, bool SC = false, bool KO = false>
 static hipError_t launch_t(const IGemmParams& p, hipStream_t s) {
     constexpr int TP = 128, TC = 16 * NI * WC;
     constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 1024 + (LN ? 8 * TC + 8 * TP : 0);      // operand stages + bias (+ ln_s, ln_t, row stats)
@@ -441,13 +479,13 @@ static hipError_t launch_t(const IGemmParams& p, hipStream_t s) {
     dim3 grid(tiles_p * tiles_c), block(128 * WC);
     static std::atomic<uint64_t> attr_seen{0};      // hipFuncSetAttribute is per DEVICE, not per process
     if (first_use_on_device(attr_seen)) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_PLAIN, NI, false, LN, WS, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_GEGLU, NI, false, LN, WS, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_PLAIN, NI, false, LN, WS, SC, KO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_GEGLU, NI, false, LN, WS, SC, KO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     if (p.epi == EPI_GEGLU)
-        hipLaunchKernelGGL((igemm_kernel<WC, EPI_GEGLU, NI, false, LN, WS, SC>), grid, block, lds, s, p);
+        hipLaunchKernelGGL((igemm_kernel<WC, EPI_GEGLU, NI, false, LN, WS, SC, KO>), grid, block, lds, s, p);
     else
-        hipLaunchKernelGGL((igemm_kernel<WC, EPI_PLAIN, NI, false, LN, WS, SC>), grid, block, lds, s, p);
+        hipLaunchKernelGGL((igemm_kernel<WC, EPI_PLAIN, NI, false, LN, WS, SC, KO>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 

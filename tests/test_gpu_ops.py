@@ -935,3 +935,45 @@ def test_ff2_residual_proj_out_as_one_gemm(M, C):
     yu = U.op_igemm(t3u, wp, bp, res=x.view(1, 1, M, C), mode=0).view(M, C)
     ru = U.rel_l2(yu[rows], ref)
     print(f"ff2 + proj_out as one GEMM M={M} C={C}: rel-L2 vs fp32 {r:.2e} (the unfused pair: {ru:.2e}), max|err|/max|ref| {m:.2e}")
+
+
+@pytest.mark.parametrize("W,C1,C2,Cout,N", [(64, 320, 0, 320, 6), (64, 640, 320, 320, 3), (32, 640, 0, 640, 10), (32, 1280, 640, 640, 6),
+                                           (16, 1280, 0, 1280, 24), (16, 640, 0, 1280, 17)])
+def test_igemm_tap_reuse_tile(W, C1, C2, Cout, N):
+    """igemm_pers_tr.hip (option tap_reuse; 2 = every eligible width): the 3x3 stride-1 convolutions with the k order (dy, slab, dx) and ONE activation
+    stage per three horizontal taps, against F.conv2d in fp32 (plain, + time embedding, + residual, channel concat), and bit for
+    bit against the 128-row tile's KO variant (igemm_ko.hip) on the same operands — the pair that makes a sample's result
+    independent of the batch it rides in."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    H = W
+    Cin = C1 + C2
+    g = torch.Generator(device="cuda").manual_seed(51)
+    x1 = torch.randn(N, H, W, C1, generator=g, device=d, dtype=torch.float32).half()
+    x2 = (torch.randn(N, H, W, C2, generator=g, device=d, dtype=torch.float32) * 0.5).half() if C2 else None
+    w = U.f16_randn(Cout, Cin, 3, 3, seed=52, scale=(9 * Cin) ** -0.5)
+    b = U.f16_randn(Cout, seed=53, scale=0.1)
+    temb = U.f16_randn(N, Cout, seed=54)
+    res = torch.randn(N, H, W, Cout, generator=g, device=d, dtype=torch.float32).half()
+    wg, bg = U.pack_conv3(w).to(d), b.to(d)
+    out = {}
+    try:
+        assert lib.dm_set_option(b"tap_reuse", 2) == 0
+        for big in (1, 0):
+            assert lib.dm_set_option(b"igemm_big", big) == 0
+            out[big] = (U.op_igemm(x1, wg, bg, X2=x2, mode=1), U.op_igemm(x1, wg, bg, X2=x2, temb=temb.to(d), mode=1),
+                        U.op_igemm(x1, wg, bg, X2=x2, res=res, mode=1))
+    finally:
+        lib.dm_set_option(b"igemm_big", -1)
+        lib.dm_set_option(b"tap_reuse", 1)
+    for k, name in enumerate(("plain", "temb", "res")):
+        assert torch.equal(out[1][k], out[0][k]), f"tap-reuse tile != 128-row KO tile ({name}): " \
+            f"{(out[1][k].float() - out[0][k].float()).abs().max().item():.3e}"
+    y_plain, y_temb, y_res = out[1]
+    for n in sorted({0, N // 2, N - 1}):
+        xin = x1[n:n + 1] if x2 is None else torch.cat([x1[n:n + 1], x2[n:n + 1]], 3)
+        ref = F.conv2d(U.to_nchw(xin.cpu().float()), w.float(), b.float(), padding=1)
+        U.assert_close_fp16(U.to_nchw(y_plain[n:n + 1]), ref, f"tap-reuse conv3x3 n={n}")
+        U.assert_close_fp16(U.to_nchw(y_temb[n:n + 1]), ref.half().float() + temb[n].float()[None, :, None, None], f"tap-reuse +temb n={n}")
+        U.assert_close_fp16(U.to_nchw(y_res[n:n + 1]), ref.half().float() + U.to_nchw(res[n:n + 1].cpu().float()), f"tap-reuse +res n={n}")
