@@ -209,7 +209,7 @@ def main():
                        "images_per_gpu_per_step": n_img, "unet_forwards_per_image": per_img,
                        "latent_dtype_flow": args.latent_dtype,
                        "parallelism": f"image-sharded x{world}, one all-gather of T(x|c)"},
-            "roofline": {"bound": "mfma", "kernel": "igemm family: igemm_pers_kernel (persistent 256x320 tile) + igemm_kernel (128x320 / 128x160 tile) incl. their LayerNorm-folded and split-K instantiations (implicit-GEMM conv3x3/1x1/linear)",
+            "roofline": {"bound": "mfma", "kernel": "igemm family: igemm_pers_kernel / igemm_pers_tr_kernel (persistent 256x320 tile; tr = 3x3 convolutions with horizontal tap reuse) + igemm_kernel (128x320 / 128x160 tile) incl. their LayerNorm-folded and split-K instantiations (implicit-GEMM conv3x3/1x1/linear)",
                          "achieved": round(ig_tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ig_tf / PEAK_TFLOPS, 4), "traffic": hbm_traffic_per_launch(prof["igemm_launches"] / max(args.steps, 1)),
                          "launches": prof["igemm_launches"], "kernel_ms_total": round(prof["igemm_ms"], 3),
