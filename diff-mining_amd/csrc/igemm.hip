@@ -177,12 +177,16 @@ int igemm_head_rows(const IGemmParams& p) {
     return head_rows(p);
 }
 
-// The (dy, slab, dx) k order + horizontal tap reuse (igemm_pers_tr.hip / igemm_ko.hip).  Option tap_reuse: 1 = the 64-pixel-wide
-// layers (-4..-6 % per launch at the bench batch), 2 = also the 32- and 16-pixel-wide ones (+-0 / +1..6 %: the out-of-order walk of
-// their larger weights costs what the activation reuse saves; kept for A/B), 0 = off.  A property of the layer, never of the batch.
+// The (dy, slab, dx) k order + horizontal tap reuse (igemm_pers_tr.hip / igemm_ko.hip).  Option tap_reuse: 1 = where it pays at
+// the bench batch (tools/ab_igemm.py tap_reuse 0 2, profiles/r03_ab_tap_reuse.txt): every eligible layer of 64-pixel-wide images
+// (-6..-9 % per launch with a time embedding — the unrolled k loop —, -5 % with a residual) and the time-embedding layers
+// (ResnetBlock2D.conv1) of 32-pixel-wide ones (-4..-5 %); 2 = every eligible layer (32 wide with a residual: +-0; 16 wide: +-0 /
+// +3 %: the out-of-order walk of their larger weights costs what the activation reuse saves); 0 = off.  A property of the
+// layer (geometry, epilogue), never of the batch.
 static bool tap_reuse_layer(const IGemmParams& p) {
     const int on = option(OPT_TAP_REUSE);
-    return on != 0 && igemm_ko_layer(p) && (on == 2 || p.W == 64);
+    if (on == 0 || !igemm_ko_layer(p)) return false;
+    return on == 2 || p.W == 64 || (p.W == 32 && p.temb != nullptr);
 }
 
 static hipError_t launch_small(const IGemmParams& p, hipStream_t s) {

@@ -17,7 +17,10 @@ namespace {
 typedef volatile __attribute__((address_space(3))) int* lds_word_t;    // a volatile LDS word as ds_read / ds_write (a generic volatile pointer compiles to flat_*)
 
 // EXTRA: PX_NONE / PX_TEMB / PX_RES as in igemm_pers_tile.h; WIMG: image width = output width (64, 32 or 16)
-template <int EXTRA, int WIMG>
+// UNROLL: the k loop walks (dy, slab) pairs with its three dx steps unrolled (compile-time dx: no branch and no run-time piece index in
+// the MFMA stream; 5-7 % faster) — for the instantiations the register allocator handles without spilling accumulators inside the
+// loop, which launch_tr_w lists and tests/test_abi.py checks against the compiled ISA; the others run the run-time-dx loop.
+template <int EXTRA, int WIMG, bool UNROLL = false>
 __global__ __launch_bounds__(512, 2)
 void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
     constexpr int EPI = EPI_PLAIN;
@@ -156,7 +159,8 @@ void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
     // one k step: weights of stage wcur, activation stage xcur read shifted by dx rows; the LDS-DMA of the next k step's weights
     // (adv = distance to the step after that) and pieces 2 dx, 2 dx + 1 (dx = 2: piece 4 only) of the
     // next activation stage interleaved.  dx is a run-time value on purpose: unrolled by three the k loop's register allocation spills accumulators.
-    auto step = [&](int wcur, int xcur, int dx, int adv) __attribute__((always_inline)) {
+    auto step = [&](int wcur, int xcur, auto dxv, int adv) __attribute__((always_inline)) {
+        const int dx = dxv;                  // an int (run-time loop) or an integral_constant (unrolled loop: everything below folds)
         const char* wt = smem + wcur * WBYTES;
         const char* xt = xs0 + xcur * XBYTES;
         const int ln = hw_lane();
@@ -371,24 +375,28 @@ void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
         if (threadIdx.x == 0) ticket = atomicAdd(&ctr[xcd * 32], 1);
         int next = 0;
         bool has_next = false;
-        const int nk = 3 * ntrip;
-        int dx = 0, tr = 0, cc = 0;                  // horizontal tap, (dy, slab) index and slab of the k step
-        for (int kt = 0; kt < nk; ++kt) {
-            // weights: the step after the next one is the next tap (+ Cin) — or, from dx = 2, the first tap of the next slab of
-            // the line (+ 64 - 2 Cin) / of the next line (+ 64)
-            const int adv = (dx == 1) ? ((cc == cpt - 1) ? BK : BK - 2 * p.Cin) : p.Cin;
-            step(g & 1, tg & 1, dx, adv);
-            ++g;
-            if (dx == 1 && tr == ntrip - 1) {        // the weights of the NEXT tile's first k step are requested by this tile's last step
-                next = tdyn + *(lds_word_t)(aux0 + slot * AUX_BYTES + 1020);
-                next = __builtin_amdgcn_readfirstlane(next);
-                has_next = next < tend;
-                set_wtile(has_next ? next : tile);
-            }
-            if (dx == 2) {
+        if constexpr (UNROLL) {
+            int cc = 0;                               // slab of the (dy, slab) pair
+            for (int tr = 0; tr < ntrip; ++tr) {
+                const bool last = tr == ntrip - 1;
+                // weights: the step after the next one is the next tap (+ Cin) — or, from dx = 2, the first tap of the next slab of
+                // the line (+ 64 - 2 Cin) / of the next line (+ 64)
+                step(g & 1, tg & 1, std::integral_constant<int, 0>{}, p.Cin);
+                ++g;
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (tr == 0 && threadIdx.x == 0) *(lds_word_t)(aux0 + slot * AUX_BYTES + 1020) = ticket;
+                step(g & 1, tg & 1, std::integral_constant<int, 1>{}, (cc == cpt - 1) ? BK : BK - 2 * p.Cin);
+                ++g;
+                if (last) {        // the weights of the NEXT tile's first k step are requested by this tile's last step
+                    next = tdyn + *(lds_word_t)(aux0 + slot * AUX_BYTES + 1020);
+                    next = __builtin_amdgcn_readfirstlane(next);
+                    has_next = next < tend;
+                    set_wtile(has_next ? next : tile);
+                }
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                step(g & 1, tg & 1, std::integral_constant<int, 2>{}, p.Cin);
+                ++g;
                 ++tg;
-                // sources of the activation stage after the one just requested: from the second-to-last stage on they belong to the
-                // next tile (without one the block re-requests its own first stage: valid addresses, unused)
                 if (tr == ntrip - 2) {               // (the ticket was published after this tile's first k step; ntrip >= 15)
                     int nx = tdyn + *(lds_word_t)(aux0 + slot * AUX_BYTES + 1020);
                     nx = __builtin_amdgcn_readfirstlane(nx);
@@ -397,11 +405,42 @@ void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
                     if (hn) load_aux(slot ^ 1, (nx - (nx / tiles_c) * tiles_c) * TC, lp0);
                 }
                 prepare_x();
-                dx = 0; ++tr;
                 if (++cc == cpt) cc = 0;
-            } else ++dx;
-            if (kt < nk - 1) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            if (kt == 0 && threadIdx.x == 0) *(lds_word_t)(aux0 + slot * AUX_BYTES + 1020) = ticket;
+                if (!last) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+        } else {
+        const int nk = 3 * ntrip;
+            int dx = 0, tr = 0, cc = 0;                  // horizontal tap, (dy, slab) index and slab of the k step
+            for (int kt = 0; kt < nk; ++kt) {
+                // weights: the step after the next one is the next tap (+ Cin) — or, from dx = 2, the first tap of the next slab of
+                // the line (+ 64 - 2 Cin) / of the next line (+ 64)
+                const int adv = (dx == 1) ? ((cc == cpt - 1) ? BK : BK - 2 * p.Cin) : p.Cin;
+                step(g & 1, tg & 1, dx, adv);
+                ++g;
+                if (dx == 1 && tr == ntrip - 1) {        // the weights of the NEXT tile's first k step are requested by this tile's last step
+                    next = tdyn + *(lds_word_t)(aux0 + slot * AUX_BYTES + 1020);
+                    next = __builtin_amdgcn_readfirstlane(next);
+                    has_next = next < tend;
+                    set_wtile(has_next ? next : tile);
+                }
+                if (dx == 2) {
+                    ++tg;
+                    // sources of the activation stage after the one just requested: from the second-to-last stage on they belong to the
+                    // next tile (without one the block re-requests its own first stage: valid addresses, unused)
+                    if (tr == ntrip - 2) {               // (the ticket was published after this tile's first k step; ntrip >= 15)
+                        int nx = tdyn + *(lds_word_t)(aux0 + slot * AUX_BYTES + 1020);
+                        nx = __builtin_amdgcn_readfirstlane(nx);
+                        const bool hn = nx < tend;
+                        set_xtile(hn ? nx : tile);
+                        if (hn) load_aux(slot ^ 1, (nx - (nx / tiles_c) * tiles_c) * TC, lp0);
+                    }
+                    prepare_x();
+                    dx = 0; ++tr;
+                    if (++cc == cpt) cc = 0;
+                } else ++dx;
+                if (kt < nk - 1) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (kt == 0 && threadIdx.x == 0) *(lds_word_t)(aux0 + slot * AUX_BYTES + 1020) = ticket;
+            }
         }
         epilogue(p0, c0out, slot);
         if (!has_next) break;
@@ -413,6 +452,28 @@ void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
 
 }  // namespace
 
+// which instantiations run the unrolled k loop: the ones hipcc 7.2 allocates without spills (tools/kernel_regs.sh; asserted by
+// tests/test_abi.py::test_tap_reuse_kernels_do_not_spill) — measured per launch against the run-time-dx loop in
+// profiles/r03_ab_tap_reuse.txt
+#ifdef DM_TR_ALL_UNROLL
+template <int EXTRA, int WIMG> struct TrUnroll { static constexpr bool value = true; };
+#else
+template <int EXTRA, int WIMG> struct TrUnroll { static constexpr bool value = false; };
+#endif
+#if !defined(DM_TR_NO_UNROLL) && !defined(DM_TR_ALL_UNROLL)
+template <> struct TrUnroll<PX_NONE, 64> { static constexpr bool value = true; };
+template <> struct TrUnroll<PX_TEMB, 64> { static constexpr bool value = true; };
+template <> struct TrUnroll<PX_TEMB, 32> { static constexpr bool value = true; };
+template <> struct TrUnroll<PX_TEMB, 16> { static constexpr bool value = true; };
+#endif
+
+template <int EXTRA, int WIMG>
+static void launch_tr_k(const IGemmParams& p, int ntiles, int cset, dim3 g, size_t lds, hipStream_t s, bool set_attr) {
+    constexpr bool U = TrUnroll<EXTRA, WIMG>::value;
+    if (set_attr) (void)hipFuncSetAttribute((const void*)igemm_pers_tr_kernel<EXTRA, WIMG, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else hipLaunchKernelGGL((igemm_pers_tr_kernel<EXTRA, WIMG, U>), g, dim3(512), lds, s, p, ntiles, cset);
+}
+
 template <int WIMG>
 static hipError_t launch_tr_w(const IGemmParams& p, hipStream_t s) {
     constexpr int TP = 256, TC = 320;
@@ -421,18 +482,18 @@ static hipError_t launch_tr_w(const IGemmParams& p, hipStream_t s) {
     const int ntiles = (p.M / TP) * (p.Cout / TC);
     const int n_cu = device_cu_count();
     const int grid = ntiles < n_cu ? ntiles : n_cu;
+    const dim3 g(grid);
     static std::atomic<uint64_t> attr_seen{0};
     if (first_use_on_device(attr_seen)) {
-        (void)hipFuncSetAttribute((const void*)igemm_pers_tr_kernel<PX_NONE, WIMG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)igemm_pers_tr_kernel<PX_TEMB, WIMG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)igemm_pers_tr_kernel<PX_RES, WIMG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        launch_tr_k<PX_NONE, WIMG>(p, 0, 0, g, lds, s, true);
+        launch_tr_k<PX_TEMB, WIMG>(p, 0, 0, g, lds, s, true);
+        launch_tr_k<PX_RES, WIMG>(p, 0, 0, g, lds, s, true);
     }
     static std::atomic<unsigned> launch_no{0};
     const int cset = (int)(launch_no.fetch_add(1) % CSETS);
-    const dim3 g(grid), b(512);
-    if (p.temb) hipLaunchKernelGGL((igemm_pers_tr_kernel<PX_TEMB, WIMG>), g, b, lds, s, p, ntiles, cset);
-    else if (p.res) hipLaunchKernelGGL((igemm_pers_tr_kernel<PX_RES, WIMG>), g, b, lds, s, p, ntiles, cset);
-    else hipLaunchKernelGGL((igemm_pers_tr_kernel<PX_NONE, WIMG>), g, b, lds, s, p, ntiles, cset);
+    if (p.temb) launch_tr_k<PX_TEMB, WIMG>(p, ntiles, cset, g, lds, s, false);
+    else if (p.res) launch_tr_k<PX_RES, WIMG>(p, ntiles, cset, g, lds, s, false);
+    else launch_tr_k<PX_NONE, WIMG>(p, ntiles, cset, g, lds, s, false);
     return hipGetLastError();
 }
 

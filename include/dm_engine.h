@@ -246,7 +246,8 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
  *     rounding of the sum instead of three) — numerically equivalent, not bit-identical to 0;
  *   "ff_fold" (1 / 0): ff.net.2 + residual + proj_out of a transformer block as one GEMM with the pre-multiplied weights Wp W2
  *     (the [tokens x C] intermediate and its fp16 rounding disappear) — numerically equivalent, not bit-identical to 0;
- *   "tap_reuse" (1 / 0 / 2): the 3x3 stride-1 convolutions of 64-pixel-wide images (2: also 32 / 16) run their k steps in the order
+ *   "tap_reuse" (1 / 0 / 2): the 3x3 stride-1 convolutions of 64-pixel-wide images and the time-embedding ones (ResnetBlock2D.conv1)
+ *     of 32-pixel-wide images (2: every eligible layer down to 16 pixels) run their k steps in the order
  *     (dy, 64-channel slab, dx) and fetch ONE activation stage per three horizontal taps (igemm_pers_tr.hip; the 128-row tile
  *     follows the same order, so the two tile kernels stay bit-identical) — numerically equivalent, not bit-identical to 0;
  *   "graph" (0 / 1): replay whole U-Net runs as captured hipGraphs (bit-identical: the same kernels with the same arguments);

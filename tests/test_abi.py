@@ -81,3 +81,25 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("the oracle", "").replace("CPU oracle", ""), f
+
+
+def test_tap_reuse_kernels_do_not_spill():
+    """igemm_pers_tr.hip picks, per instantiation, the unrolled or the run-time-dx form of its k loop by whether the register
+    allocator handles it without spilling (a spilled accumulator is reloaded inside the k loop, behind the LDS-DMA on vmcnt).
+    That list is a property of the compiler, so it is checked against the compiled ISA: every instantiation of the kernel that
+    the library ships must have no spilled VGPR."""
+    import importlib
+    import re
+    import subprocess
+    import tempfile
+    b = importlib.import_module("diff-mining_amd.build")
+    src = os.path.join(os.path.dirname(b.__file__), "csrc", "igemm_pers_tr.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "tr.s")
+        subprocess.run([b._hipcc()] + b.FLAGS + ["-S", "--cuda-device-only", "-o", out, src], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    found = re.findall(r"\.name:\s+(\S*igemm_pers_tr_kernel\S*).*?\.vgpr_spill_count:\s+(\d+)", text, re.S)
+    assert len(found) == 9, found
+    spilled = [(n, int(c)) for n, c in found if int(c) != 0]
+    assert not spilled, f"tap-reuse kernels with spilled registers (move them to the run-time-dx loop: TrUnroll): {spilled}"
