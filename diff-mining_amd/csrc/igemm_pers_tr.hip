@@ -20,7 +20,9 @@ typedef volatile __attribute__((address_space(3))) int* lds_word_t;    // a vola
 // UNROLL: the k loop walks (dy, slab) pairs with its three dx steps unrolled (compile-time dx: no branch and no run-time piece index in
 // the MFMA stream; 5-7 % faster) — for the instantiations the register allocator handles without spilling accumulators inside the
 // loop, which launch_tr_w lists and tests/test_abi.py checks against the compiled ISA; the others run the run-time-dx loop.
-template <int EXTRA, int WIMG, bool UNROLL = false>
+// UP: the convolution runs on the nearest-2x up-sampled image (Upsample2D): the stage rows are up-sampled coordinates, a row's source
+// pixel is (ih >> 1, iw >> 1) of the H x W input.
+template <int EXTRA, int WIMG, bool UNROLL = false, bool UP = false>
 __global__ __launch_bounds__(512, 2)
 void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
     constexpr int EPI = EPI_PLAIN;
@@ -109,6 +111,10 @@ void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
         const int ir = r / PITCH;
         const int iw = r - ir * PITCH - 1;
         const int ih = oh0 + ir + x_dy - 1;
+        if constexpr (UP) {
+            const bool oku = r < ROWS && iw >= 0 && iw < WIMG && ih >= 0 && ih < p.OH;
+            return oku ? (n * p.H + (ih >> 1)) * p.W + (iw >> 1) : -1;
+        }
         const bool ok = r < ROWS && iw >= 0 && iw < WIMG && ih >= 0 && ih < p.H;
         return ok ? (n * p.H + ih) * WIMG + iw : -1;
     };
@@ -467,6 +473,23 @@ template <> struct TrUnroll<PX_TEMB, 32> { static constexpr bool value = true; }
 template <> struct TrUnroll<PX_TEMB, 16> { static constexpr bool value = true; };
 #endif
 
+#ifndef DM_TR_UP_UNROLL
+#define DM_TR_UP_UNROLL false
+#endif
+template <bool U>
+static hipError_t launch_tr_up64(const IGemmParams& p, hipStream_t s) {      // Upsample2D.conv onto a 64-pixel-wide image: bias only
+    constexpr size_t lds = 2 * (size_t)320 * 128 + 2 * (size_t)33 * 1024 + 2 * 2048;
+    const int ntiles = (p.M / 256) * (p.Cout / 320);
+    const int n_cu = device_cu_count();
+    static std::atomic<uint64_t> attr_seen{0};
+    if (first_use_on_device(attr_seen))
+        (void)hipFuncSetAttribute((const void*)igemm_pers_tr_kernel<PX_NONE, 64, U, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static std::atomic<unsigned> launch_no{0};
+    const int cset = (int)(launch_no.fetch_add(1) % CSETS);
+    hipLaunchKernelGGL((igemm_pers_tr_kernel<PX_NONE, 64, U, true>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), lds, s, p, ntiles, cset);
+    return hipGetLastError();
+}
+
 template <int EXTRA, int WIMG>
 static void launch_tr_k(const IGemmParams& p, int ntiles, int cset, dim3 g, size_t lds, hipStream_t s, bool set_attr) {
     constexpr bool U = TrUnroll<EXTRA, WIMG>::value;
@@ -506,7 +529,8 @@ bool igemm_pers_tr_ok(const IGemmParams& p) {
 
 hipError_t launch_igemm_pers_tr(const IGemmParams& p, hipStream_t s) {
     if (!igemm_ko_layer(p) || !igemm_pers_tr_ok(p)) return hipErrorInvalidValue;
-    return p.W == 64 ? launch_tr_w<64>(p, s) : p.W == 32 ? launch_tr_w<32>(p, s) : launch_tr_w<16>(p, s);
+    if (p.mode == IG_CONV3_UP) return p.OW == 64 ? launch_tr_up64<DM_TR_UP_UNROLL>(p, s) : hipErrorInvalidValue;
+    return p.OW == 64 ? launch_tr_w<64>(p, s) : p.OW == 32 ? launch_tr_w<32>(p, s) : launch_tr_w<16>(p, s);
 }
 
 }  // namespace dm

@@ -285,11 +285,12 @@ void igemm_kernel(IGemmParams p) {
         for (int k = 0; k < XI; ++k) {
             long long pix = -1;
             if (xn[k] >= 0) {
-                const int ih = xoh[k] + dy - 1, iw = xow[k];
-                if (ih >= 0 && ih < p.H) {
-                    pix = ((long long)xn[k] * p.H + ih) * p.W + iw;
+                const int ih = xoh[k] + dy - 1, iw = xow[k];            // in output (= up-sampled) coordinates
+                if (ih >= 0 && ih < p.OH) {
+                    // IG_CONV3_UP (exact 2x): the row of the source image; the column is added per dx (neighbours are not adjacent)
+                    pix = (p.mode == IG_CONV3_UP) ? ((long long)xn[k] * p.H + (ih >> 1)) * p.W : ((long long)xn[k] * p.H + ih) * p.W + iw;
                     xlr |= ((iw >= 1) ? 1 : 0) << (2 * k);
-                    xlr |= ((iw + 1 < p.W) ? 2 : 0) << (2 * k);
+                    xlr |= ((iw + 1 < p.OW) ? 2 : 0) << (2 * k);
                 }
             }
             xpix[k] = pix;
@@ -305,7 +306,8 @@ void igemm_kernel(IGemmParams p) {
 #pragma unroll
         for (int k = 0; k < XI; ++k) {
             const bool ok = xpix[k] >= 0 && (ld_dx == 1 || ((xlr >> (2 * k + (ld_dx >> 1))) & 1) != 0);
-            xsrc[k] = ok ? base + (xpix[k] + ld_dx - 1) * cs + cho + lchunk : zero;
+            const long long px = (p.mode == IG_CONV3_UP) ? xpix[k] + ((xow[k] + ld_dx - 1) >> 1) : xpix[k] + ld_dx - 1;
+            xsrc[k] = ok ? base + px * cs + cho + lchunk : zero;
             xinc[k] = 0;
         }
         // weight offset of the NEXT k step relative to this one: dx + 1 = the next tap (+ Cin); after dx = 2 back to the first

@@ -977,3 +977,34 @@ def test_igemm_tap_reuse_tile(W, C1, C2, Cout, N):
         U.assert_close_fp16(U.to_nchw(y_plain[n:n + 1]), ref, f"tap-reuse conv3x3 n={n}")
         U.assert_close_fp16(U.to_nchw(y_temb[n:n + 1]), ref.half().float() + temb[n].float()[None, :, None, None], f"tap-reuse +temb n={n}")
         U.assert_close_fp16(U.to_nchw(y_res[n:n + 1]), ref.half().float() + U.to_nchw(res[n:n + 1].cpu().float()), f"tap-reuse +res n={n}")
+
+
+def test_igemm_tap_reuse_upsample():
+    """The tap-reuse tile on Upsample2D.conv (nearest 2x, then 3x3) onto a 64-pixel-wide image: against F.conv2d on the
+    F.interpolate'd input in fp32, and bit for bit against the 128-row tile's KO variant."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    N, H, W, C, Cout = 5, 32, 32, 640, 640
+    g = torch.Generator(device="cuda").manual_seed(61)
+    x = torch.randn(N, H, W, C, generator=g, device=d, dtype=torch.float32).half()
+    w = U.f16_randn(Cout, C, 3, 3, seed=62, scale=(9 * C) ** -0.5)
+    b = U.f16_randn(Cout, seed=63, scale=0.1)
+    wg, bg = U.pack_conv3(w).to(d), b.to(d)
+    out = {}
+    try:
+        assert lib.dm_set_option(b"tap_reuse", 2) == 0          # (the up-sampling layer is not in the default rule: +3 %)
+        for big in (1, 0):
+            assert lib.dm_set_option(b"igemm_big", big) == 0
+            out[big] = U.op_igemm(x, wg, bg, mode=3, OH=2 * H, OW=2 * W)
+        assert lib.dm_set_option(b"tap_reuse", 0) == 0
+        std = U.op_igemm(x, wg, bg, mode=3, OH=2 * H, OW=2 * W)
+    finally:
+        lib.dm_set_option(b"igemm_big", -1)
+        lib.dm_set_option(b"tap_reuse", 1)
+    assert torch.equal(out[1], out[0]), f"tap-reuse up-sampling tile != 128-row KO tile: {(out[1].float() - out[0].float()).abs().max().item():.3e}"
+    for n in (0, N - 1):
+        up = F.interpolate(U.to_nchw(x[n:n + 1].cpu().float()), scale_factor=2, mode="nearest")
+        ref = F.conv2d(up, w.float(), b.float(), padding=1)
+        U.assert_close_fp16(U.to_nchw(out[1][n:n + 1]), ref, f"tap-reuse upsample conv n={n}")
+    assert (std.float() - out[1].float()).abs().max().item() <= 2e-3 * std.float().abs().max().item()
