@@ -3,7 +3,9 @@
 // tile's image rows with a one-pixel halo left and right ((W + 2) LDS rows per image row: 264 / 272 / 288 rows for W = 64 / 32 /
 // 16), the B-fragment read of tap dx being the same read shifted by dx rows.  Per three k steps the LDS-DMA moves 33-36 KiB of
 // activations + 3 x 40 KiB of weights instead of 3 x 72 KiB (6.2-6.5 instead of 9 LDS-DMA instructions per wave and step):
-// tools/probes/probe_feed.hip prices a k step at 1.58-1.65 us instead of 1.87-1.89 (profiles/r03_probe_feed_tap_reuse.txt).
+// tools/probes/probe_feed.hip prices a k step at 1.58-1.65 us instead of 1.87-1.89 (profiles/r03_probe_feed_tap_reuse.txt); the kernel
+// gets a third to a half of that: -7..-9 % per launch on the 64-pixel-wide time-embedding layers, -6 % with a residual, -4..-5 % on the
+// 32-pixel-wide time-embedding layers, nothing at 16 pixels (profiles/r03_ab_tap_reuse.txt; the rule is tap_reuse_layer(), igemm.hip).
 // Same arithmetic, k order and epilogue as igemm_tile.h's KO variant (igemm_ko.hip): bit-identical tiles, so which of the two
 // kernels computes a row never shows in a result.  Everything else (tile hand-out, continuous k stream across tiles, epilogue
 // straight from the accumulators, counted vmcnt at the tile top) is igemm_pers_tile.h's; reached from `unet(...)`,
@@ -18,7 +20,7 @@ typedef volatile __attribute__((address_space(3))) int* lds_word_t;    // a vola
 
 // EXTRA: PX_NONE / PX_TEMB / PX_RES as in igemm_pers_tile.h; WIMG: image width = output width (64, 32 or 16)
 // UNROLL: the k loop walks (dy, slab) pairs with its three dx steps unrolled (compile-time dx: no branch and no run-time piece index in
-// the MFMA stream; 5-7 % faster) — for the instantiations the register allocator handles without spilling accumulators inside the
+// the MFMA stream; 3-5 % faster) — for the instantiations the register allocator handles without spilling accumulators inside the
 // loop, which launch_tr_w lists and tests/test_abi.py checks against the compiled ISA; the others run the run-time-dx loop.
 // UP: the convolution runs on the nearest-2x up-sampled image (Upsample2D): the stage rows are up-sampled coordinates, a row's source
 // pixel is (ih >> 1, iw >> 1) of the H x W input.
