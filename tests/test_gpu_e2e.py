@@ -726,3 +726,30 @@ def test_hipgraph_replay_is_bit_identical(engine):
     assert launches >= 2, launches
     assert all(torch.equal(o, want) for o in outs)
     assert torch.equal(got2, want2)
+
+
+def test_tap_reuse_option_end_to_end(engine):
+    """Option "tap_reuse" end to end at a 64x64 latent (the geometry whose 64- and 32-pixel-wide convolutions take the tap-reuse
+    tile): the loss grids with the option off / on (default rule) / on for every eligible layer agree to fp32 summation order,
+    a sample's bits do not depend on the batch it rides in with the option on, and the default stays what the oracle tests saw."""
+    lib = engine.lib
+    x, eps, t, c = _inputs(64, 64, 3, flow="f32")
+    dev = engine.device
+    xd, ed, td = x.to(dev), eps.to(dev), t.to(dev)
+    engine.set_prompts(c)
+    out = {}
+    try:
+        for v in (1, 0, 2):
+            assert lib.dm_set_option(b"tap_reuse", v) == 0
+            out[v] = engine.score_conds(xd, ed, td, 2, latent_dtype=torch.float32).clone()
+        assert lib.dm_set_option(b"tap_reuse", 1) == 0
+        one = engine.score_conds(xd, ed[:1], td[:1], 2, latent_dtype=torch.float32).clone()      # rows (cond 0, draw 0), (cond 1, draw 0)
+    finally:
+        lib.dm_set_option(b"tap_reuse", 1)
+    n = eps.shape[0]                                 # draws: row (cond k, draw i) = k * n + i
+    assert torch.equal(one[0], out[1][0]) and torch.equal(one[1], out[1][n]), "a draw's loss depends on the batch with tap_reuse on"
+    for v in (0, 2):
+        rel = ((out[v] - out[1]).norm() / out[1].norm()).item()
+        print(f"tap_reuse {v} vs 1: rel-L2 {rel:.2e}")
+        assert rel < 2.5e-3, rel          # a pure reordering of fp32 partial sums: the oracle's own noise floor is 1.1-1.2e-3 (tests/test_oracle.py)
+    assert not torch.equal(out[0], out[1])          # (the k order differs: equal bits would mean the option does nothing)
