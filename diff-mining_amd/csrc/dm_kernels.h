@@ -112,13 +112,13 @@ inline bool igemm_pers_ok(const IGemmParams& p) {
 
 // Layers whose k steps run (dy, 64-channel slab, dx) so that the persistent tile can reuse one activation stage for the three
 // horizontal taps (igemm_pers_tr.hip; the 128-row tile has the same k order as its KO variant, igemm_ko.hip): plain 3x3 stride-1
-// convolutions on 16 / 32 / 64 pixel wide images whose samples are whole 256-row tiles.  A property of the LAYER and the sample
+// convolutions on 16 / 32 / 64 / 128 pixel wide images whose samples are whole 256-row tiles.  A property of the LAYER and the sample
 // geometry, never of the batch: a sample's bits do not depend on the batch it rides in.
 inline bool igemm_ko_layer(const IGemmParams& p) {
     const bool same = p.mode == IG_CONV3 && p.H == p.OH && p.W == p.OW;
     const bool up2 = p.mode == IG_CONV3_UP && p.OH == 2 * p.H && p.OW == 2 * p.W && !p.temb && !p.res;     // nearest 2x, then the convolution
     return (same || up2) && p.epi == EPI_PLAIN && !p.ln_s && p.ksplit <= 1 && !p.X3 && !p.w_sample_stride &&
-           (p.OW == 16 || p.OW == 32 || p.OW == 64) && (p.OH * p.OW) % 256 == 0 &&
+           (p.OW == 16 || p.OW == 32 || p.OW == 64 || p.OW == 128) && (p.OH * p.OW) % 256 == 0 &&
            p.Cout % 160 == 0 && p.Cin % 64 == 0 && p.C1 % 64 == 0;
 }
 

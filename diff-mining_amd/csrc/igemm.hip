@@ -187,7 +187,7 @@ static bool tap_reuse_layer(const IGemmParams& p) {
     const int on = option(OPT_TAP_REUSE);
     if (on == 0 || !igemm_ko_layer(p)) return false;
     if (p.mode == IG_CONV3_UP) return on == 2 && p.OW == 64;           // Upsample2D.conv onto 64 pixels: built, +3 % (1.33 PFLOP/s without it: its taps share source pixels), A/B only
-    return on == 2 || p.OW == 64 || (p.OW == 32 && p.temb != nullptr);
+    return on == 2 || p.OW >= 64 || (p.OW == 32 && p.temb != nullptr);       // (128 wide: the first level of a 1024-pixel image, the X-ray configuration)
 }
 
 static hipError_t launch_small(const IGemmParams& p, hipStream_t s) {

@@ -176,7 +176,7 @@ void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
         const int a_row_off = (wc * 80 * CH + l15) * 128;
         const int koff0 = ((lg ^ (l15 & 7)) << 4), koff1 = (((4 + lg) ^ (l15 & 7)) << 4);
         // B rows: pixel (wp * 64 + 16 j + l15) of the tile sits in LDS row rb + cj + l15, cj = (16 j / W) (W + 2) + 16 j % W
-        const int rb = wp * (64 / WIMG) * PITCH + dx + l15;
+        const int rb = ((wp * 64) / WIMG) * PITCH + (wp * 64) % WIMG + dx + l15;
         int boff[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -471,6 +471,8 @@ template <int EXTRA, int WIMG> struct TrUnroll { static constexpr bool value = f
 #if !defined(DM_TR_NO_UNROLL) && !defined(DM_TR_ALL_UNROLL)
 template <> struct TrUnroll<PX_NONE, 64> { static constexpr bool value = true; };
 template <> struct TrUnroll<PX_TEMB, 64> { static constexpr bool value = true; };
+template <> struct TrUnroll<PX_NONE, 128> { static constexpr bool value = true; };
+template <> struct TrUnroll<PX_TEMB, 128> { static constexpr bool value = true; };
 template <> struct TrUnroll<PX_TEMB, 32> { static constexpr bool value = true; };
 template <> struct TrUnroll<PX_TEMB, 16> { static constexpr bool value = true; };
 #endif
@@ -532,7 +534,7 @@ bool igemm_pers_tr_ok(const IGemmParams& p) {
 hipError_t launch_igemm_pers_tr(const IGemmParams& p, hipStream_t s) {
     if (!igemm_ko_layer(p) || !igemm_pers_tr_ok(p)) return hipErrorInvalidValue;
     if (p.mode == IG_CONV3_UP) return p.OW == 64 ? launch_tr_up64<DM_TR_UP_UNROLL>(p, s) : hipErrorInvalidValue;
-    return p.OW == 64 ? launch_tr_w<64>(p, s) : p.OW == 32 ? launch_tr_w<32>(p, s) : launch_tr_w<16>(p, s);
+    return p.OW == 128 ? launch_tr_w<128>(p, s) : p.OW == 64 ? launch_tr_w<64>(p, s) : p.OW == 32 ? launch_tr_w<32>(p, s) : launch_tr_w<16>(p, s);
 }
 
 }  // namespace dm

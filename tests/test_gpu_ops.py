@@ -937,7 +937,7 @@ def test_ff2_residual_proj_out_as_one_gemm(M, C):
     print(f"ff2 + proj_out as one GEMM M={M} C={C}: rel-L2 vs fp32 {r:.2e} (the unfused pair: {ru:.2e}), max|err|/max|ref| {m:.2e}")
 
 
-@pytest.mark.parametrize("W,C1,C2,Cout,N", [(64, 320, 0, 320, 6), (64, 640, 320, 320, 3), (32, 640, 0, 640, 10), (32, 1280, 640, 640, 6),
+@pytest.mark.parametrize("W,C1,C2,Cout,N", [(128, 320, 0, 320, 2), (128, 320, 320, 320, 1), (64, 320, 0, 320, 6), (64, 640, 320, 320, 3), (32, 640, 0, 640, 10), (32, 1280, 640, 640, 6),
                                            (16, 1280, 0, 1280, 24), (16, 640, 0, 1280, 17)])
 def test_igemm_tap_reuse_tile(W, C1, C2, Cout, N):
     """igemm_pers_tr.hip (option tap_reuse; 2 = every eligible width): the 3x3 stride-1 convolutions with the k order (dy, slab, dx) and ONE activation
