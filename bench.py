@@ -159,7 +159,13 @@ def main():
     if eng is not None:
         eng.prof_enable(False)
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    rank_ms = [dt / args.steps * 1e3]
     if world > 1:
+        # every rank's own clock over the same barrier-bracketed region, so a straggler shows in the line; the reported time
+        # is the MAX over ranks
+        each = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(each, tt)
+        rank_ms = [e.item() / args.steps * 1e3 for e in each]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = tt.item()
 
@@ -228,6 +234,16 @@ def main():
         }
         if eng is not None:
             out["engine_stats"] = eng.stats()
+        out["roofline"]["traffic_recorded_from"] = TRAFFIC_SOURCE.get("file")
+        if world > 1:
+            out["ranks_seen"] = dist.get_world_size()
+            out["backend"] = dist.get_backend()
+            try:
+                out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if not STUB else None
+            except Exception as ex:                          # a missing version string must not cost the measurement
+                out["rccl_version"] = f"unavailable ({type(ex).__name__})"
+            out["rank_ms_per_step"] = {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3),
+                                       "all": [round(v, 3) for v in rank_ms]}
         if STUB:
             out["data"] = "stub (DM_BENCH_STUB=1: launcher / gather path only, no engine)"
         if not args.no_cpu_baseline and world == 1 and not STUB:
@@ -237,15 +253,20 @@ def main():
         dist.destroy_process_group()
 
 
+TRAFFIC_SOURCE = {}
+
+
 def hbm_traffic_per_launch(launches_per_step):
     """HBM bytes per igemm launch (one launch_igemm call = one GEMM of the network; the head / tail row split makes some
     of them two kernel dispatches) from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950
     correction, + WRITE_SIZE): family bytes per step / launches per step.  rocprofv3 cannot run inside this process,
     so the number is the recorded one for this kernel build, or None when no record exists."""
-    for tag in ("r03_final", "r02_final"):          # the newest record of this kernel build that is committed
+    for tag in ("r04_final", "r03_final", "r02_final"):          # the newest record that is committed
         try:
             with open(os.path.join(ROOT, "profiles", tag + "_pmc.json")) as f:
                 k = json.load(f)["kernels"]["igemm_family"]
+            # a RECORDED value (separate rocprofv3 --pmc passes of this command), not measured in this run: the line says which file
+            TRAFFIC_SOURCE["file"] = f"profiles/{tag}_pmc.json"
             return round((k["fetch_GB_per_step"] + k["write_GB_per_step"]) * 1e9 / launches_per_step)
         except Exception:
             continue

@@ -187,7 +187,9 @@ hipError_t launch_typicality(const void* loss, int is_f16, int n_images, int n_d
 // AvgPool2d((kx, ky), stride 1); tmp [H][W-ky+1], out [H-kx+1][W-ky+1] fp32
 hipError_t launch_typicality_image(const float* map, int h, int w, int H, int W, int kx, int ky, float* tmp,
                                    float* out, hipStream_t s);
-
+// consumers' normalisations of an fp32 map (cluster.py:32-47, utils.py:14-20,130): mode 1 signed -> [0,1], 2 / max|.|,
+// 3 positive only, 4 split (out2 = the negative part); mm = 2 floats of scratch (min, max)
+hipError_t launch_map_normalize(const float* map, long long n, int mode, float* mm, float* out, float* out2, hipStream_t s);
 
 // ---- VAE encoder (vae.hip) ---------------------------------------------------------------------
 // RGB image NCHW fp16 -> im2col rows of encoder.conv_in: out [B*H*W][64], k = c*9 + ky*3 + kx (k < 27), zero after

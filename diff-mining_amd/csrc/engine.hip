@@ -1872,6 +1872,19 @@ int dm_typicality_image(dm_engine* e, const void* loss_dev, int loss_is_f16, int
     return 0;
 }
 
+int dm_normalize_map(dm_engine* e, const void* map_dev, int64_t n, int mode, void* work_dev, void* out_dev, void* out_neg_dev,
+                     void* stream) {
+    if (!e) return 1;
+    if (!map_dev || !work_dev || !out_dev) DM_FAIL(e, "dm_normalize_map: null argument");
+    if (n < 1) DM_FAIL(e, "dm_normalize_map: empty map");
+    if (mode < DM_NORM_SIGNED || mode > DM_NORM_SPLIT) DM_FAIL(e, "dm_normalize_map: unknown mode %d", mode);
+    if (mode == DM_NORM_SPLIT && !out_neg_dev) DM_FAIL(e, "dm_normalize_map: DM_NORM_SPLIT needs out_neg_dev");
+    DM_HIP(e, hipSetDevice(e->device));
+    DM_HIP(e, launch_map_normalize((const float*)map_dev, (long long)n, mode, (float*)work_dev, (float*)out_dev, (float*)out_neg_dev,
+                                   (hipStream_t)stream));
+    return 0;
+}
+
 int dm_prof_enable(dm_engine* e, int on) {
     if (!e) return 1;
     e->prof = on != 0;

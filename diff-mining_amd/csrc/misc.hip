@@ -264,6 +264,51 @@ __global__ void colsum_kernel(const float* __restrict__ tmp, int H, int OWd, int
     out[i] = acc * inv;
 }
 
+// Consumers' normalisations of an image-space typicality map (fp32, numpy semantics restated in fp32 IEEE arithmetic):
+//   mode 1  `normalize(dm)` of cluster.py:32-47 as `load_typicality_norm` (cluster.py:112-123) calls it: negatives / |min|,
+//           positives / max, then (dm + 1) / 2
+//   mode 2  `dm / np.max(np.abs(dm))`: `d_compute` (utils.py:122-134) and utils.normalize (utils.py:14-20)
+//   mode 3  positive_only: max(dm, 0) / max(max(dm, 0))  (cluster.py:39-42, utils.py:16-19)
+//   mode 4  positive_only == 'split' (cluster.py:34-36): d = dm / |max(dm)|; out = clip(d, 0, 1), out2 = -clip(d, -1, 0)
+// pass 1: min / max / max|.| of the map (order-independent, so any reduction tree gives numpy's value); pass 2: elementwise.
+__global__ void map_minmax_kernel(const float* __restrict__ x, long long n, float* __restrict__ mm) {
+    __shared__ float smin[1024], smax[1024];
+    float lo = INFINITY, hi = -INFINITY;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) { const float v = x[i]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+    smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + o]);
+            smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { mm[0] = smin[0]; mm[1] = smax[0]; }
+}
+
+__global__ void map_normalize_kernel(const float* x, long long n, int mode, const float* __restrict__ mm,
+                                     float* out, float* out2) {              // out may alias x (same index read, then written)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float lo = mm[0], hi = mm[1];
+    float v = x[i];
+    if (mode == 1) {
+        if (v < 0.f) v = __fdiv_rn(v, fabsf(lo));
+        // numpy re-reads the maximum after the negatives were rescaled: positives are untouched by that, so it is `hi`
+        if (v > 0.f) v = __fdiv_rn(v, hi);
+        out[i] = __fdiv_rn(v + 1.0f, 2.0f);
+    } else if (mode == 2) {
+        out[i] = __fdiv_rn(v, fmaxf(fabsf(lo), fabsf(hi)));
+    } else if (mode == 3) {
+        out[i] = __fdiv_rn(fmaxf(v, 0.f), fmaxf(hi, 0.f));
+    } else {
+        const float d = __fdiv_rn(v, fabsf(hi));
+        out[i] = fminf(fmaxf(d, 0.f), 1.f);
+        out2[i] = -fminf(fmaxf(d, -1.f), 0.f);
+    }
+}
+
 __global__ void mean_reduce_kernel(const float* __restrict__ map, int n, float* __restrict__ out) {
     __shared__ double sh[256];
     map += (size_t)blockIdx.x * n;
@@ -389,6 +434,13 @@ hipError_t launch_typicality_image(const float* map, int h, int w, int H, int W,
     hipLaunchKernelGGL(upsample_rowsum_kernel, dim3((H * OWd + 255) / 256), dim3(256), 0, s, map, h, w, H, W, ky, tmp);
     hipLaunchKernelGGL(colsum_kernel, dim3((OHd * OWd + 255) / 256), dim3(256), 0, s, tmp, H, OWd, kx,
                        1.0f / ((float)kx * (float)ky), out);
+    return hipGetLastError();
+}
+
+hipError_t launch_map_normalize(const float* map, long long n, int mode, float* mm, float* out, float* out2, hipStream_t s) {
+    if (n <= 0 || mode < 1 || mode > 4 || (mode == 4 && !out2)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(map_minmax_kernel, dim3(1), dim3(1024), 0, s, map, n, mm);
+    hipLaunchKernelGGL(map_normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, map, n, mode, mm, out, out2);
     return hipGetLastError();
 }
 

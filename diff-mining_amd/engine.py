@@ -25,7 +25,7 @@ SYMBOLS = [
     "dm_engine_load_vae_weight", "dm_engine_finalize_vae", "dm_vae_encode", "dm_op_attention512", "dm_patch_embed",
     "dm_engine_load_clip_weight", "dm_engine_finalize_clip", "dm_clip_encode", "dm_op_igemm_splitk",
     "dm_op_ln_stats", "dm_op_igemm_ln", "dm_reduce_typicality_batched", "dm_op_igemm_tile", "dm_op_igemm_head_rows", "dm_set_option",
-    "dm_engine_reserve", "dm_engine_stats", "dm_op_groupnorm_conv1x1", "dm_op_igemm_shortcut",
+    "dm_engine_reserve", "dm_engine_stats", "dm_op_groupnorm_conv1x1", "dm_op_igemm_shortcut", "dm_normalize_map",
 ]
 
 
@@ -95,6 +95,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if hasattr(lib, "dm_engine_reserve"):        # absent only from older A/B libraries loaded through DM_ENGINE_LIB
         lib.dm_engine_reserve.argtypes = [vp, i32, i32, i32, i32, i32, vp]
         lib.dm_engine_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+    if hasattr(lib, "dm_normalize_map"):
+        lib.dm_normalize_map.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
     if path is None:
         _lib = lib
     return lib
@@ -451,6 +453,24 @@ class UNetEngine:
                                                  C.c_void_p(work.data_ptr()), C.c_void_p(out.data_ptr()), self._stream()),
                     "dm_typicality_image")
         return out
+
+    NORM_MODES = {"signed": 1, "maxabs": 2, "positive": 3, "split": 4}
+
+    def normalize_map(self, dm, mode: str = "signed"):
+        """The consumers' normalisations of an image-space map (fp32, on the GPU, numpy's fp32 arithmetic): "signed" =
+        `normalize(dm)` of cluster.py:32-47 as `load_typicality_norm` calls it (cluster.py:112-123); "maxabs" = `dm /
+        np.max(np.abs(dm))` (`d_compute`, utils.py:130; utils.py:14-20); "positive" = positive_only=True; "split" =
+        positive_only='split' (returns the pair)."""
+        torch = self._torch
+        dm = dm.to(self.device, torch.float32).contiguous()
+        out = torch.empty_like(dm)
+        neg = torch.empty_like(dm) if mode == "split" else None
+        work = torch.empty(2, dtype=torch.float32, device=self.device)
+        self._check(self.lib.dm_normalize_map(self._h, C.c_void_p(dm.data_ptr()), dm.numel(), self.NORM_MODES[mode],
+                                              C.c_void_p(work.data_ptr()), C.c_void_p(out.data_ptr()),
+                                              C.c_void_p(neg.data_ptr()) if neg is not None else None, self._stream()),
+                    "dm_normalize_map")
+        return (out, neg) if mode == "split" else out
 
     def patch_embed(self, feat, boxes):
         """DIFT patch descriptors (cluster.py:291-299): feat [C,h,w] or [1,C,h,w] fp32 (the ensemble mean of

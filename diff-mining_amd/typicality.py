@@ -12,6 +12,8 @@
     D.rescale                compute.py:165-180       TypicalityScorer.rescale
     D.compute / __call__ / exists  compute.py:182-202 TypicalityScorer.compute / __call__ / exists
     Typicallity.compute      xray/compute.py:210-218  TypicalityScorer.heatmap / typicality_scalar
+    Cluster.load_typicality(_norm) cluster.py:112-137 TypicalityScorer.load_typicality / load_typicality_norm
+    d_compute                utils.py:122-134         TypicalityScorer.d_compute
     unet(sample, t, c).sample compute.py:100          UNetCallable (assignable over `pipe.unet`)
 
 Same names, argument meaning and output layout ([N, n_cond, 4, h, w] float16, cond 0 = c,
@@ -88,20 +90,54 @@ class UNetCallable:
 
     def __init__(self, engine: UNetEngine):
         self.engine = engine
-        self._ctx_key = None
+        self._ctx_key = None                # [P, 77*768] fp16: the distinct prompts registered with the engine
         self._ctx_generation = -1
+        self._key_hash = None               # [P] int64 row hashes of _ctx_key
+        self._hash_w = None
+        self._last = None                   # (source tensor, its _version, slots): the identical-object fast path
+        self.stats = {"identity_hits": 0, "key_hits": 0, "unique_calls": 0}
+
+    def _row_hash(self, flat):
+        """64-bit hash per row of an fp16 [n, L] matrix (L even): the rows as int32 words against fixed odd weights."""
+        words = flat.view(torch.int32).to(torch.int64)
+        if self._hash_w is None or self._hash_w.shape[0] != words.shape[1] or self._hash_w.device != flat.device:
+            g = torch.Generator().manual_seed(0x5D1F)
+            self._hash_w = (torch.randint(-(1 << 40), 1 << 40, (words.shape[1],), generator=g, dtype=torch.int64) | 1).to(flat.device)
+        return (words * self._hash_w).sum(1)
 
     def _slots_for(self, c: torch.Tensor):
-        flat = c.reshape(c.shape[0], -1)
-        uniq, inv = torch.unique(flat, dim=0, return_inverse=True)
+        """Prompt slot of every row of c [n, 77, 768] (fp16, on the device).  Three paths, cheapest first:
+          1. the same tensor object, unmodified, as the previous call (a caller that keeps its `c`): nothing runs;
+          2. every row equals one of the prompts already registered (the reference builds a fresh `torch.cat` of the same
+             n_cond embeddings for every chunk of every image, compute.py:152): a row hash finds the candidate slot, ONE exact
+             comparison against the registered rows confirms it — no sort, one scalar read-back;
+          3. otherwise `torch.unique(dim=0)` (sort + sync) and a new `set_prompts`."""
+        eng = self.engine
         # the engine's K/V cache is shared: anyone else's set_prompts (SDFeaturizer, compute_losses, a direct
-        # call) bumps `prompt_generation`, which invalidates this cache key
-        if (self._ctx_key is None or self._ctx_generation != self.engine.prompt_generation
-                or self._ctx_key.shape != uniq.shape or not torch.equal(self._ctx_key, uniq)):
-            self.engine.set_prompts(uniq.reshape(uniq.shape[0], c.shape[1], c.shape[2]))
+        # call) bumps `prompt_generation`, which invalidates every cache here
+        valid = self._ctx_key is not None and self._ctx_generation == eng.prompt_generation
+        if valid and self._last is not None and self._last[0] is c and self._last[1] == c._version:
+            self.stats["identity_hits"] += 1
+            return self._last[2]
+        flat = c.reshape(c.shape[0], -1)
+        inv = None
+        if valid and flat.shape[1] == self._ctx_key.shape[1] and flat.shape[1] % 2 == 0 and flat.dtype == torch.float16:
+            cand = (self._row_hash(flat)[:, None] == self._key_hash[None, :]).to(torch.uint8).argmax(1)
+            if bool((flat == self._ctx_key[cand]).all()):
+                inv = cand.to(torch.int32)
+                self.stats["key_hits"] += 1
+        if inv is None:
+            self.stats["unique_calls"] += 1
+            uniq, inv = torch.unique(flat, dim=0, return_inverse=True)
+            eng.set_prompts(uniq.reshape(uniq.shape[0], c.shape[1], c.shape[2]))
             self._ctx_key = uniq
-            self._ctx_generation = self.engine.prompt_generation
-        return inv.to(torch.int32)
+            self._key_hash = self._row_hash(uniq) if uniq.shape[1] % 2 == 0 and uniq.dtype == torch.float16 else None
+            self._ctx_generation = eng.prompt_generation
+            inv = inv.to(torch.int32)
+            if self._key_hash is None:
+                self._ctx_key = None
+        self._last = (c, c._version, inv)
+        return inv
 
     def __call__(self, sample, timestep, encoder_hidden_states, **_):
         eng = self.engine
@@ -285,6 +321,15 @@ class TypicalityScorer:
         if kx == 1 or ky == 1:
             kx = ky = 1
         return self.engine.typicality_image(grid, image_size, kx, ky)
+
+    def load_typicality_norm(self, grid, image_size):
+        """`Cluster.load_typicality_norm` (cluster.py:112-123): the per-pixel map `(dm[:, 1] - dm[:, 0]).mean(0)` at the
+        image size, then `normalize` (cluster.py:32-47) -> [H, W] fp32 in [0, 1] on the GPU."""
+        return self.engine.normalize_map(self.engine.typicality_image(grid, image_size, 1, 1), "signed")
+
+    def d_compute(self, grid, h: int, w: int, x_start: int, y_start: int, x_end: int, y_end: int):
+        """`d_compute` (utils.py:122-134): the per-pixel map at (h, w) divided by its max |.|, cropped to the box."""
+        return self.engine.normalize_map(self.engine.typicality_image(grid, (h, w), 1, 1), "maxabs")[x_start:x_end, y_start:y_end]
 
     def pixel_heatmap(self, grid, image_size):
         """`Typicallity.compute` dm_pixel (xray/compute.py:210-218): per-pixel E_N[L_null - L_c] at image size."""

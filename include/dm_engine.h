@@ -137,6 +137,18 @@ int dm_typicality_image(dm_engine* e, const void* loss_dev, int loss_is_f16, int
                         int h, int w, int img_h, int img_w, int kx, int ky, void* work_dev, void* out_dev,
                         void* stream);
 
+/* The consumers' normalisations of an image-space map (fp32 [n] on the device, e.g. dm_typicality_image's output with
+ * kx = ky = 1), in numpy's fp32 arithmetic:
+ *   DM_NORM_SIGNED    `normalize(dm)` of diffmining/typicality/cluster.py:32-47 as `Cluster.load_typicality_norm`
+ *                     (cluster.py:112-123) calls it: negatives / |min|, positives / max, (dm + 1) / 2
+ *   DM_NORM_MAXABS    `dm / np.max(np.abs(dm))`: `d_compute` (diffmining/typicality/utils.py:122-134) and utils.py:14-20
+ *   DM_NORM_POSITIVE  positive_only=True (cluster.py:39-42, utils.py:16-19): max(dm, 0) / max(max(dm, 0))
+ *   DM_NORM_SPLIT     positive_only='split' (cluster.py:34-36): d = dm / |max(dm)|; out = clip(d, 0, 1), out_neg = -clip(d, -1, 0)
+ * out_dev (and out_neg_dev for DM_NORM_SPLIT) fp32 [n]; out_dev may alias map_dev.  work_dev: 2 floats of scratch. */
+enum { DM_NORM_SIGNED = 1, DM_NORM_MAXABS = 2, DM_NORM_POSITIVE = 3, DM_NORM_SPLIT = 4 };
+int dm_normalize_map(dm_engine* e, const void* map_dev, int64_t n, int mode, void* work_dev, void* out_dev,
+                     void* out_neg_dev, void* stream);
+
 /* Profiling support for bench.py: when enabled, every launch of the dominant (implicit-GEMM)
  * kernel is bracketed by hipEvents on the launch stream.  dm_prof_read synchronises and returns
  * the accumulated kernel milliseconds, launch count and algorithmic FLOPs since the last reset. */

@@ -357,6 +357,44 @@ def load_typicality(grid: torch.Tensor, image_size, kx: int, ky: int) -> torch.T
     return -d.squeeze(1).mean(dim=0)
 
 
+def normalize_map(dm, mode: str = "signed"):
+    """The consumers' normalisations of a map (numpy fp32, restated): "signed" = `normalize(dm)` of cluster.py:32-47 with
+    positive_only=False (negatives / |min|, positives / max, (dm + 1) / 2), "positive" = positive_only=True (cluster.py:39-42,
+    utils.py:16-19), "split" = positive_only='split' (cluster.py:34-36), "maxabs" = `dm / np.max(np.abs(dm))` (utils.py:14-20,
+    `d_compute` utils.py:130).  Pinned to the reference's own functions by tests/golden/consumers_ref.npz."""
+    import numpy as np
+    dm = np.array(dm, dtype=np.float32, copy=True)
+    if mode == "split":
+        dm = dm / np.abs(np.max(dm))
+        return np.clip(dm, 0, 1), -np.clip(dm, -1, 0)
+    if mode == "positive":
+        dm = np.maximum(dm, 0)
+        return dm / np.max(dm)
+    if mode == "maxabs":
+        return dm / np.max(np.abs(dm))
+    assert mode == "signed", mode
+    lo = np.abs(np.min(dm))
+    neg = dm < 0
+    dm[neg] = dm[neg] / lo
+    pos = dm > 0
+    dm[pos] = dm[pos] / np.max(dm)
+    return (dm + np.float32(1)) / np.float32(2.0)
+
+
+def load_typicality_norm(grid: torch.Tensor, image_size):
+    """`Cluster.load_typicality_norm` (cluster.py:112-123): mean over C, bilinear to (H, W), `(dm[:, 1] - dm[:, 0]).mean(0)`,
+    `normalize`.  grid [N,2,4,h,w] -> numpy [H, W] fp32 in [0, 1]."""
+    dm = F.interpolate(grid.float().mean(dim=2), tuple(image_size), mode="bilinear")
+    return normalize_map((dm[:, 1] - dm[:, 0]).mean(dim=0).numpy(), "signed")
+
+
+def d_compute(grid: torch.Tensor, h: int, w: int, x_start: int, y_start: int, x_end: int, y_end: int):
+    """`d_compute` (utils.py:122-134): the same per-pixel map at (h, w), divided by its max |.|, cropped."""
+    dm = F.interpolate(grid.float().mean(dim=2), (h, w), mode="bilinear")
+    dm = (dm[:, 1] - dm[:, 0]).mean(dim=0).numpy()
+    return normalize_map(dm, "maxabs")[x_start:x_end, y_start:y_end]
+
+
 def typicality_scalar(grid: torch.Tensor) -> torch.Tensor:
     """T(x|c) = mean over pixels of `typicality_map` (intent of cluster.py:517-531)."""
     return typicality_map(grid).mean()

@@ -190,6 +190,64 @@ def test_unet_callable_cache_is_invalidated_by_other_set_prompts():
     assert eng.calls == 3 and eng.n_prompts == 2            # the stale K/V were replaced, not reused
 
 
+def test_unet_callable_slot_paths_identity_key_unique():
+    """the reference builds a fresh `torch.cat` of the same n_cond embeddings for every chunk
+    (compute.py:152): that must not sort (`torch.unique`) again — the rows are matched against the registered prompts by a
+    row hash + one exact comparison; the identical tensor object costs nothing; new content falls back to `unique`."""
+    eng = _FakeEngine()
+    u = T.UNetCallable(eng)
+    emb = torch.randn(2, 77, 768).half()
+    mk = lambda n: torch.cat([emb[k].unsqueeze(0).expand(n, -1, -1) for k in range(2)], 0)      # noqa: E731
+    c = mk(5)
+    s1 = u._slots_for(c)
+    assert u.stats == {"identity_hits": 0, "key_hits": 0, "unique_calls": 1} and eng.calls == 1
+    ref = torch.unique(c.reshape(10, -1), dim=0, return_inverse=True)[1].to(torch.int32)
+    assert torch.equal(s1, ref)
+    assert u._slots_for(c) is s1 and u.stats["identity_hits"] == 1                       # same object, unmodified
+    s2 = u._slots_for(mk(5))                                                             # fresh tensor, same rows
+    assert torch.equal(s2, ref) and u.stats["key_hits"] == 1 and eng.calls == 1
+    s3 = u._slots_for(mk(3))                                                             # another chunk size (ragged last chunk)
+    assert torch.equal(s3, torch.unique(mk(3).reshape(6, -1), dim=0, return_inverse=True)[1].to(torch.int32))
+    assert u.stats["key_hits"] == 2 and eng.calls == 1
+    c.mul_(1.0)                                                                          # in-place edit bumps _version
+    u._slots_for(c)
+    assert u.stats["identity_hits"] == 1 and u.stats["key_hits"] == 3                    # no identity hit on a modified tensor
+    other = mk(5)
+    other[7, 3, 5] += 1                                                                  # one row differs in one element
+    s4 = u._slots_for(other)
+    assert u.stats["unique_calls"] == 2 and eng.calls == 2 and eng.n_prompts == 3
+    assert torch.equal(s4, torch.unique(other.reshape(10, -1), dim=0, return_inverse=True)[1].to(torch.int32))
+    sub = u._slots_for(mk(4)[:4])                                                        # only prompt 0: a subset of the registered rows
+    assert u.stats["key_hits"] == 4 and eng.calls == 2 and len(set(sub.tolist())) == 1
+
+
+def test_dift_featurizer_registers_a_prompt_once():
+    """`SDFeaturizer.forward` recomputed the 16 blocks' K/V projections for every call; now only when the
+    engine does not already hold this prompt (and again after anyone else's set_prompts)."""
+    from diff_mining_amd.dift import SDFeaturizer
+
+    class _E(_FakeEngine):
+        def dift(self, noisy, t, slots, up_ft_index, ens):
+            return None, torch.zeros(1)
+    eng = _E()
+    f = SDFeaturizer.__new__(SDFeaturizer)
+    f.engine, f.device, f.tokenizer = eng, torch.device("cpu"), None
+    f._registered, f.prompt_registrations = None, 0
+    f.acp = torch.linspace(0.999, 0.01, 1000)
+    p = torch.randn(1, 77, 768)
+    lat = torch.randn(1, 4, 8, 8)
+    for _ in range(3):
+        f.forward(lat, p, ensemble_size=2, noise=torch.zeros(2, 4, 8, 8))
+    assert eng.calls == 1 and f.prompt_registrations == 1
+    f.forward(lat, p.clone(), ensemble_size=2, noise=torch.zeros(2, 4, 8, 8))            # equal values in a new tensor
+    assert eng.calls == 1
+    f.forward(lat, p + 1, ensemble_size=2, noise=torch.zeros(2, 4, 8, 8))                # another prompt
+    assert eng.calls == 2
+    eng.set_prompts(torch.zeros(2, 77, 768))                                             # somebody else re-registers
+    f.forward(lat, p + 1, ensemble_size=2, noise=torch.zeros(2, 4, 8, 8))
+    assert eng.calls == 4 and f.prompt_registrations == 3
+
+
 def test_slot_range_is_checked_before_the_call():
     from diff_mining_amd.engine import EngineError, UNetEngine
     e = UNetEngine.__new__(UNetEngine)
@@ -220,6 +278,11 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
     assert out["allgather_ms"] is not None and out["allgather_ms"] > 0   # the collective is timed on its own
     assert out["scores_checksum"] == sum(range(8)) + sum(100 + i for i in range(8))     # both ranks' images arrived, in order
+    # the N > 1 line says how many ranks really ran, on which backend, and every rank's own clock
+    assert out["ranks_seen"] == 2 and out["backend"] == "gloo" and "rccl_version" in out
+    rk = out["rank_ms_per_step"]
+    assert len(rk["all"]) == 2 and rk["min"] <= rk["max"] and abs(rk["max"] - out["ms_per_step"]) < 1e-2
+    assert "traffic_recorded_from" in out["roofline"]
     # a launcher that gives a different world size than --gpus asks for is refused, not silently reported
     env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,

@@ -14,6 +14,8 @@ import torch
 from diff_mining_amd import synth, unet_spec
 from oracle import unet_ref as R
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
 TINY = dict(block_out_channels=(32, 64, 64, 64), cross_attention_dim=48, num_heads=2, norm_num_groups=8)
 
 
@@ -410,3 +412,27 @@ def test_oracle_noise_floor_under_summation_order(sd15_weights_torch, hw, capsys
             assert rp_perm > 5e-4, rp_perm
     with capsys.disabled():
         print("\n" + "\n".join(lines))
+
+
+def test_consumer_reductions_match_the_reference_fixture():
+    """PINNED: the oracle's restatements of the grid consumers against outputs of the reference's OWN functions
+    (tests/golden/consumers_ref.npz, written by tests/make_golden_consumers.py from /root/reference: `Cluster.load_typicality`,
+    `load_typicality_norm`, `rank_images.compute`, `normalize` of cluster.py and utils.py, `pool`, `d_compute`)."""
+    f = np.load(os.path.join(GOLDEN, "consumers_ref.npz"))
+    for tag in ("a", "b", "c"):
+        grid = torch.from_numpy(f[f"{tag}_grid"])
+        H, W, k = (int(v) for v in f[f"{tag}_size"])
+        # same torch ops in the same order: bit-equal
+        assert np.array_equal(R.load_typicality(grid, (H, W), k, k).numpy(), f[f"{tag}_load_typicality"])
+        assert np.array_equal(R.load_typicality(grid, (H, W), 1, 1).numpy(), f[f"{tag}_load_typicality_k1"])
+        assert np.array_equal(R.load_typicality_norm(grid, (H, W)), f[f"{tag}_load_typicality_norm"])
+        assert np.array_equal(R.d_compute(grid, H, W, *[int(v) for v in f[f"{tag}_box"]]), f[f"{tag}_d_compute"])
+        # rank_images' scalar is the mean of the image-size map; the oracle's `typicality_scalar` is the mean of the latent map
+        # (bilinear interpolation with align_corners=False does not preserve the mean exactly): compare like with like
+        assert abs(float(R.load_typicality(grid, (H, W), 1, 1).numpy().mean()) - float(f[f"{tag}_rank_score"])) <= 1e-7
+    dm = f["a_load_typicality_k1"]
+    assert np.array_equal(R.normalize_map(dm, "positive"), f["a_cnorm_positive"])
+    sp = R.normalize_map(dm, "split")
+    assert np.array_equal(sp[0], f["a_cnorm_split_pos"]) and np.array_equal(sp[1], f["a_cnorm_split_neg"])
+    assert np.array_equal(R.normalize_map(dm, "maxabs"), f["a_unorm"])
+    assert np.array_equal(R.normalize_map(dm, "positive"), f["a_unorm_positive"])
