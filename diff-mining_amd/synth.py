@@ -110,11 +110,83 @@ def synth_tensor(name: str, shape, seed: int = 0) -> np.ndarray:
     return v.astype(np.float16).astype(np.float32).reshape(shape)
 
 
-def synth_state_dict(cfg: UNetConfig = SD15, seed: int = 0, dtype=np.float32) -> dict:
-    """name -> ndarray (fp16-representable values stored as `dtype`)."""
+def hash_uniform(name: str, n: int, seed: int = 0) -> np.ndarray:
+    """n values in [0, 1) for tensor `name` from the same integer hash (top 53 bits)."""
+    with np.errstate(over="ignore"):
+        key = np.uint64(fnv1a64(name)) ^ _splitmix64(np.array([seed], dtype=np.uint64) + _GOLDEN)[0]
+        bits = _splitmix64(key + np.arange(n, dtype=np.uint64) * _GOLDEN)
+    return (bits >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+
+
+# ---- "stress" weights: the same architecture OFF the benign operating point (VERDICT r03 #3) -------------------------------------
+# The default weights give zero-mean O(1) activations everywhere.  Real SD-1.5 checkpoints do not: channel scales spread over
+# decades, normalisation inputs carry |mean| >> std, a few channels are outliers.  mode="stress" builds that on the same hash:
+#   * every conv / linear: output-channel scales log-uniform over two decades (10^U(-1,1), RMS-normalised so the layer's output
+#     stays O(1) overall); attention q / k / v projections are left alone (outlier q.k products only saturate the softmax);
+#   * the layers that WRITE a normalisation input (conv_in, conv1, conv2, conv_shortcut, proj_in, proj_out, to_out, ff.net.2,
+#     down / up samplers): a common-sign bias of STRESS_BIAS x the layer's output RMS (sign per tensor) + three x50 outlier
+#     output channels per tensor;
+#   * norm gammas log-uniform over one decade, betas +-0.5.
+# tests/test_oracle.py::test_stress_weights_operating_point measures what this does at every GroupNorm / LayerNorm input
+# (|mean| / std per group or token, max |activation| < 65504).
+STRESS_BIAS = 10.0
+STRESS_OUTLIER = 50.0
+_NORM_WRITERS = ("conv_in", "conv1", "conv2", "conv_shortcut", "proj_in", "proj_out", "to_out.0", "ff.net.2", "downsamplers.0.conv",
+                 "upsamplers.0.conv")
+# x50 outlier channels only where the layer's INPUT is normalised (the transformer's inner stream feeds proj_out un-normalised, the
+# residual stream feeds conv_shortcut and the samplers un-normalised: outliers there compound to 50^2 ... and overflow fp16)
+_OUTLIER_WRITERS = ("conv_in", "conv1", "conv2", "proj_in")
+
+
+def _stress_tensor(name: str, shape, seed: int, stress_bias: float) -> np.ndarray:
+    leaf = name.rsplit(".", 1)[1]
+    mod = name.rsplit(".", 1)[0]
+    short = mod.split(".")[-1] if not mod.endswith(("to_out.0", "ff.net.2", "downsamplers.0.conv", "upsamplers.0.conv")) else \
+        next(w for w in _NORM_WRITERS if mod.endswith(w))
+    is_norm = "norm" in mod.rsplit(".", 1)[-1] and len(shape) == 1
+    n = int(np.prod(shape))
+    if is_norm:
+        if leaf == "weight":
+            v = 10.0 ** (hash_uniform(name + "#g", n, seed) - 0.5)                       # 0.32 .. 3.2
+            sign = np.where(hash_uniform(name + "#s", n, seed) < 0.15, -1.0, 1.0)       # a few negative gammas, as in real nets
+            v = v * sign
+        else:
+            v = 0.5 * hash_normal(name, n, seed)
+        return v.astype(np.float32).astype(np.float16).astype(np.float32).reshape(shape)
+    writer = short in _NORM_WRITERS
+    scaled = writer or short in ("proj", "linear_1", "linear_2", "time_emb_proj", "conv_out")      # not to_q / to_k / to_v
+    cout = shape[0]
+    sc = np.ones(cout)
+    if scaled and cout >= 32:
+        sc = 10.0 ** (2.0 * hash_uniform(mod + "#scale", cout, seed) - 1.0)
+        sc /= np.sqrt(np.mean(sc * sc))
+        if short in _OUTLIER_WRITERS:
+            idx = (hash_uniform(mod + "#outlier", 3, seed) * cout).astype(np.int64)
+            sc[idx] = STRESS_OUTLIER / np.sqrt(10.86)          # x50 the typical (median = 1 / 3.3) channel
+    if leaf == "bias":
+        v = 0.02 * hash_normal(name, n, seed) * sc
+        if writer:
+            sign = 1.0 if (short != "conv1" or hash_uniform(mod + "#sign", 1, seed)[0] < 0.5) else -1.0
+            v = v + sign * stress_bias * (1.0 + 0.05 * hash_normal(name + "#b", n, seed))
+        return v.astype(np.float32).astype(np.float16).astype(np.float32).reshape(shape)
+    fan_in = 1
+    for d in shape[1:]:
+        fan_in *= d
+    z = hash_normal(name, n, seed).reshape(cout, -1)
+    v = z * (sc / np.sqrt(float(fan_in)))[:, None]
+    return v.astype(np.float32).astype(np.float16).astype(np.float32).reshape(shape)
+
+
+def synth_state_dict(cfg: UNetConfig = SD15, seed: int = 0, dtype=np.float32, mode: str = "benign",
+                     stress_bias: float = STRESS_BIAS) -> dict:
+    """name -> ndarray (fp16-representable values stored as `dtype`).  mode "benign": fan-in-scaled zero-mean weights (O(1)
+    activations everywhere); "stress": per-channel scales over two decades, biased normalisation inputs, outlier channels
+    (`stress_bias`: the common-sign offset of the norm-writing layers' biases; tests/stress_weights.py passes 0 and calibrates
+    every offset against the measured spread of the normalisation input it feeds)."""
+    assert mode in ("benign", "stress"), mode
     out = {}
     for name, shape in unet_tensor_spec(cfg):
-        t = synth_tensor(name, shape, seed)
+        t = synth_tensor(name, shape, seed) if mode == "benign" else _stress_tensor(name, shape, seed, stress_bias)
         out[name] = t if dtype == np.float32 else t.astype(dtype)
     return out
 

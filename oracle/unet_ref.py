@@ -73,9 +73,19 @@ class _SD:
         return name in self.sd
 
 
-def _r(x: torch.Tensor, autocast: bool) -> torch.Tensor:
+# Rounding-point ablation (tests/test_oracle.py::test_rounding_point_ablation, tools/oracle_ablation.py): every fp16 rounding of
+# the autocast emulation carries a site tag; a tag in ROUND_OFF is skipped (that value stays fp32), so the contribution of one
+# class of roundings to the autocast-vs-fp32 distance can be named.  Empty by default = the emulation described above.
+#   "in"     operand of a conv / linear (what autocast casts to fp16 before the op)       "out"   result of a conv / linear
+#   "res"    a residual sum (ResNet output, the three transformer residuals, proj_out + input)     "temb"  conv1 + time embedding
+#   "p"      softmax output fed to P.V     "o"  attention output     "geglu"  GELU(gate) and value * gate
+#   "emb"    the time-embedding MLP chain (sinusoid, SiLU outputs)     "x"  the rounding of the sample / prompt at the boundary
+ROUND_OFF = set()
+
+
+def _r(x: torch.Tensor, autocast: bool, site: str = "out") -> torch.Tensor:
     """Round through fp16 when emulating autocast (output of an fp16 op)."""
-    return x.half().float() if autocast else x
+    return x.half().float() if (autocast and site not in ROUND_OFF) else x
 
 
 # --------------------------------------------------------------------------------------------
@@ -114,19 +124,28 @@ def timestep_sinusoid(timesteps: torch.Tensor, dim: int = 320) -> torch.Tensor:
 
 
 def _conv(p: _SD, name: str, x, ac, stride=1, padding=1):
-    return _r(F.conv2d(_r(x, ac), p(name + ".weight"), p(name + ".bias"), stride=stride, padding=padding), ac)
+    return _r(F.conv2d(_r(x, ac, "in"), p(name + ".weight"), p(name + ".bias"), stride=stride, padding=padding), ac, "out")
 
 
 def _linear(p: _SD, name: str, x, ac, bias=True):
-    return _r(F.linear(_r(x, ac), p(name + ".weight"), p(name + ".bias") if bias else None), ac)
+    return _r(F.linear(_r(x, ac, "in"), p(name + ".weight"), p(name + ".bias") if bias else None), ac, "out")
+
+
+# Optional observer of every normalisation input: PROBE(kind, name, x) with kind "gn" / "ln" (tests: |mean| / std and max |x|
+# of the operating point a weight set puts the norms at).  None = off.
+PROBE = None
 
 
 def _gn(p: _SD, name: str, x, groups, eps):
     # autocast promotes group_norm to fp32: the output is NOT rounded to fp16
+    if PROBE is not None:
+        PROBE("gn", name, x)
     return F.group_norm(x, groups, p(name + ".weight"), p(name + ".bias"), eps)
 
 
 def _ln(p: _SD, name: str, x, eps):
+    if PROBE is not None:
+        PROBE("ln", name, x)
     return F.layer_norm(x, (x.shape[-1],), p(name + ".weight"), p(name + ".bias"), eps)
 
 
@@ -135,12 +154,12 @@ def _resnet(p: _SD, name: str, x, temb_act, cfg: RefConfig, ac):
     h = F.silu(_gn(p, name + ".norm1", x, cfg.norm_num_groups, cfg.norm_eps))
     h = _conv(p, name + ".conv1", h, ac)
     t = _linear(p, name + ".time_emb_proj", temb_act, ac)
-    h = _r(h + t[:, :, None, None], ac)
+    h = _r(h + t[:, :, None, None], ac, "temb")
     h = F.silu(_gn(p, name + ".norm2", h, cfg.norm_num_groups, cfg.norm_eps))
     h = _conv(p, name + ".conv2", h, ac)
     if p.has(name + ".conv_shortcut.weight"):
         x = _conv(p, name + ".conv_shortcut", x, ac, padding=0)
-    return _r(x + h, ac)
+    return _r(x + h, ac, "res")
 
 
 def _attention(p: _SD, name: str, x, ctx, heads, ac):
@@ -159,7 +178,7 @@ def _attention(p: _SD, name: str, x, ctx, heads, ac):
     def rows(qb):
         s = torch.matmul(qb, kT) * (d ** -0.5)
         pr = torch.softmax(s, dim=-1)            # fp32 softmax on fp32 scores (flash kernels)
-        return _r(torch.matmul(_r(pr, ac), v), ac)  # P is fed to the PV matmul in fp16
+        return _r(torch.matmul(_r(pr, ac, "p"), v), ac, "o")  # P is fed to the PV matmul in fp16
     # the softmax is per query row, so blocks of query rows are independent: at 128 x 128 latents (16 384 tokens, the
     # X-ray case) the full score tensor would be 8.6 GB per sample — keep it below 2^28 elements at a time
     qc = max(1, (1 << 28) // max(1, B * heads * kv.shape[1]))
@@ -176,16 +195,16 @@ def _transformer(p: _SD, name: str, x, ctx, cfg: RefConfig, ac):
     h = _conv(p, name + ".proj_in", h, ac, padding=0)
     h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
     b = name + ".transformer_blocks.0"
-    h = _r(_attention(p, b + ".attn1", _ln(p, b + ".norm1", h, cfg.ln_eps), None, cfg.num_heads, ac) + h, ac)
-    h = _r(_attention(p, b + ".attn2", _ln(p, b + ".norm2", h, cfg.ln_eps), ctx, cfg.num_heads, ac) + h, ac)
+    h = _r(_attention(p, b + ".attn1", _ln(p, b + ".norm1", h, cfg.ln_eps), None, cfg.num_heads, ac) + h, ac, "res")
+    h = _r(_attention(p, b + ".attn2", _ln(p, b + ".norm2", h, cfg.ln_eps), ctx, cfg.num_heads, ac) + h, ac, "res")
     n3 = _ln(p, b + ".norm3", h, cfg.ln_eps)
     proj = _linear(p, b + ".ff.net.0.proj", n3, ac)
     a, g = proj.chunk(2, dim=-1)
-    ff = _r(a * _r(F.gelu(g), ac), ac)                       # GEGLU, erf GELU in fp16 under autocast
-    h = _r(_linear(p, b + ".ff.net.2", ff, ac) + h, ac)
+    ff = _r(a * _r(F.gelu(g), ac, "geglu"), ac, "geglu")     # GEGLU, erf GELU in fp16 under autocast
+    h = _r(_linear(p, b + ".ff.net.2", ff, ac) + h, ac, "res")
     h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
     h = _conv(p, name + ".proj_out", h, ac, padding=0)
-    return _r(h + res, ac)
+    return _r(h + res, ac, "res")
 
 
 def unet_forward(sd: Dict[str, torch.Tensor], sample: torch.Tensor, timesteps: torch.Tensor,
@@ -203,19 +222,19 @@ def unet_forward(sd: Dict[str, torch.Tensor], sample: torch.Tensor, timesteps: t
     if timesteps.dim() == 0:
         timesteps = timesteps[None]
     timesteps = timesteps.expand(B)
-    sample = _r(sample.float(), ac)
-    ctx = _r(encoder_hidden_states.float(), ac)
+    sample = _r(sample.float(), ac, "x")
+    ctx = _r(encoder_hidden_states.float(), ac, "x")
     boc = cfg.block_out_channels
     nb = len(boc)
     n_up = nb - 1                                    # number of upsamplers
     fwd_up_size = any(s % (2 ** n_up) != 0 for s in sample.shape[-2:])   # dift.py:54-56
 
     # 1. time (dift.py:84-91)
-    t_emb = _r(timestep_sinusoid(timesteps, boc[0]), ac)
+    t_emb = _r(timestep_sinusoid(timesteps, boc[0]), ac, "emb")
     emb = _linear(p, "time_embedding.linear_1", t_emb, ac)
-    emb = _r(F.silu(emb), ac)
+    emb = _r(F.silu(emb), ac, "emb")
     emb = _linear(p, "time_embedding.linear_2", emb, ac)
-    temb_act = _r(F.silu(emb), ac)                   # every ResNet applies SiLU before time_emb_proj
+    temb_act = _r(F.silu(emb), ac, "emb")            # every ResNet applies SiLU before time_emb_proj
 
     # 2. conv_in
     h = _conv(p, "conv_in", sample, ac)
