@@ -27,14 +27,29 @@ from tests import gpu_util as U  # noqa: E402
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 FLOW = {"f32": (np.float32, torch.float32), "f16": (np.float16, torch.float16)}
 
-# asserted bounds: each <= 2x the largest value measured on MI355X in r02 (gpurun_out/r02b/pytest.log)
-TOL_EPS_HAT = 3.0e-3      # eps_hat rel-L2 vs autocast oracle (measured <= 2.03e-3) and vs fp32 oracle (<= 1.61e-3)
-TOL_LOSS = 2.8e-3         # loss / grid rel-L2 vs autocast oracle (measured <= 1.41e-3)
-TOL_T_MEANLOSS = 4.7e-4   # |dT| / mean loss with 1-4 draws (measured <= 2.35e-4)
-TOL_T10_MEANLOSS = 9e-5   # |dT| / mean loss at N = 10 draws (measured <= 4.45e-5)
-TOL_T10_REL = 5.8e-3      # |dT| / |T| at N = 10 draws (measured <= 2.86e-3)
-TOL_C1_MEANLOSS = 1.2e-4  # config-1 substitute, 16 images x N = 2: max |dT| / mean loss (measured 5.9e-5)
-TOL_DIFT = 3.2e-3         # DIFT feature rel-L2 vs the fp32 oracle (measured <= 1.62e-3)
+# Asserted bounds are DERIVED from the oracle's own indeterminacy (not "2 x what an earlier round measured"):
+# the fp16-autocast oracle against itself under a pure re-ordering of its fp32 partial sums moves by up to 1.90e-3 (eps_hat) /
+# 1.23e-3 (loss) rel-L2 (tests/test_oracle.py::test_oracle_noise_floor_under_summation_order, profiles/r03_oracle_noise_floor.txt);
+# the engine is held to 1.5 x that.
+TOL_EPS_HAT = 1.5 * 1.90e-3   # eps_hat rel-L2 vs the autocast oracle (engine: 1.80-2.03e-3) and vs the fp32 oracle (1.40-1.61e-3)
+TOL_LOSS = 1.5 * 1.23e-3      # loss / grid rel-L2 vs the autocast oracle (engine: 1.14-1.41e-3)
+# |dT| / mean loss with 1-4 draws: T is a mean over n_draws * h * w pixel-draws of differences of nearly equal losses, so its noise
+# scales with 1 / sqrt(count): the N = 10 @32x32 floor (2.48e-5 over 10 240 pixel-draws) x sqrt(10 240 / 64) for the smallest case
+# (one draw @8x8) x 1.5 = 4.7e-4 (engine: <= 2.35e-4)
+TOL_T_MEANLOSS = 4.7e-4
+# config-1 substitute, 16 images x N = 2 @32x48: the same scaling gives 2.48e-5 x sqrt(10240 / 3072) = 4.5e-5 as the floor's largest
+# of six samples; the assertion is on the MAX over 16 images, held to 2.7 x that (engine: 5.9e-5)
+TOL_C1_MEANLOSS = 1.2e-4
+TOL_DIFT = 1.5 * 1.90e-3 * 1.15   # DIFT feature rel-L2 vs the fp32 oracle: the eps_hat bound; the tap sits at 2/3 of the depth but has no final norm (engine <= 1.62e-3)
+# T(x|c) at the BASELINE draw count: the bound is DERIVED, not "2 x what an earlier round measured": 1.5 x the spread of the
+# fp16-autocast oracle against ITSELF when only the order of its fp32 partial sums changes (one thread / channels-last / hidden
+# channels permuted; the same two images, N = 10 x 2 prompts @32x32; tools/oracle_noise.py floor -> tests/golden/oracle_T_floor.json,
+# profiles/r04_oracle_T_noise_floor.txt).  Two fp16 evaluations of the same function cannot be asked to agree better than one of
+# them agrees with itself.
+with open(os.path.join(GOLDEN, "oracle_T_floor.json")) as _f:
+    _T_FLOOR = json.load(_f)
+TOL_T10_MEANLOSS = 1.5 * _T_FLOOR["max_dT_over_mean_loss"]   # 1.5 x 2.48e-5 = 3.7e-5 (engine r04: 2.0e-5, 2.0e-5)
+TOL_T10_REL = 1.5 * _T_FLOOR["max_dT_over_T"]               # 1.5 x 1.59e-3 = 2.4e-3 (engine r04: 1.20e-3, 1.27e-3)
 
 
 @pytest.fixture(scope="module")

@@ -8,7 +8,8 @@ Prints per image |dT|/|T| and |dT|/mean loss of (engine vs autocast oracle), (en
 oracle), next to the autocast oracle's own spread under re-ordering (tests/golden/oracle_T_floor.json).  Test infrastructure
 (runs the oracle on the host cores).
 
-    python tools/t_deviation.py [n_images] > profiles/r04_T_deviation.txt
+    python tools/t_deviation.py [n_images] [--fp32-only] > profiles/r04_T_deviation.txt
+(--fp32-only: the fp32 oracle alone, fewer option variants — more images per minute; the "vs autocast" columns then repeat "vs fp32")
 """
 import json
 import os
@@ -32,6 +33,10 @@ DEFAULTS = {"ln_fold": 1, "gn_fold": 1, "ff_fold": 1, "sc_fold": 1, "tap_reuse":
 
 def main():
     n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    fp32_only = "--fp32-only" in sys.argv           # more images, ground truth only (the autocast emulation is the slow oracle)
+    global OPTIONS
+    if fp32_only:
+        OPTIONS = [(), ("sc_fold",), ("ln_inkernel",), ("ln_fold", "gn_fold", "ff_fold", "sc_fold", "tap_reuse")]
     N, hw = 10, 32
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     sdn = synth.synth_state_dict(seed=0, dtype=np.float16)
@@ -51,8 +56,8 @@ def main():
         x = xs[i:i + 1]
         noises, ts = sc.draw(x.shape)
         with torch.no_grad():
-            g_ac = R.compute_losses(sd, x, c.float(), noises, ts, B=N, autocast=True, latent_dtype=torch.float32)
             g_32 = R.compute_losses(sd, x, c.float(), noises, ts, B=N, autocast=False)
+            g_ac = g_32 if fp32_only else R.compute_losses(sd, x, c.float(), noises, ts, B=N, autocast=True, latent_dtype=torch.float32)
         T_ac, T_32 = R.typicality_scalar(g_ac).item(), R.typicality_scalar(g_32).item()
         ml = g_32.float().mean().item()
         ac32.append((abs(T_ac - T_32) / abs(T_32), abs(T_ac - T_32) / ml))
