@@ -98,7 +98,11 @@ inline bool igemm_pers_ok(const IGemmParams& p) {
     const int nk = ((p.mode == IG_DENSE) ? 1 : 9) * (p.Cin / 64);
     if (nk < 4 || p.Cout % 320 != 0 || p.M < 2) return false;
     {   // the kernel keeps activation element offsets (row * channels + chunk) in 32 bits: larger tensors take the 128-row tile
-        const long long cmax = p.C1 > p.Cin - p.C1 ? p.C1 : p.Cin - p.C1;
+        long long cmax = p.C1 > p.Cin - p.C1 ? p.C1 : p.Cin - p.C1;
+        if (p.X3) {                          // the folded shortcut's sources (third / fourth k-loop source) use the same 32-bit offsets
+            const long long c3 = p.C3 > p.Csc - p.C3 ? p.C3 : p.Csc - p.C3;
+            cmax = cmax > c3 ? cmax : c3;
+        }
         const long long src_rows = (p.mode == IG_DENSE) ? (long long)p.M : (long long)(p.M / (p.OH * p.OW > 0 ? p.OH * p.OW : 1)) * p.H * p.W;
         if (src_rows * cmax >= (1LL << 31)) return false;
     }

@@ -248,7 +248,14 @@ void host_sinusoid(int t, int dim, float* out) {
 struct Packer {
     dm_engine* e;
     std::vector<char> blob;
+    std::vector<char> scratch;                             // operands needed only while finalize runs (freed afterwards)
     std::map<std::string, HostTensor>* src = nullptr;      // default: the U-Net state dict
+    size_t put_scratch(const void* src, size_t bytes) {
+        size_t off = (scratch.size() + 255) & ~(size_t)255;
+        scratch.resize(off + bytes);
+        memcpy(scratch.data() + off, src, bytes);
+        return off;
+    }
     size_t put(const void* src, size_t bytes) {
         size_t off = (blob.size() + 255) & ~(size_t)255;
         blob.resize(off + bytes);
@@ -466,7 +473,7 @@ int pack_tfm(Packer& P, const std::string& name, int c, TfmW* t, dm_engine* e) {
         std::vector<f16> w2t((size_t)4 * c * c);
         for (int o = 0; o < c; ++o)
             for (int j = 0; j < 4 * c; ++j) w2t[(size_t)j * c + o] = w2->data[(size_t)o * 4 * c + j];
-        t->w2t_off = P.put(w2t.data(), w2t.size() * 2);
+        t->w2t_off = P.put_scratch(w2t.data(), w2t.size() * 2);      // dead after finalize: not in the weight slab
         const size_t K = (size_t)5 * c;
         std::vector<f16> pk((size_t)c * K, (f16)0.f), pb(c);
         for (int o = 0; o < c; ++o) {
@@ -609,7 +616,8 @@ struct Fwd {
     // GroupNorm (no activation) folded into the following 1x1 convolution (Transformer2D.norm -> proj_in): statistics as in
     // groupnorm(), then per-sample weights W diag(a_n) and bias rows W b_n + bias, then the GEMM on the RAW x — the normalised
     // tensor (one write + one read of the residual stream) never exists.  Pays while the per-sample weights (N x C x C) are
-    // small next to the tensor: the 64x64 and 32x32 levels (C = 320, 640); at C = 1280 they would be 524 MB per launch.
+    // small next to the tensor (the rule below: Cout * 8 <= H * W): at a 64x64 latent that is the 320-channel level only — the
+    // 640-channel level (32x32 positions) would spend 62 % of what it saves on the weights, C = 1280 five times as much.
     bool gn_fold_ok(const Tensor& x, const ConvW& cv) const {
         const int HW = x.H * x.W;
         return option(OPT_GN_FOLD) != 0 && cv.k == 1 && cv.cin == x.C && x.C <= 640 && cv.cout % 160 == 0 && HW % 128 == 0 &&
@@ -1150,6 +1158,7 @@ int run_forward_graphed(dm_engine* e, const FwdArgs& A, hipStream_t s) {
             DM_HIP(e, hipGraphLaunch(g.exec, s));
             return 0;
         }
+    if (e->graph_seen.size() > 256) e->graph_seen.clear();                   // callers that never repeat a key (fresh tensors every call) must not grow this
     if (e->graph_seen[key]++ == 0) return run_forward(e, A, s, false);      // first sight: plain run (function attributes, warm caches)
     hipGraph_t graph = nullptr;
     DM_HIP(e, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -1381,15 +1390,20 @@ int dm_engine_finalize(dm_engine* e) {
         rebase_conv(e->up[i].up, base);
     }
     rebase_res(e->mid_res[0], base); rebase_res(e->mid_res[1], base); rebase_tfm(e->mid_tf, base);
-    // (Wp W2) of every transformer block into the first 4C columns of its fused rows: Y[o][j] = sum_c Wp[o][c] W2^T[j][c]
+    // (Wp W2) of every transformer block into the first 4C columns of its fused rows: Y[o][j] = sum_c Wp[o][c] W2^T[j][c];
+    // the W2^T operands live in a temporary buffer
+    char* scratch = nullptr;
+    DM_HIP(e, hipMalloc((void**)&scratch, P.scratch.size() ? P.scratch.size() : 256));
+    DM_HIP(e, hipMemcpy(scratch, P.scratch.data(), P.scratch.size(), hipMemcpyHostToDevice));
     for (TfmW* t : e->tfs) {
         IGemmParams p;
-        p.X = t->proj_out.w; p.X2 = nullptr; p.Wp = reinterpret_cast<const f16*>(base + t->w2t_off); p.bias = nullptr; p.temb = nullptr;
+        p.X = t->proj_out.w; p.X2 = nullptr; p.Wp = reinterpret_cast<const f16*>(scratch + t->w2t_off); p.bias = nullptr; p.temb = nullptr;
         p.res = nullptr; p.Y = const_cast<f16*>(t->ffp.w); p.M = t->c; p.Cout = 4 * t->c; p.Cin = t->c; p.C1 = t->c;
         p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M; p.mode = IG_DENSE; p.epi = EPI_PLAIN; p.ldy = 5 * t->c; p.ldres = 0; p.temb_ld = 0;
         DM_HIP(e, launch_igemm(p, nullptr));
     }
     DM_HIP(e, hipDeviceSynchronize());
+    DM_HIP(e, hipFree(scratch));
     e->host.clear();
 
     // scheduler + sinusoid tables

@@ -207,7 +207,8 @@ hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
         // GroupNorm folded into a 1x1 convolution: per-sample weights.  The persistent tile when a sample is whole 256-row tiles
         // and the launch has >= 2 rounds of them (or igemm_big forces it), else the 128-row tile; no head / tail cut (both give
         // the same bits, so which one runs is a matter of time only)
-        const bool pers = p.Cout % 320 == 0 && p.rows_per_sample % 256 == 0 &&
+        if (p.Cout % 160 != 0 || p.mode != IG_DENSE || p.X3) return hipErrorInvalidValue;      // shapes the WS kernels do not cover
+        const bool pers = p.Cout % 320 == 0 && p.rows_per_sample % 256 == 0 && igemm_pers_ok(p) &&      // (32-bit activation offsets)
                           (option(OPT_IGEMM_BIG) >= 0 ? option(OPT_IGEMM_BIG) != 0
                                                       : (long long)(p.M / 256) * (p.Cout / 320) >= 2LL * device_cu_count());
         return pers ? launch_igemm_pers_ws(p, s) : launch_igemm_tile_ws(p, s);
@@ -215,7 +216,10 @@ hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
     if (p.ln_s) {
         if (!p.ln_t || p.Cout % 160 != 0 || p.mode != IG_DENSE || p.C1 != p.Cin) return hipErrorInvalidValue;
     } else {
-        if (p.Cout % 160 != 0 || p.mode == IG_CONV3_S2P0) return launch_igemm64(p, s);        // VAE channel counts
+        if (p.Cout % 160 != 0 || p.mode == IG_CONV3_S2P0) {
+            if (p.X3) return hipErrorInvalidValue;       // the folded shortcut exists on the 160-channel-wave tiles only: never drop it silently
+            return launch_igemm64(p, s);                 // VAE channel counts
+        }
         if (p.Cin % BK != 0 || p.C1 % BK != 0 || p.M <= 0) return hipErrorInvalidValue;
     }
     if (option(OPT_IGEMM_EXP) == 1 && p.epi == EPI_GEGLU) return p.ln_s ? launch_igemm_tile_ln_half(p, s) : launch_t<2, 5>(p, s);

@@ -14,6 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdm_engine.so")
 _lib = None
+_CHECK_DEVICE_SLOTS = os.environ.get("DM_CHECK_SLOTS", "0") not in ("", "0")     # debug: validate prompt slots that live on the GPU
 
 # every symbol include/dm_engine.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -300,7 +301,7 @@ class UNetEngine:
         torch = self._torch
         s = torch.as_tensor(slots)
         assert s.shape == (batch,), (s.shape, batch)
-        if s.numel() and not s.is_cuda:
+        if s.numel() and (not s.is_cuda or _CHECK_DEVICE_SLOTS):      # DM_CHECK_SLOTS=1: also range-check device tensors (two syncs)
             lo, hi = int(s.min()), int(s.max())
             if lo < 0 or hi >= self.n_prompts:
                 raise EngineError(f"prompt slot {lo if lo < 0 else hi} outside the {self.n_prompts} prompts registered "

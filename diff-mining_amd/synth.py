@@ -127,7 +127,7 @@ def hash_uniform(name: str, n: int, seed: int = 0) -> np.ndarray:
 #     down / up samplers): a common-sign bias of STRESS_BIAS x the layer's output RMS (sign per tensor) + three x50 outlier
 #     output channels per tensor;
 #   * norm gammas log-uniform over one decade, betas +-0.5.
-# tests/test_oracle.py::test_stress_weights_operating_point measures what this does at every GroupNorm / LayerNorm input
+# tests/test_gpu_stress.py::test_stress_operating_point_is_off_benign measures what the calibrated form (tests/stress_weights.py) does at every GroupNorm / LayerNorm input
 # (|mean| / std per group or token, max |activation| < 65504).
 STRESS_BIAS = 10.0
 STRESS_OUTLIER = 50.0

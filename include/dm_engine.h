@@ -252,7 +252,8 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
  *     "attn_pipe" / "attn_cross" (pipelined / one-pass-softmax kernels vs the generic online-softmax kernel: different
  *     rescaling points), "ln_stats_g" (different lane order of the row reductions), "ln_inkernel" (0 / 1 / 2: LayerNorm
  *     statistics from a statistics kernel (two-pass) or inside the folded GEMM (one-pass fp32 sums; 1 = where cheaper));
- *   "gn_fold" (1 / 0): Transformer2D.norm folded into proj_in at the 320- / 640-channel levels (per-sample weights; the rounding
+ *   "gn_fold" (1 / 0): Transformer2D.norm folded into proj_in where the per-sample weights are <= 1/8 of a sample's activations (Cout * 8 <= H * W:
+ *     the 320-channel level of latents >= 64x64, the 640-channel level of latents >= 144x144; per-sample weights; the rounding
  *     moves from the normalised activations to the scaled weights) — numerically equivalent, not bit-identical to 0;
  *   "sc_fold" (1 / 0): the ResNet blocks' conv_shortcut folded into conv2 as extra k steps wherever conv2 runs unsplit (one
  *     rounding of the sum instead of three) — numerically equivalent, not bit-identical to 0;

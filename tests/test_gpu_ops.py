@@ -798,6 +798,48 @@ def test_layernorm_statistics_inside_the_gemm(M, C, Cout, epi):
     assert frac < 0.05 and diff.max().item() <= 4e-3 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("ratio", [10.0, 30.0, 100.0])
+def test_layernorm_fold_at_large_mean_over_std(ratio):
+    """rows whose |mean| is `ratio` x their spread — where a one-pass variance E[x^2] - mean^2 cancels.  The folded
+    LN -> Linear with the statistics inside the GEMM (the default up to N = 2560) and with the two-pass statistics kernel, both
+    against F.linear(F.layer_norm(x)) in fp32.  x is fp16, so at ratio 100 the INPUT itself carries the row's spread with
+    only ~4 significant bits more than the mean's ulp: the reference LayerNorm output is what it is; the question is only
+    whether the folded forms add to its error."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    M, C, Cout = 4096, 320, 960
+    sign = torch.where(torch.arange(M) % 2 == 0, 1.0, -1.0)[:, None]
+    x = (U.f16_randn(M, C, seed=11).float() * 0.5 + sign * 0.5 * ratio).half()
+    got_ratio = (x.float().mean(1).abs() / x.float().std(1)).median().item()
+    w = U.f16_randn(Cout, C, seed=3, scale=C ** -0.5)
+    b = U.f16_randn(Cout, seed=4, scale=0.1)
+    gamma = (1 + 0.1 * U.f16_randn(C, seed=5).float()).half()
+    beta = (0.05 * U.f16_randn(C, seed=6).float()).half()
+    wf = (w.float() * gamma.float()[None]).half()
+    ln_s, ln_t = wf.float().sum(1), (w.float() @ beta.float()) + b.float()
+    xg, wfd, sd_, td_ = x.to(d), wf.to(d), ln_s.to(d), ln_t.to(d)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=d)
+    assert lib.dm_op_ln_stats(U.stream(), U.ptr(xg), M, C, 1e-5, U.ptr(stats)) == 0
+
+    def run(st):
+        y = torch.full((M, Cout), float("nan"), dtype=torch.float16, device=d)
+        assert lib.dm_op_igemm_ln(U.stream(), U.ptr(xg), U.ptr(wfd), U.ptr(sd_), U.ptr(td_), U.ptr(st) if st is not None else None,
+                                  U.ptr(y), M, C, Cout, 0) == 0
+        torch.cuda.synchronize()
+        return y.float().cpu()
+    y_in, y_st = run(None), run(stats)
+    xr = x.double()
+    ref = F.linear(F.layer_norm(xr, (C,), gamma.double(), beta.double(), 1e-5), w.double(), b.double()).float()
+    unf = F.linear(F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), 1e-5).half().float(), w.float(), b.float()).half().float()   # the unfused pair's roundings
+    rel = lambda a: ((a - ref).norm() / ref.norm()).item()        # noqa: E731
+    mu = stats.cpu()[:, 0]
+    print(f"LN fold at |mean|/std = {got_ratio:.0f}: rel-L2 vs fp64 LayerNorm+Linear: statistics in the GEMM {rel(y_in):.2e}, statistics kernel "
+          f"{rel(y_st):.2e}, unfused fp16 LN output -> Linear (the autocast pair) {rel(unf):.2e}; max |mean err| of the kernel {(mu - x.float().mean(1)).abs().max():.1e}")
+    assert rel(y_st) <= max(1.5 * rel(unf), 6e-4)
+    assert rel(y_in) <= max(1.5 * rel(y_st), 6e-4), "one-pass statistics inside the GEMM lose precision at this |mean|/std"
+
+
 @pytest.mark.parametrize("N,H,W,C,Cout", [(3, 16, 16, 320, 320), (2, 32, 32, 640, 640), (160, 64, 64, 320, 320), (5, 16, 8, 64, 160)])
 def test_groupnorm_folded_into_conv1x1(N, H, W, C, Cout):
     """r03: `Transformer2DModel.norm` (GroupNorm 32, eps 1e-6, no activation) folded into `proj_in` (1x1 convolution): per-sample
