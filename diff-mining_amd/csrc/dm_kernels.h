@@ -83,8 +83,20 @@ struct IGemmParams {
     const f16* X3 = nullptr;
     const f16* X4 = nullptr;
     int C3 = 0, Csc = 0;
+    // persistent kernels: device address of the launcher's 1 KiB zero page (the source of halo / out-of-range LDS-DMA lanes), set by
+    // the launcher.  As a kernel ARGUMENT it sits in an SGPR pair; taken from the global symbol inside the kernel it is a GOT load
+    // (s_getpc + s_load_dwordx2 + s_waitcnt lgkmcnt(0) — which also waits for every fragment read in flight) that the compiler
+    // re-materialises inside the k loop of the register-tight variants (r04: once per k step in the tap-reuse and folded-LayerNorm
+    // kernels).
+    const void* zero_page = nullptr;
 };
 constexpr int IGEMM_TILE_CTR_INTS = 8 * 32 + 32;
+// LayerNorm statistics taken inside the folded GEMM are one-pass fp32 sums (var = E[x^2] - mean^2): with |mean| >> std the
+// subtraction cancels (measured r04: rel-L2 of the output 7.8e-4 instead of 2.9e-4 at |mean| / std = 100, equal at 30).  A row
+// whose mean^2 exceeds LN_REDO_RATIO2 x var gets its variance re-taken exactly — sum of (x - mean)^2 over the row, read back
+// from global memory (L2-hot: the tile just streamed it) — by the lane pair that owns it.  Rare path; the same code in
+// igemm_pers_tile.h and igemm_tile.h, so the two tiles stay bit-identical.
+constexpr float LN_REDO_RATIO2 = 256.0f;       // |mean| / std > 16
 hipError_t launch_igemm(const IGemmParams& p, hipStream_t s);
 // number of k parts for a layer with `spatial` output positions per sample (1 = no split); batch independent;
 // the caller provides the workspace

@@ -248,8 +248,8 @@ void host_sinusoid(int t, int dim, float* out) {
 struct Packer {
     dm_engine* e;
     std::vector<char> blob;
-    std::vector<char> scratch;                             // operands needed only while finalize runs (freed afterwards)
     std::map<std::string, HostTensor>* src = nullptr;      // default: the U-Net state dict
+    std::vector<char> scratch;                             // operands needed only while finalize runs (freed afterwards)
     size_t put_scratch(const void* src, size_t bytes) {
         size_t off = (scratch.size() + 255) & ~(size_t)255;
         scratch.resize(off + bytes);

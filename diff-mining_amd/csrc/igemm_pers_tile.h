@@ -81,6 +81,23 @@ __device__ long long g_pers_dbg[8];
 #define PTICK(i) do {} while (0)
 #endif
 
+// IGemmParams::zero_page of this translation unit's zero page, per device
+static inline IGemmParams with_zero_page(const IGemmParams& p) {
+    static std::atomic<const void*> cache[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const void* z = cache[dev & 63].load(std::memory_order_relaxed);
+    if (!z) {
+        void* a = nullptr;
+        (void)hipGetSymbolAddress(&a, HIP_SYMBOL(g_zero_page_pers));
+        z = a;
+        cache[dev & 63].store(z, std::memory_order_relaxed);
+    }
+    IGemmParams q = p;
+    q.zero_page = z;
+    return q;
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -279,7 +296,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
         } else {
             const int k = idx - WI;
             lptr_t dst = (lptr_t)(wt + WBYTES + (wid + k * NW) * 1024);
-            const f16* a = (xoff[k] >= 0) ? (xbase + (size_t)(unsigned)xoff[k]) : reinterpret_cast<const f16*>(g_zero_page_pers) + lchunk;
+            const f16* a = (xoff[k] >= 0) ? (xbase + (size_t)(unsigned)xoff[k]) : reinterpret_cast<const f16*>(p.zero_page) + lchunk;
             __builtin_amdgcn_global_load_lds((gptr_t)a, dst, 16, 0, 0);
             if (xoff[k] >= 0) xoff[k] += BK;
         }
@@ -288,7 +305,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
     auto load_aux = [&](int slot) __attribute__((always_inline)) {
         char* ax = aux0 + slot * AUX_BYTES;
         const int lane = hw_lane();
-        const char* zp = reinterpret_cast<const char*>(g_zero_page_pers) + lane * 16;
+        const char* zp = reinterpret_cast<const char*>(p.zero_page) + lane * 16;
         if (wid == 0) {
             const char* s = (p.bias && lane < TC / 8) ? reinterpret_cast<const char*>(p.bias + lc0) + lane * 16 : zp;
             __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(ax + AUX_BIAS), 16, 0, 0);
@@ -592,6 +609,19 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
                 const float mean = t1 / (float)p.Cin;
                 float var = t2 / (float)p.Cin - mean * mean;
                 var = var > 0.f ? var : 0.f;
+                if (mean * mean > LN_REDO_RATIO2 * var) {            // cancellation: exact second pass over this row (dm_kernels.h)
+                    int m = p0 + ((wid * 64 + ln2) >> 1);
+                    m = m < p.M ? m : p.M - 1;
+                    const int half_c = p.Cin >> 1;
+                    const f16* xr = p.X + (size_t)m * p.Cin + (ln2 & 1) * half_c;
+                    float q = 0.f;
+                    for (int c = 0; c < half_c; c += 8) {
+                        const half8 v = *reinterpret_cast<const half8*>(xr + c);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { const float d = (float)v[k] - mean; q = __builtin_fmaf(d, d, q); }
+                    }
+                    var = (q + __shfl_xor(q, 1)) / (float)p.Cin;
+                }
                 if ((ln2 & 1) == 0)
                     *reinterpret_cast<float2*>(aux0 + slot * AUX_BYTES + AUX_STATS + ((wid * 64 + ln2) >> 1) * 8) = float2{mean, rsqrtf(var + p.ln_eps)};
                 ln_s1 = 0.f; ln_s2 = 0.f;
@@ -636,12 +666,12 @@ static hipError_t launch_igemm_pers_t(const IGemmParams& p, hipStream_t s) {
     static std::atomic<unsigned> launch_no{0};
     const int cset = (int)(launch_no.fetch_add(1) % CSETS);
     const dim3 g(grid), b(512);
-    if (p.epi == EPI_GEGLU) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_GEGLU, LN, PX_NONE>), g, b, lds, s, p, ntiles, cset); return hipGetLastError(); }
+    if (p.epi == EPI_GEGLU) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_GEGLU, LN, PX_NONE>), g, b, lds, s, with_zero_page(p), ntiles, cset); return hipGetLastError(); }
     if constexpr (!LN) {        // the folded-LayerNorm layers never carry a time embedding or a residual (igemm_pers_ok)
-        if (p.temb) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_TEMB>), g, b, lds, s, p, ntiles, cset); return hipGetLastError(); }
-        if (p.res) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_RES>), g, b, lds, s, p, ntiles, cset); return hipGetLastError(); }
+        if (p.temb) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_TEMB>), g, b, lds, s, with_zero_page(p), ntiles, cset); return hipGetLastError(); }
+        if (p.res) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_RES>), g, b, lds, s, with_zero_page(p), ntiles, cset); return hipGetLastError(); }
     }
-    hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, LN, PX_NONE>), g, b, lds, s, p, ntiles, cset);
+    hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, LN, PX_NONE>), g, b, lds, s, with_zero_page(p), ntiles, cset);
     return hipGetLastError();
 }
 
@@ -662,8 +692,8 @@ static hipError_t launch_igemm_pers_sc_t(const IGemmParams& p, hipStream_t s) {
     }
     static std::atomic<unsigned> launch_no{0};
     const int cset = (int)(launch_no.fetch_add(1) % CSETS);
-    if (p.res) hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_RES, false, true>), dim3(grid), dim3(512), lds, s, p, ntiles, cset);
-    else hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_NONE, false, true>), dim3(grid), dim3(512), lds, s, p, ntiles, cset);
+    if (p.res) hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_RES, false, true>), dim3(grid), dim3(512), lds, s, with_zero_page(p), ntiles, cset);
+    else hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_NONE, false, true>), dim3(grid), dim3(512), lds, s, with_zero_page(p), ntiles, cset);
     return hipGetLastError();
 }
 #endif
@@ -683,7 +713,7 @@ static hipError_t launch_igemm_pers_ws_t(const IGemmParams& p, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, true, PX_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     static std::atomic<unsigned> launch_no{0};
     const int cset = (int)(launch_no.fetch_add(1) % CSETS);
-    hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, true, PX_NONE, true>), dim3(grid), dim3(512), lds, s, p, ntiles, cset);
+    hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, true, PX_NONE, true>), dim3(grid), dim3(512), lds, s, with_zero_page(p), ntiles, cset);
     return hipGetLastError();
 }
 #endif
@@ -700,7 +730,7 @@ static hipError_t launch_igemm_pers_partial_t(const IGemmParams& p, hipStream_t 
         (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PARTIAL, false, PX_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     static std::atomic<unsigned> launch_no{0};
     const int cset = (int)(launch_no.fetch_add(1) % CSETS);
-    hipLaunchKernelGGL((igemm_pers_kernel<EPI_PARTIAL, false, PX_NONE>), dim3(grid), dim3(512), lds, s, p, units, cset);
+    hipLaunchKernelGGL((igemm_pers_kernel<EPI_PARTIAL, false, PX_NONE>), dim3(grid), dim3(512), lds, s, with_zero_page(p), units, cset);
     return hipGetLastError();
 }
 

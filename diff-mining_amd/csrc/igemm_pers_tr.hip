@@ -143,13 +143,13 @@ void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
         if (i == XI - 1 && wid >= XP - NW * (XI - 1)) return;                            // uniform per wave (i: run-time, uniform)
         lptr_t dst = (lptr_t)(xs0 + buf * XBYTES + (wid + i * NW) * 1024);
         const f16* a = (off >= 0) ? (xbase + (size_t)(unsigned)off)
-                                  : reinterpret_cast<const f16*>(g_zero_page_pers) + ((ln & 7) ^ (ln >> 3)) * 8;
+                                  : reinterpret_cast<const f16*>(p.zero_page) + ((ln & 7) ^ (ln >> 3)) * 8;
         __builtin_amdgcn_global_load_lds((gptr_t)a, dst, 16, 0, 0);
     };
     auto load_aux = [&](int slot, int lc0, int lp0) __attribute__((always_inline)) {      // vectors of the tile at (lp0, lc0)
         char* ax = aux0 + slot * AUX_BYTES;
         const int lane = hw_lane();
-        const char* zp = reinterpret_cast<const char*>(g_zero_page_pers) + lane * 16;
+        const char* zp = reinterpret_cast<const char*>(p.zero_page) + lane * 16;
         if (wid == 0) {
             const char* s = (p.bias && lane < TC / 8) ? reinterpret_cast<const char*>(p.bias + lc0) + lane * 16 : zp;
             __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(ax + AUX_BIAS), 16, 0, 0);
@@ -490,7 +490,7 @@ static hipError_t launch_tr_up64(const IGemmParams& p, hipStream_t s) {      // 
         (void)hipFuncSetAttribute((const void*)igemm_pers_tr_kernel<PX_NONE, 64, U, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     static std::atomic<unsigned> launch_no{0};
     const int cset = (int)(launch_no.fetch_add(1) % CSETS);
-    hipLaunchKernelGGL((igemm_pers_tr_kernel<PX_NONE, 64, U, true>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), lds, s, p, ntiles, cset);
+    hipLaunchKernelGGL((igemm_pers_tr_kernel<PX_NONE, 64, U, true>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), lds, s, with_zero_page(p), ntiles, cset);
     return hipGetLastError();
 }
 
@@ -498,7 +498,7 @@ template <int EXTRA, int WIMG>
 static void launch_tr_k(const IGemmParams& p, int ntiles, int cset, dim3 g, size_t lds, hipStream_t s, bool set_attr) {
     constexpr bool U = TrUnroll<EXTRA, WIMG>::value;
     if (set_attr) (void)hipFuncSetAttribute((const void*)igemm_pers_tr_kernel<EXTRA, WIMG, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    else hipLaunchKernelGGL((igemm_pers_tr_kernel<EXTRA, WIMG, U>), g, dim3(512), lds, s, p, ntiles, cset);
+    else hipLaunchKernelGGL((igemm_pers_tr_kernel<EXTRA, WIMG, U>), g, dim3(512), lds, s, with_zero_page(p), ntiles, cset);
 }
 
 template <int WIMG>

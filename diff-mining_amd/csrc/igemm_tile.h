@@ -463,6 +463,19 @@ void igemm_kernel(IGemmParams p) {
         const float mean = t1 / (float)p.Cin;
         float var = t2 / (float)p.Cin - mean * mean;
         var = var > 0.f ? var : 0.f;
+        if (ln_ink && mean * mean > LN_REDO_RATIO2 * var) {      // cancellation: exact second pass over this row (dm_kernels.h)
+            int m = p0 + (tid >> 1);
+            m = m < p.M ? m : p.M - 1;
+            const int half_c = p.Cin >> 1;
+            const f16* xr = p.X + (size_t)m * p.Cin + (tid & 1) * half_c;
+            float q = 0.f;
+            for (int c = 0; c < half_c; c += 8) {
+                const half8 v = *reinterpret_cast<const half8*>(xr + c);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float d = (float)v[k] - mean; q = __builtin_fmaf(d, d, q); }
+            }
+            var = (q + __shfl_xor(q, 1)) / (float)p.Cin;
+        }
         if (ln_ink && (tid & 1) == 0)
             *reinterpret_cast<float2*>(smem + 2 * STAGE + 1024 + 8 * TC + (tid >> 1) * 8) = float2{mean, rsqrtf(var + p.ln_eps)};
         __syncthreads();

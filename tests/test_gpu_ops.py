@@ -3,6 +3,7 @@ in fp32 on the CPU from the same fp16 inputs.  Runs on th
 
 Tolerances: kernels accumulate in fp32 and round the output once to fp16, so the bound is fp16
 output rounding: rel-L2 <= 2e-3 and max|err| <= 2e-3 * max|ref| (fp16 eps = 9.8e-4)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -106,6 +107,51 @@ def test_igemm_geglu():
     y = U.op_igemm(x.to(d), wp.to(d), bp.to(d), epi=1)
     assert y.shape[-1] == 4 * Cc
     U.assert_close_fp16(y.view(M, 4 * Cc), ref, "geglu", rel=3e-3, abs_frac=3e-3)
+
+
+def test_geglu_gelu_over_every_fp16_gate():
+    """The GELU of the GEGLU epilogue over ALL 63 488 finite fp16 gate values (the gate is rounded to fp16 before the GELU, so this
+    is everything the epilogue can ever see): a GEMM whose value column is exactly 1 and whose gate column is exactly x, on the
+    persistent 256 x 320 tile and on the 128-row tile.  Against x Phi(x) in float64 rounded to fp16: the Abramowitz-Stegun form
+    of the epilogue differs for 257 inputs by one fp16 ulp (tools/gen_gelu_table.py emulates it; a 64-entry cubic table form
+    that differs for 4 was built and measured in r04 — same time, not kept: profiles/r04_ab_gelu_lut.txt), and the two tiles
+    agree bit for bit."""
+    import math
+    from scipy.special import erfc
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    bits = np.arange(65536, dtype=np.uint16)
+    x16 = bits.view(np.float16)
+    x16 = x16[np.isfinite(x16)]
+    M, K, Cout = len(x16), 256, 640                      # 320 GEGLU outputs
+    X = torch.zeros(1, 1, M, K, dtype=torch.float16)
+    X[0, 0, :, 0] = torch.from_numpy(x16.copy())
+    X[0, 0, :, 1] = 1.0
+    w = torch.zeros(Cout, K, dtype=torch.float16)
+    w[: Cout // 2, 1] = 1.0                              # value half: h = 1
+    w[Cout // 2:, 0] = 1.0                               # gate half: g = x
+    b = torch.zeros(Cout, dtype=torch.float16)
+    wp, bp = U.pack_geglu(w, b)
+    d = U.dev()
+    out = {}
+    try:
+        for big in (0, 1):
+            assert lib.dm_set_option(b"igemm_big", big) == 0
+            out[big] = U.op_igemm(X.to(d), wp.to(d), bp.to(d), epi=1).view(M, Cout // 2).cpu()
+    finally:
+        lib.dm_set_option(b"igemm_big", -1)
+    assert torch.equal(out[0], out[1]), "the two tile kernels evaluate the GELU differently"
+    got = out[1].numpy()
+    assert (got == got[:, :1]).all()                     # every output channel sees the same gate
+    x64 = x16.astype(np.float64)
+    exact = x64 * (1.0 - 0.5 * erfc(x64 / math.sqrt(2.0)))
+    ref16 = exact.astype(np.float16)
+    diff = got[:, 0] != ref16
+    n, big_n = int(diff.sum()), int((diff & (np.abs(exact) > 1e-4)).sum())
+    worst = float(np.abs(got[:, 0].astype(np.float64) - exact).max())
+    print(f"GELU over {M} fp16 gates: results that differ from the correctly rounded x Phi(x): {n} ({big_n} with |gelu| > 1e-4); "
+          f"max |fp16 result - float64| {worst:.2e}")
+    assert n <= 300, n
 
 
 @pytest.mark.parametrize("D,Tq,Tk", [(40, 256, 256), (40, 200, 200), (80, 336, 336), (160, 64, 64), (40, 4096, 4096), (80, 1024, 1024), (80, 256, 256)])
