@@ -185,6 +185,68 @@ __global__ __launch_bounds__(512, 2) void mix32_kernel(const _Float16* __restric
     if (sum == 1.2345f) sink[1] = 1;
 }
 
+// r04: the same three activities as a RING of BK = 32 half-steps: four stages of (256 + 320) rows x 64 B = 36 KiB (the same 144 KiB of
+// LDS as two BK = 64 stages), the LDS-DMA of half-step h + AHEAD issued while half-step h computes, and a COUNTED wait at the bottom
+// (only half-step h + 1 must have landed: the memory pipe never drains), one barrier per 40 MFMAs instead of one per 80.
+//   AHEAD = 3: two half-steps stay in flight across the barrier; AHEAD = 2: one; AHEAD = 1: drain (the 2-stage structure at BK = 32)
+template <int AHEAD, int RD, int MF>
+__global__ __launch_bounds__(512, 2) void ring_kernel(const _Float16* __restrict__ Wp, const _Float16* __restrict__ X, int K, int C, int nk,
+                                                      int tiles_c, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STG = (TP + TC) * 64;                       // 36 864 B
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lrow = lane >> 2, lchunk = ((lane & 3) ^ ((lrow >> 2) & 3)) * 8;      // a 1 KiB piece = 16 rows x 64 B
+    const int b = blockIdx.x;
+    const int pt = b / tiles_c, ct = b % tiles_c;
+    // 36 pieces per stage: 20 weight pieces (16 rows each), 16 activation pieces; wave w issues pieces w, w + 8, ... (5 for w < 4, else 4)
+    const int np = 4 + (wid < 4 ? 1 : 0);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int roff = ((wid & 3) * 64 + l15) * 64 + ((lg ^ ((l15 >> 2) & 3)) << 4);
+    f4 acc[20];
+    for (int i = 0; i < 20; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    h8 fa, fb;
+    for (int k = 0; k < 8; ++k) { fa[k] = (_Float16)(0.01f * (lane + k)); fb[k] = (_Float16)(0.02f * (lane - k)); }
+    const int nh = 2 * nk;
+    auto issue = [&](int h, int i) __attribute__((always_inline)) {
+        const int pc = wid + 8 * i;                           // piece of the stage
+        char* st = smem + (h & 3) * STG;
+        const int hk = h % nh;
+        const _Float16* src = (pc < 20) ? Wp + (size_t)(ct * TC + pc * 16 + lrow) * K + hk * 32 + lchunk
+                                        : X + (size_t)(pt * TP + (pc - 20) * 16 + lrow) * C + (hk * 32) % C + lchunk;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + pc * 1024), 16, 0, 0);
+    };
+    for (int a = 0; a < AHEAD; ++a)
+        for (int i = 0; i < 5; ++i) if (i < np) issue(a, i);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int h = 0; h < nh; ++h) {
+        const char* cur = smem + (h & 3) * STG;
+        int piece = 0;
+#pragma unroll
+        for (int g = 0; g < 10; ++g) {
+            if (RD) {          // 14 fragment reads per half-step: one per group + 4 extra
+                const h8 v = *reinterpret_cast<const h8*>(cur + roff + g * 1024);
+                if (MF) fa = v; else { asm volatile("" :: "v"(v)); }
+                if (g < 4) { const h8 u = *reinterpret_cast<const h8*>(cur + 20480 + roff + g * 1024); if (MF) fb = u; else { asm volatile("" :: "v"(u)); } }
+            }
+            if (MF) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[(g % 5) * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc[(g % 5) * 4 + j], 0, 0, 0);
+            }
+            if (piece < 5 && (g & 1) == 0) { if (piece < np) issue(h + AHEAD, piece); ++piece; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // half-step h + 1 must have landed; the AHEAD - 1 younger ones may stay in flight (np pieces each, uniform per wave)
+        if (AHEAD == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (AHEAD == 2) { if (wid < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else { if (wid < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        asm volatile("s_barrier" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float sum = 0.f;
+    for (int i = 0; i < 20; ++i) sum += acc[i][0] + acc[i][3];
+    if (sum == 1.2345f) sink[1] = 1;
+}
+
 int main() {
     const int K = 5760, C = 640, Cout = 1280, M = 65536, tiles_c = Cout / TC, nblk = (M / TP) * tiles_c;   // 1024 tiles = 4 per CU
     _Float16 *W, *X; unsigned* sink;
@@ -238,6 +300,16 @@ int main() {
     runm("DMA only, weight k order rotated per block (+7)", mix_kernel<1, 0, 0, 7>);
     runm("MFMA + reads + DMA, rotated (+7)", mix_kernel<1, 1, 1, 7>);
     runm("MFMA + reads + DMA, rotated (+1)", mix_kernel<1, 1, 1, 1>);
+    printf("--- r04: BK = 32 ring, 4 stages of 36 KiB, counted vmcnt (ns per 64-k step = two half-steps)\n");
+    runm("ring, drain every half-step: DMA only", ring_kernel<1, 0, 0>);
+    runm("ring, 1 half-step in flight: DMA only", ring_kernel<2, 0, 0>);
+    runm("ring, 2 half-steps in flight: DMA only", ring_kernel<3, 0, 0>);
+    runm("ring, drain: MFMA + reads + DMA", ring_kernel<1, 1, 1>);
+    runm("ring, 1 in flight: MFMA + reads + DMA", ring_kernel<2, 1, 1>);
+    runm("ring, 2 in flight: MFMA + reads + DMA", ring_kernel<3, 1, 1>);
+    runm("ring, 2 in flight: MFMA + DMA", ring_kernel<3, 0, 1>);
+    runm("MFMA + fragment reads + DMA (2 stages, again)", mix_kernel<1, 1, 1>);
+    runm("ring, 2 in flight: MFMA + reads + DMA (again)", ring_kernel<3, 1, 1>);
     runm("32x32x16: MFMA only", mix32_kernel<0, 0>);
     runm("32x32x16: MFMA + fragment reads", mix32_kernel<0, 1>);
     runm("32x32x16: MFMA + DMA", mix32_kernel<1, 0>);

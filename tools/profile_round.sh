@@ -2,7 +2,7 @@
 # Regenerate the judged artifacts of a round on the GPU box:  bash tools/profile_round.sh <tag>
 # (run through gpurun; outputs land in gpurun_out/<tag>/, copy the summaries into profiles/).
 set -u
-TAG=${1:-r03_final}
+TAG=${1:-r04_final}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
