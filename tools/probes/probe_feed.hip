@@ -247,6 +247,69 @@ __global__ __launch_bounds__(512, 2) void ring_kernel(const _Float16* __restrict
     if (sum == 1.2345f) sink[1] = 1;
 }
 
+// r04: the same block tile (256 px x 320 ch, two 64-channel stages) computed by FOUR waves of 128 px x 160 ch on the full 512-register
+// file (320 accumulator registers per wave: AGPRs + VGPRs), one wave per SIMD: 36 fragment reads per 160 MFMAs instead of 28 per 80
+// (-36 % LDS read traffic), 18 LDS-DMA pieces per wave and step.  Is one wave per SIMD enough to keep the matrix pipe fed?
+template <int DMA, int RD>
+__global__ __launch_bounds__(256, 1) void mix4_kernel(const _Float16* __restrict__ Wp, const _Float16* __restrict__ X, int K, int C, int nk,
+                                                      int tiles_c, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lrow = lane >> 3, lchunk = ((lane & 7) ^ lrow) * 8;
+    const int b = blockIdx.x;
+    const int pt = b / tiles_c, ct = b % tiles_c;
+    const _Float16* wsrc = Wp + (size_t)(ct * TC + wid * 8 + lrow) * K + lchunk;
+    const _Float16* xsrc = X + (size_t)(pt * TP + wid * 8 + lrow) * C + lchunk;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wc = wid >> 1, wp = wid & 1;
+    const int aoff = (wc * 160 + l15) * 128, boff = 40960 + (wp * 128 + l15) * 128;
+    f4 acc[10][8];
+    for (int i = 0; i < 10; ++i) for (int j = 0; j < 8; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    h8 fa, fb[8];
+    for (int k = 0; k < 8; ++k) fa[k] = (_Float16)(0.01f * (lane + k));
+    for (int j = 0; j < 8; ++j) for (int k = 0; k < 8; ++k) fb[j][k] = (_Float16)(0.02f * (lane - k + j));
+    for (int kt = 0; kt < nk; ++kt) {
+        char* st = smem + ((kt + 1) & 1) * (TP + TC) * 128;
+        const char* cur = smem + (kt & 1) * (TP + TC) * 128;
+        int ko = ((kt + 1) * 64) % C, kw = ((kt + 1) % nk) * 64;
+        asm volatile("" : "+v"(ko), "+v"(kw));          // opaque per step: the 18 piece addresses are formed where they are used, not hoisted
+        int piece = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int koff = (((4 * s2 + lg) ^ (l15 & 7)) << 4);
+            if (RD) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fb[j] = *reinterpret_cast<const h8*>(cur + boff + j * 2048 + koff);
+            }
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                if (RD) fa = *reinterpret_cast<const h8*>(cur + aoff + i * 2048 + koff);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb[j], acc[i][j], 0, 0, 0);
+                if (DMA && s2 == 0) {           // 18 pieces per wave, two per group in the first k half (minus two)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (piece < 18) {
+                            const int i2 = piece++;
+                            const int pc = wid + 4 * i2;                       // piece of the stage: 0..39 weights, 40..71 activations
+                            const unsigned off = (pc < 40) ? (unsigned)((ct * TC + pc * 8 + lrow) * K + kw + lchunk)
+                                                           : (unsigned)((pt * TP + (pc - 40) * 8 + lrow) * C + ko + lchunk);
+                            const _Float16* src = ((pc < 40) ? Wp : X) + off;
+                            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + pc * 1024), 16, 0, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    float sum = 0.f;
+    for (int i = 0; i < 10; ++i) for (int j = 0; j < 8; ++j) sum += acc[i][j][0] + acc[i][j][3];
+    if (sum == 1.2345f) sink[1] = 1;
+    (void)wsrc; (void)xsrc;
+}
+
 int main() {
     const int K = 5760, C = 640, Cout = 1280, M = 65536, tiles_c = Cout / TC, nblk = (M / TP) * tiles_c;   // 1024 tiles = 4 per CU
     _Float16 *W, *X; unsigned* sink;
@@ -310,6 +373,22 @@ int main() {
     runm("ring, 2 in flight: MFMA + DMA", ring_kernel<3, 0, 1>);
     runm("MFMA + fragment reads + DMA (2 stages, again)", mix_kernel<1, 1, 1>);
     runm("ring, 2 in flight: MFMA + reads + DMA (again)", ring_kernel<3, 1, 1>);
+    printf("--- r04: four waves of 128 px x 160 ch (one per SIMD, 320 accumulator registers), the same 2-stage step\n");
+    auto run4 = [&](const char* name, auto kern) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, 0, W, X, K, C, nk, tiles_c, sink);
+        hipEventRecord(e0, 0);
+        for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, 0, W, X, K, C, nk, tiles_c, sink);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+        printf("%-44s %7.3f ms  per step: %5.0f ns\n", name, ms, ms * 1e6 / (nblk / 256.0) / nk);
+    };
+    run4("4 waves: MFMA only", mix4_kernel<0, 0>);
+    run4("4 waves: MFMA + fragment reads", mix4_kernel<0, 1>);
+    run4("4 waves: MFMA + DMA", mix4_kernel<1, 0>);
+    run4("4 waves: MFMA + fragment reads + DMA", mix4_kernel<1, 1>);
+    runm("MFMA + fragment reads + DMA (8 waves, again)", mix_kernel<1, 1, 1>);
+    run4("4 waves: MFMA + fragment reads + DMA (again)", mix4_kernel<1, 1>);
     runm("32x32x16: MFMA only", mix32_kernel<0, 0>);
     runm("32x32x16: MFMA + fragment reads", mix32_kernel<0, 1>);
     runm("32x32x16: MFMA + DMA", mix32_kernel<1, 0>);
