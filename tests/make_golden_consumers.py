@@ -10,6 +10,7 @@ plain torch / numpy code inside the reference repository:
     Cluster.load_typicality_norm diffmining/typicality/cluster.py:112-123
     Cluster.load_typicality      diffmining/typicality/cluster.py:125-137
     Cluster.rank_images.compute  diffmining/typicality/cluster.py:517-531
+    <X-ray class>.compute        diffmining/applications/xray/compute.py:210-218 (dm_pixel)
 
 The two modules cannot be imported as they are (`skimage`, `umap` are not installed), so this script parses them with `ast`,
 compiles exactly those function definitions — the reference's text, unmodified, never written anywhere — and calls them with
@@ -58,6 +59,13 @@ def main():
     load_typicality_norm = ref_function(CL, ("Cluster", "load_typicality_norm"), c_ns)
     load_typicality = ref_function(CL, ("Cluster", "load_typicality"), c_ns)
 
+    XR = "diffmining/applications/xray/compute.py"
+    x_ns = dict(base)
+    xray_compute = None
+    for cls in [n for n in ast.parse(open(os.path.join(REF, XR)).read()).body if isinstance(n, ast.ClassDef)]:
+        if any(isinstance(n, ast.FunctionDef) and n.name == "compute" and [a.arg for a in n.args.args][:3] == ["self", "dm", "size"] for n in cls.body):
+            xray_compute = ref_function(XR, (cls.name, "compute"), x_ns)        # `compute(self, dm, size, blur=False)` (xray/compute.py:210-218)
+    assert xray_compute is not None
     out = {}
     rng = np.random.default_rng(20260929)
     cases = {"a": (3, 12, 10, 45, 37, 5), "b": (10, 16, 21, 128, 171, 32), "c": (2, 16, 16, 96, 96, 1)}
@@ -87,6 +95,9 @@ def main():
         rank = ref_function(CL, ("Cluster", "rank_images", "compute"), r_ns)
         _, score = rank(("x.jpg", True))
         out[f"{tag}_rank_score"] = np.array(score, dtype=np.float32)
+        # the X-ray application's per-pixel map (applications/xray/compute.py:210-218): `dm_pixel`, second return value
+        _, dm_pixel = xray_compute(types.SimpleNamespace(), torch.from_numpy(grid.copy()), (H, W))
+        out[f"{tag}_xray_dm_pixel"] = np.asarray(dm_pixel, dtype=np.float32)
         if tag != "a":
             continue
         dm = out[f"{tag}_load_typicality_k1"]

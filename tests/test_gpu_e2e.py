@@ -379,6 +379,32 @@ def test_image_space_typicality_vs_reference_order(engine, h, w, H, W, k):
         torch.testing.assert_close(sc.pixel_heatmap(grid, (H, W)).cpu(), ref, atol=2e-5, rtol=1e-4)
 
 
+def test_compute_losses_vs_the_reference_classes_fixture(engine):
+    """tests/golden/host_ref.npz: the grid the reference's OWN `D.compute_losses` / `SD.compute_loss` produced (run from /root/reference by
+    tests/make_golden_host.py with the fp32 oracle as `pipe.unet`; torch.autocast('cuda') is inert without CUDA, so the flow is fp32):
+    N = 7 draws in chunks of B = 3.  The scorer must make the same draws and fill the same [N, 2, 4, h, w] layout; the values agree to the
+    fp16-vs-fp32 distance."""
+    import json
+    from diff_mining_amd.typicality import TypicalityScorer
+    a = np.load(os.path.join(GOLDEN, "host_ref.npz"))
+    m = json.load(open(os.path.join(GOLDEN, "host_ref.json")))
+    sc = TypicalityScorer(engine, seed=m["seed"], N=m["N"], t_min=m["t_min"], t_max=m["t_max"])
+    x, c = torch.from_numpy(a["x"]), torch.from_numpy(a["embeds"])
+    grid = sc.compute_losses(x, c, B=m["B"])                       # draws its own (eps, t)
+    eps, t = sc.draw(x.shape)
+    assert np.array_equal(eps.numpy(), a["noises"]) and np.array_equal(t.numpy(), a["timesteps"])
+    ref = torch.from_numpy(a["grid"]).float()
+    assert grid.shape == ref.shape and grid.dtype == torch.float16
+    rl = U.rel_l2(grid.float(), ref)
+    print(f"grid vs the reference classes' fp32 grid: rel-L2 {rl:.2e}")
+    assert rl < TOL_LOSS
+    # layout: every (draw, prompt) cell is closest to its own cell of the reference grid
+    for i in range(m["N"]):
+        for k in range(2):
+            d_own = (grid[i, k].float() - ref[i, k]).norm()
+            assert d_own < (grid[i, k].float() - ref[i, 1 - k]).norm() and d_own < (grid[i, k].float() - ref[(i + 1) % m["N"], k]).norm()
+
+
 def test_consumers_vs_the_reference_fixture(engine):
     """PINNED to the reference's own code: `Cluster.load_typicality`, `load_typicality_norm`, `d_compute`, `normalize` run by
     tests/make_golden_consumers.py from /root/reference (tests/golden/consumers_ref.npz) vs dm_typicality_image +
@@ -415,8 +441,10 @@ def test_consumers_vs_the_reference_fixture(engine):
     for tag in ("a", "b", "c"):
         grid = torch.from_numpy(f[f"{tag}_grid"])
         H, W, _ = (int(v) for v in f[f"{tag}_size"])
-        m = sc.pixel_heatmap(grid, (H, W)).mean().item()
-        assert abs(m - float(f[f"{tag}_rank_score"])) <= 2e-6
+        hm = sc.pixel_heatmap(grid, (H, W))
+        assert abs(hm.mean().item() - float(f[f"{tag}_rank_score"])) <= 2e-6
+        # the X-ray application's `dm_pixel` (applications/xray/compute.py:210-218), from the reference's own method
+        assert np.abs(hm.cpu().numpy() - f[f"{tag}_xray_dm_pixel"]).max() <= 2e-6
 
 
 def test_safetensors_checkpoint_round_trip(engine, sd15_weights_f16, tmp_path):

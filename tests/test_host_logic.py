@@ -481,3 +481,73 @@ def test_load_pipeline_dir_names_what_is_missing(tmp_path):
     e = UNetEngine.__new__(UNetEngine)
     with pytest.raises(EngineError, match="unet.*diffusion_pytorch_model.safetensors not found"):
         e.load_pipeline_dir(str(tmp_path))
+
+
+# ---- r04: the host surface against the reference's OWN classes (tests/make_golden_host.py ran CategoryFeatures, SD.compute_loss and D from
+#      /root/reference/diffmining/typicality/compute.py with the oracle as pipe.unet; tests/golden/host_ref.{npz,json}) ----------------------
+def _host_ref():
+    import json
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return np.load(os.path.join(g, "host_ref.npz")), json.load(open(os.path.join(g, "host_ref.json")))
+
+
+def _scorer(**kw):
+    sc = T.TypicalityScorer.__new__(T.TypicalityScorer)
+    sc.generator_device, sc.latent_dtype, sc.num_train_timesteps = "cpu", torch.float32, 1000
+    for k, v in kw.items():
+        setattr(sc, k, v)
+    return sc
+
+
+def test_prompt_templates_match_the_reference_classes():
+    """`CategoryFeatures.embed`'s strings (compute.py:39-48) as the reference's own class produced them, for every dataset."""
+    _, m = _host_ref()
+    for which, want in m["prompts"].items():
+        assert T.CategoryFeatures.prompts(which, m["xray_categories"] if which == "xray" else m["categories"]) == want, which
+    assert m["tokenizer_kwargs"] == {"max_length": 77, "padding": "max_length", "truncation": True, "return_tensors": "pt"}
+
+
+def test_draws_match_the_reference_noising():
+    """`D.noising` x N after `torch.manual_seed(seed)` (compute.py:115-124,139-141), run by the reference's own class D on the CPU
+    generator: TypicalityScorer.draw gives the same (eps, t) bit for bit — draw order, randint bounds int(t_min * 1000) .. int(t_max * 1000)."""
+    a, m = _host_ref()
+    sc = _scorer(seed=m["seed"], N=m["N"], t_min=m["t_min"], t_max=m["t_max"])
+    eps, t = sc.draw((1, 4, 8, 8))
+    assert eps.dtype == torch.float32 and t.dtype == torch.int64
+    assert np.array_equal(eps.numpy(), a["noises"]) and np.array_equal(t.numpy(), a["timesteps"])
+    sc = _scorer(seed=7, N=3, t_min=0.0, t_max=1.0)
+    eps, t = sc.draw((1, 4, 6, 10))
+    assert np.array_equal(eps.numpy(), a["noising_eps"]) and np.array_equal(t.numpy(), a["noising_t"])
+    # and the oracle's restatement of the same draws
+    eps2, t2 = R.draw_noise_and_timesteps((1, 4, 8, 8), m["N"], m["t_min"], m["t_max"], seed=m["seed"])
+    assert np.array_equal(eps2.numpy(), a["noises"]) and np.array_equal(t2.numpy(), a["timesteps"])
+
+
+def test_oracle_compute_losses_matches_the_reference_control_flow(sd15_weights_torch):
+    """`D.compute_losses` + `SD.compute_loss` (compute.py:95-160) — the reference's own code, chunks of B = 3 over N = 7 draws (6 + 6 + 2
+    U-Net rows), cond-major tiling, split / stack / cat, fp16 cast — with the oracle's U-Net plugged in as `pipe.unet`: the oracle's
+    restatement of that control flow reproduces the grid bit for bit."""
+    a, m = _host_ref()
+    assert m["chunk_rows"] == [6, 6, 2] and all(m["cond_rows_equal_embeds"])
+    grid = R.compute_losses(sd15_weights_torch, torch.from_numpy(a["x"]), torch.from_numpy(a["embeds"]).float(), torch.from_numpy(a["noises"]),
+                            torch.from_numpy(a["timesteps"]), B=m["B"], autocast=False)
+    assert grid.dtype == torch.float16 and np.array_equal(grid.numpy(), a["grid"])
+
+
+def test_rescale_and_get_path_match_the_reference_class():
+    """`D.rescale` (compute.py:165-180: cars short side 256 with int(), places 512 with math.ceil, LANCZOS) down to the pixels, and
+    `D.get_path` (:162-163), against what the reference's own class returned."""
+    import hashlib
+    import PIL.Image
+    _, m = _host_ref()
+    rng = np.random.default_rng(3)
+    for r in m["rescale"]:
+        W, H = r["in"]
+        img = PIL.Image.fromarray(rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8))
+        out = _scorer(which=r["which"]).rescale(img)
+        assert list(out.size) == r["out"], r
+        o = np.asarray(out)
+        assert o[:2, :3].tolist() == r["corner"] and hashlib.sha256(o.tobytes()).hexdigest() == r["sha256"], r
+        assert list(T.TypicalityScorer.rescale_size(r["which"], W, H)) == r["out"]
+    for src, want in m["get_path"].items():
+        assert T.TypicalityScorer.get_path("/data/out/typicality", src) == want

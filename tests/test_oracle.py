@@ -430,6 +430,8 @@ def test_consumer_reductions_match_the_reference_fixture():
         # rank_images' scalar is the mean of the image-size map; the oracle's `typicality_scalar` is the mean of the latent map
         # (bilinear interpolation with align_corners=False does not preserve the mean exactly): compare like with like
         assert abs(float(R.load_typicality(grid, (H, W), 1, 1).numpy().mean()) - float(f[f"{tag}_rank_score"])) <= 1e-7
+        # the X-ray application's dm_pixel (applications/xray/compute.py:210-218) = the per-pixel map with (null - cond) written the other way round
+        assert np.abs(R.load_typicality(grid, (H, W), 1, 1).numpy() - f[f"{tag}_xray_dm_pixel"]).max() <= 1e-6
     dm = f["a_load_typicality_k1"]
     assert np.array_equal(R.normalize_map(dm, "positive"), f["a_cnorm_positive"])
     sp = R.normalize_map(dm, "split")
