@@ -17,6 +17,12 @@ scheduler-table and sinusoid known answers, shape walks and algebraic properties
 
 Each function cites the reference call site it stands in for.
 
+Pinned parts (r04): the CONTROL FLOW restated here — `draw_noise_and_timesteps`, `compute_loss`, `compute_losses` — and the grid consumers
+(`load_typicality`, `load_typicality_norm`, `d_compute`, `normalize_map`) reproduce, bit for bit, what the reference's own classes /
+functions produce when they are run from /root/reference with this module's U-Net plugged in as `pipe.unet`
+(tests/make_golden_host.py, tests/make_golden_consumers.py -> tests/golden/host_ref.npz, consumers_ref.npz).  The U-Net / scheduler
+ARITHMETIC (the diffusers part) is what remains unpinned.
+
 Two numeric modes:
   * `autocast=False` — plain fp32 everywhere (the mathematical ground truth).
   * `autocast=True`  — emulates `torch.autocast('cuda', dtype=float16)` as used at
