@@ -647,6 +647,36 @@ def test_dift_full_size_properties(engine):
     assert torch.equal(one, feat[8:16])                                                # depend on the batch it rides in
 
 
+def test_two_engines_on_one_gpu_two_streams(engine, sd15_weights_f16):
+    """What a one-GPU box can check of the multi-engine contract (the two-GPU test below is skipped there): two engines on the SAME
+    device, each on a stream of its own, their U-Net runs enqueued back to back so the persistent kernels of both are in flight
+    together — per-engine tile hand-out counters, per-engine workspace and K/V cache, the launcher-side zero page.  Both must give
+    the bits of a lone run, repeatedly."""
+    from diff_mining_amd.engine import UNetEngine
+    x, eps, t, c = _inputs(32, 32, 3, flow="f32")
+    nb, tb, cc, slots = _tile(eps, t, c)
+    dev = engine.device
+    xd, nbd, tbd, sld = x.to(dev), nb.to(dev), tb.to(dev), slots.to(dev)
+    engine.set_prompts(c)
+    ref = engine.score(xd, nbd, tbd, sld, latent_dtype=torch.float32).clone()
+    e2 = UNetEngine(0)
+    e2.load_state_dict(sd15_weights_f16)
+    e2.set_prompts(c)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    outs = []
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            a = engine.score(xd, nbd, tbd, sld, latent_dtype=torch.float32)
+        with torch.cuda.stream(s2):
+            b = e2.score(xd, nbd, tbd, sld, latent_dtype=torch.float32)
+        outs.append((a, b))
+    torch.cuda.synchronize()
+    for a, b in outs:
+        assert torch.equal(a, ref) and torch.equal(b, ref)
+    e2.close()
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process")
 def test_two_engines_in_one_process(sd15_weights_f16):
     """Kernel function attributes (dynamic LDS size) are per device: a second engine on another GPU of the same
