@@ -1,0 +1,372 @@
+// f32_ops.hip — the non-GEMM kernels of the fp32 U-Net path (reference: the DIFT featuriser's fp32 run, dift.py:191,197-199):
+// flash attention on the fp32 matrix cores, GroupNorm (+ SiLU), LayerNorm, GEGLU, the time-step embedding, conv_in / conv_out and the
+// layout kernels at the NCHW boundary.  All tensors fp32, NHWC inside.
+#include "f32_kernels.h"
+#include <math.h>
+
+namespace dm32 {
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// ---- attention -----------------------------------------------------------------------------------------------------------------
+// One block = 128 queries of one (sample, head): 4 waves x 32 queries (two 16-query MFMA tiles).  Key tiles of KT keys are staged
+// in LDS as [key][D + 4] fp32 rows (the + 4 makes every fragment read below bank-conflict-free for D = 40 / 80 / 160: 16 rows
+// x 4 column groups hit 64 distinct banks).
+//   S^T[key][query] = K Q^T   : A = K rows  (lane (c, g): key c, d = 4 s + g),  B = Q^T (query c, d = 4 s + g), D/4 k steps — head_dim
+//                                40 needs no padding on the k = 4 instruction
+//   softmax over keys          : a lane holds keys 4 g + r of query c; the row maximum crosses the four g lanes by two shuffles
+//   O^T[d][query] += V^T P^T   : B = P^T is the S^T accumulator AS IT LIES (register r <-> key 4 g + r, lane <-> query c) — P never
+//                                leaves its lane —, A = V^T (lane (c, g): d = 16 dt + c, key 4 g + r)
+// Online softmax (running maximum / sum, exp2 on pre-scaled scores), exact fp32 products and accumulation.
+template <int D, int KT>
+__global__ __launch_bounds__(256) void attn32_kernel(AttnParams p) {
+    constexpr int LD = D + 4, DT = (D + 15) / 16, KS = D / 4, NKT = KT / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;
+    float* Vs = smem + KT * LD;            // + 16 floats of slack after it: the last d tile of D = 40 reads columns 40..47
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wid * 32;
+    int kb = b;
+    if (p.kv_slot) { kb = p.kv_slot[b]; kb = kb < 0 ? 0 : (kb >= p.n_slots ? p.n_slots - 1 : kb); }
+    const float* Qb = p.Q + (long long)b * p.bsq + h * D;
+    const float* Kb = p.K + (long long)kb * p.bsk + h * D;
+    const float* Vb = p.V + (long long)kb * p.bsv + h * D;
+    const float qscale = p.scale * 1.44269504088896340736f;
+
+    float qf[2][KS];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int qi = q0 + qt * 16 + c; qi = qi < p.Tq ? qi : p.Tq - 1;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qf[qt][s] = Qb[(long long)qi * p.ldq + 4 * s + g] * qscale;
+    }
+    v4f o[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { o[dt][0] = v4f{0.f, 0.f, 0.f, 0.f}; o[dt][1] = v4f{0.f, 0.f, 0.f, 0.f}; }
+    float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
+
+    for (int k0 = 0; k0 < p.Tk; k0 += KT) {
+        __syncthreads();
+        for (int i = tid; i < KT * (D / 4); i += 256) {
+            const int r = i / (D / 4), c4 = i - r * (D / 4), key = k0 + r;
+            v4f kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (key < p.Tk) {
+                kv = *reinterpret_cast<const v4f*>(Kb + (long long)key * p.ldk + 4 * c4);
+                vv = *reinterpret_cast<const v4f*>(Vb + (long long)key * p.ldv + 4 * c4);
+            }
+            *reinterpret_cast<v4f*>(Ks + r * LD + 4 * c4) = kv;
+            *reinterpret_cast<v4f*>(Vs + r * LD + 4 * c4) = vv;
+        }
+        __syncthreads();
+        v4f sacc[NKT][2];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) { sacc[kt][0] = v4f{0.f, 0.f, 0.f, 0.f}; sacc[kt][1] = v4f{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const float a = Ks[(kt * 16 + c) * LD + 4 * s + g];
+                sacc[kt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qf[0][s], sacc[kt][0], 0, 0, 0);
+                sacc[kt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qf[1][s], sacc[kt][1], 0, 0, 0);
+            }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kt * 16 + 4 * g + r;
+                    const float v = key < p.Tk ? sacc[kt][qt][r] : -INFINITY;
+                    sacc[kt][qt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun[qt], mx);          // finite: every key tile holds at least one real key
+            const float alpha = exp2f(mrun[qt] - mnew);
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = exp2f(sacc[kt][qt][r] - mnew);
+                    sacc[kt][qt][r] = pv;
+                    sum += pv;
+                }
+            lrun[qt] = lrun[qt] * alpha + sum;
+            mrun[qt] = mnew;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[dt][qt] *= alpha;
+        }
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const float a = Vs[(kt * 16 + 4 * g + r) * LD + dt * 16 + c];
+                    o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sacc[kt][0][r], o[dt][0], 0, 0, 0);
+                    o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sacc[kt][1][r], o[dt][1], 0, 0, 0);
+                }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = lrun[qt];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int qi = q0 + qt * 16 + c;
+        if (qi >= p.Tq) continue;
+        float* orow = p.O + (long long)b * p.bso + (long long)qi * p.ldo + h * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = dt * 16 + 4 * g;
+            if (d < D) *reinterpret_cast<v4f*>(orow + d) = o[dt][qt] * inv;
+        }
+    }
+}
+
+template <int D, int KT>
+hipError_t launch_attn_t(const AttnParams& p, hipStream_t s) {
+    const size_t lds = (size_t)(2 * KT * (D + 4) + 16) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn32_kernel<D, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((attn32_kernel<D, KT>), dim3((p.Tq + 127) / 128, p.heads, p.B), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+// ---- GroupNorm -----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn32_stats_kernel(const float* X, const float* X2, int HW, int C, int C1, int G, float eps, float* stats) {
+    const int n = blockIdx.x / G, g = blockIdx.x - n * G, cpg = C / G, ch0 = g * cpg, C2 = C - C1;
+    double s = 0.0, ss = 0.0;
+    const long long total = (long long)HW * cpg;
+    for (long long e = threadIdx.x; e < total; e += 256) {
+        const long long px = e / cpg;
+        const int ch = ch0 + (int)(e - px * cpg);
+        const float v = ch < C1 ? X[((long long)n * HW + px) * C1 + ch] : X2[((long long)n * HW + px) * C2 + (ch - C1)];
+        s += (double)v; ss += (double)v * (double)v;
+    }
+    __shared__ double rs[256], rq[256];
+    rs[threadIdx.x] = s; rq[threadIdx.x] = ss;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { rs[threadIdx.x] += rs[threadIdx.x + w]; rq[threadIdx.x] += rq[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean = rs[0] / (double)total;
+        double var = rq[0] / (double)total - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        stats[2 * blockIdx.x] = (float)mean;
+        stats[2 * blockIdx.x + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+__global__ void gn32_apply_kernel(const float* X, const float* X2, long long rows, int HW, int C, int C1, int G, const float* gamma,
+                                  const float* beta, const float* stats, int silu, float* Y) {
+    const int c4n = C / 4, cpg = C / G, C2 = C - C1;
+    const long long total = rows * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / c4n;
+        const int ch = 4 * (int)(i - row * c4n);
+        const int n = (int)(row / HW);
+        const v4f x = ch < C1 ? *reinterpret_cast<const v4f*>(X + row * C1 + ch) : *reinterpret_cast<const v4f*>(X2 + row * C2 + (ch - C1));
+        v4f y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = (ch + j) / cpg;
+            const float mean = stats[2 * (n * G + g)], rstd = stats[2 * (n * G + g) + 1];
+            float v = (x[j] - mean) * rstd * gamma[ch + j] + beta[ch + j];
+            if (silu) v = v / (1.0f + expf(-v));
+            y[j] = v;
+        }
+        *reinterpret_cast<v4f*>(Y + row * C + ch) = y;
+    }
+}
+
+// ---- LayerNorm: one wave per row, two-pass statistics ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln32_kernel(const float* X, int rows, int C, const float* gamma, const float* beta, float eps, float* Y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* x = X + (long long)row * C;
+    float s = 0.f;
+    for (int i = lane; i < C; i += 64) s += x[i];
+    for (int w = 32; w > 0; w >>= 1) s += __shfl_xor(s, w);
+    const float mean = s / (float)C;
+    float q = 0.f;
+    for (int i = lane; i < C; i += 64) { const float d = x[i] - mean; q += d * d; }
+    for (int w = 32; w > 0; w >>= 1) q += __shfl_xor(q, w);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    float* y = Y + (long long)row * C;
+    for (int i = lane; i < C; i += 64) y[i] = (x[i] - mean) * rstd * gamma[i] + beta[i];
+}
+
+__global__ void silu32_kernel(const float* in, float* out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = in[i];
+        out[i] = v / (1.0f + expf(-v));
+    }
+}
+
+__global__ void geglu32_kernel(const float* proj, long long M, int F, float* out) {
+    const int f4 = F / 4;
+    const long long total = M * f4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / f4;
+        const int ch = 4 * (int)(i - row * f4);
+        const v4f a = *reinterpret_cast<const v4f*>(proj + row * 2 * F + ch);
+        const v4f gt = *reinterpret_cast<const v4f*>(proj + row * 2 * F + F + ch);
+        v4f y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = a[j] * (0.5f * gt[j] * (1.0f + erff(gt[j] * 0.70710678118654752440f)));
+        *reinterpret_cast<v4f*>(out + row * F + ch) = y;
+    }
+}
+
+__global__ void temb32_kernel(const int64_t* t, int B, int dim, float* out) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, j = i - b * half;
+    const float freq = expf(-logf(10000.0f) * (float)j / (float)half);
+    const float a = (float)t[b] * freq;
+    out[(long long)b * dim + j] = cosf(a);
+    out[(long long)b * dim + half + j] = sinf(a);
+}
+
+__global__ void conv_in32_kernel(const float* x, const float* w, const float* bias, int B, int Cin, int H, int W, int Cout, float* y) {
+    const long long total = (long long)B * H * W * Cout;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        const long long m = i / Cout;
+        const int ox = (int)(m % W), oy = (int)((m / W) % H), n = (int)(m / ((long long)W * H));
+        float acc = 0.f;
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int dy = 0; dy < 3; ++dy) {
+                const int iy = oy + dy - 1;
+                if (iy < 0 || iy >= H) continue;
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int ix = ox + dx - 1;
+                    if (ix < 0 || ix >= W) continue;
+                    acc += x[(((long long)n * Cin + ci) * H + iy) * W + ix] * w[((co * Cin + ci) * 3 + dy) * 3 + dx];
+                }
+            }
+        y[i] = acc + bias[co];
+    }
+}
+
+// one wave per output pixel: lanes over channels, Cout <= 8 accumulators, shuffle reduction
+__global__ __launch_bounds__(256) void conv_out32_kernel(const float* x, const float* w, const float* bias, int B, int H, int W, int C, int Cout, float* y) {
+    const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (m >= (long long)B * H * W) return;
+    const int ox = (int)(m % W), oy = (int)((m / W) % H), n = (int)(m / ((long long)W * H));
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int tap = 0; tap < 9; ++tap) {
+        const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        const float* xr = x + (((long long)n * H + iy) * W + ix) * C;
+        for (int ch = lane; ch < C; ch += 64) {
+            const float v = xr[ch];
+            for (int co = 0; co < Cout; ++co) acc[co] += v * w[((long long)co * 9 + tap) * C + ch];
+        }
+    }
+    for (int co = 0; co < Cout; ++co) {
+        float v = acc[co];
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+        if (lane == 0) y[(((long long)n * Cout + co) * H + oy) * W + ox] = v + bias[co];
+    }
+}
+
+__global__ void nhwc_to_nchw32_kernel(const float* X, int N, int HW, int C, float* Y) {
+    const long long total = (long long)N * HW * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % HW);
+        const long long nc = i / HW;
+        const int ch = (int)(nc % C);
+        const long long n = nc / C;
+        Y[i] = X[(n * HW + px) * C + ch];
+    }
+}
+
+__global__ void ensemble_mean32_kernel(const float* X, int groups, int ens, int HW, int C, float* Y) {
+    const long long total = (long long)groups * HW * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % HW);
+        const long long gc = i / HW;
+        const int ch = (int)(gc % C);
+        const long long gi = gc / C;
+        float s = 0.f;
+        for (int k = 0; k < ens; ++k) s += X[((gi * ens + k) * HW + px) * C + ch];
+        Y[i] = s / (float)ens;
+    }
+}
+
+inline unsigned grid_for(long long n, int block = 256) {
+    long long g = (n + block - 1) / block;
+    return (unsigned)(g < 1 ? 1 : (g > 65536 * 16 ? 65536 * 16 : g));
+}
+
+}  // namespace
+
+hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
+    if (p.B <= 0 || p.Tq <= 0 || p.Tk <= 0 || (p.ldq | p.ldk | p.ldv | p.ldo) % 4 != 0) return hipErrorInvalidValue;
+    switch (p.D) {
+        case 40: return launch_attn_t<40, 64>(p, s);
+        case 80: return launch_attn_t<80, 64>(p, s);
+        case 160: return launch_attn_t<160, 64>(p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_gn_stats(const float* X, const float* X2, int N, int HW, int C, int C1, int G, float eps, float* stats, hipStream_t s) {
+    if (C % G != 0 || (C1 < C && !X2)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn32_stats_kernel, dim3(N * G), dim3(256), 0, s, X, X2, HW, C, C1, G, eps, stats);
+    return hipGetLastError();
+}
+hipError_t launch_gn_apply(const float* X, const float* X2, int N, int HW, int C, int C1, int G, const float* gamma, const float* beta,
+                           const float* stats, int silu, float* Y, hipStream_t s) {
+    if (C % 4 != 0 || C1 % 4 != 0) return hipErrorInvalidValue;
+    const long long rows = (long long)N * HW;
+    hipLaunchKernelGGL(gn32_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, s, X, X2, rows, HW, C, C1, G, gamma, beta, stats, silu, Y);
+    return hipGetLastError();
+}
+hipError_t launch_layernorm(const float* X, int rows, int C, const float* gamma, const float* beta, float eps, float* Y, hipStream_t s) {
+    hipLaunchKernelGGL(ln32_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, X, rows, C, gamma, beta, eps, Y);
+    return hipGetLastError();
+}
+hipError_t launch_silu(const float* in, float* out, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(silu32_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
+    return hipGetLastError();
+}
+hipError_t launch_geglu(const float* proj, long long M, int F, float* out, hipStream_t s) {
+    if (F % 4 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(geglu32_kernel, dim3(grid_for(M * (F / 4))), dim3(256), 0, s, proj, M, F, out);
+    return hipGetLastError();
+}
+hipError_t launch_timestep_embed(const int64_t* t, int B, int dim, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(temb32_kernel, dim3((B * (dim / 2) + 255) / 256), dim3(256), 0, s, t, B, dim, out);
+    return hipGetLastError();
+}
+hipError_t launch_conv_in(const float* x, const float* w, const float* bias, int B, int Cin, int H, int W, int Cout, float* y, hipStream_t s) {
+    hipLaunchKernelGGL(conv_in32_kernel, dim3(grid_for((long long)B * H * W * Cout)), dim3(256), 0, s, x, w, bias, B, Cin, H, W, Cout, y);
+    return hipGetLastError();
+}
+hipError_t launch_conv_out(const float* x, const float* w, const float* bias, int B, int H, int W, int C, int Cout, float* y, hipStream_t s) {
+    if (Cout > 8) return hipErrorInvalidValue;
+    const long long px = (long long)B * H * W;
+    hipLaunchKernelGGL(conv_out32_kernel, dim3((unsigned)((px + 3) / 4)), dim3(256), 0, s, x, w, bias, B, H, W, C, Cout, y);
+    return hipGetLastError();
+}
+hipError_t launch_nhwc_to_nchw(const float* X, int N, int HW, int C, float* Y, hipStream_t s) {
+    hipLaunchKernelGGL(nhwc_to_nchw32_kernel, dim3(grid_for((long long)N * HW * C)), dim3(256), 0, s, X, N, HW, C, Y);
+    return hipGetLastError();
+}
+hipError_t launch_ensemble_mean(const float* X, int groups, int ens, int HW, int C, float* Y, hipStream_t s) {
+    hipLaunchKernelGGL(ensemble_mean32_kernel, dim3(grid_for((long long)groups * HW * C)), dim3(256), 0, s, X, groups, ens, HW, C, Y);
+    return hipGetLastError();
+}
+
+}  // namespace dm32

@@ -1,0 +1,656 @@
+// unet_f32.hip — the SDv1.5 U-Net in plain fp32 on the fp32 matrix cores: the arithmetic of the reference's DIFT featuriser.
+//
+// `SDFeaturizer.__init__` (diffmining/typicality/dift.py:197-199) builds `OneStepSDPipeline.from_pretrained(sd_id, unet=unet,
+// safety_checker=None)` with NO torch_dtype and calls the U-Net with NO autocast (dift.py:191): every tensor and every product
+// of that path is fp32.  The fp16 engine (engine.hip) reproduces the autocast arithmetic of the typicality path
+// (compute.py:98-101); this file is the second arithmetic the reference uses, behind its own C-ABI handle (include/dm_engine.h,
+// dm_f32_*): fp32 weights, fp32 NHWC activations, v_mfma_f32_16x16x4_f32 GEMMs (f32_gemm.hip) and attention (f32_ops.hip).
+// It runs the whole U-Net (dm_f32_unet_forward) or the early exit after up_blocks[i] (dm_f32_dift), so it is also the
+// full-size fp32 ground truth on the GPU that the CPU oracle is too slow for.
+//
+// Schedule = MyUNet2DConditionModel.forward (dift.py:24-169) op by op, nothing folded or fused beyond the GEMM epilogue
+// (bias, time embedding, residual); cross-attention K/V are projected once per registered prompt.
+#include "f32_kernels.h"
+#include "arena.h"
+#include "../../include/dm_engine.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include <hip/hip_fp16.h>
+
+using namespace dm32;
+
+namespace {
+
+constexpr int NB = 4;
+const int BOC[NB] = {320, 640, 1280, 1280};
+constexpr int LAYERS = 2, CTX_DIM = 768, CTX_LEN = 77, HEADS = 8, GROUPS = 32, TEMB = 1280;
+constexpr float GN_EPS = 1e-5f, ATTN_GN_EPS = 1e-6f, LN_EPS = 1e-5f;
+const bool DOWN_ATTN[NB] = {true, true, true, false};
+const bool UP_ATTN[NB] = {false, true, true, true};
+constexpr size_t NONE = (size_t)-1;
+
+thread_local std::string g_create_error32;
+
+struct HostT { std::vector<float> data; std::vector<int64_t> shape; bool used = false; };
+// offsets (in floats) into the weight slab
+struct Conv { size_t w = NONE, b = NONE; int cin = 0, cout = 0, k = 0; };
+struct Norm { size_t g = NONE, b = NONE; int c = 0; };
+struct Res { Norm n1, n2; Conv c1, c2, sc; bool has_sc = false; int temb_off = 0; };
+struct Tfm { Norm gn, ln1, ln2, ln3; Conv proj_in, proj_out, qkv, o1, q2, kv2, o2, ff1, ff2; int c = 0, layer = 0; };
+struct DownB { Res res[2]; Tfm tf[2]; bool attn = false; Conv down; bool has_down = false; };
+struct UpB { Res res[3]; Tfm tf[3]; bool attn = false; Conv up; bool has_up = false; };
+
+struct T32 {                // NHWC fp32 activation in the arena
+    size_t off = NONE; float* p = nullptr; int N = 0, H = 0, W = 0, C = 0;
+    long long rows() const { return (long long)N * H * W; }
+};
+struct Ev { hipEvent_t a, b; double flops; int kind; };
+
+}  // namespace
+
+struct dm_f32_net {
+    int device = 0;
+    std::string err;
+    std::map<std::string, HostT> host;
+    bool finalized = false;
+    std::vector<float> blob;           // host staging of the slab (freed after upload)
+    float* slab = nullptr; size_t slab_floats = 0;
+    Conv conv_in, conv_out, time1, time2, tproj_all;
+    Norm norm_out;
+    DownB down[NB]; Res mid_res[2]; Tfm mid_tf; UpB up[NB];
+    int tproj_total = 0, n_tf = 0;
+    std::vector<Tfm*> tfs;
+    std::vector<float> tw, tb;         // stacked time_emb_proj rows / biases while packing
+    int n_prompts = 0, kv_capacity = 0;
+    std::vector<float*> kv_cache;      // per transformer layer [P*77][2C]
+    dm::Arena arena; char* arena_base = nullptr; size_t arena_cap = 0;
+    bool prof = false;
+    std::vector<Ev> evs; std::vector<hipEvent_t> ev_pool;
+    double prof_ms[2] = {0, 0}, prof_flops[2] = {0, 0}; long long prof_n[2] = {0, 0};
+};
+
+namespace {
+
+#define F_FAIL(e, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (e)->err = _b; return 1; } while (0)
+#define F_HIP(e, call) do { hipError_t _r = (call); if (_r != hipSuccess) { \
+    char _b[512]; snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #call, hipGetErrorString(_r), __FILE__, __LINE__); \
+    (e)->err = _b; return 1; } } while (0)
+#define F_TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+// ---- packing ---------------------------------------------------------------------------------------------------------------
+HostT* get(dm_f32_net* e, const std::string& name, std::initializer_list<int64_t> shape) {
+    auto it = e->host.find(name);
+    if (it == e->host.end()) { e->err = "missing tensor: " + name; return nullptr; }
+    if (it->second.shape != std::vector<int64_t>(shape)) { e->err = "shape mismatch for " + name; return nullptr; }
+    it->second.used = true;
+    return &it->second;
+}
+size_t put(dm_f32_net* e, const float* src, size_t n) {
+    const size_t off = (e->blob.size() + 63) & ~(size_t)63;
+    e->blob.resize(off + n);
+    memcpy(e->blob.data() + off, src, n * sizeof(float));
+    return off;
+}
+int pack_vec(dm_f32_net* e, const std::string& name, int c, size_t* off) {
+    HostT* t = get(e, name, {c});
+    if (!t) return 1;
+    *off = put(e, t->data.data(), (size_t)c);
+    return 0;
+}
+int pack_conv3(dm_f32_net* e, const std::string& name, int cout, int cin, Conv* o) {      // [cout][cin][3][3] -> [cout][(tap, cin)]
+    HostT* w = get(e, name + ".weight", {cout, cin, 3, 3});
+    if (!w) return 1;
+    std::vector<float> pk((size_t)cout * 9 * cin);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int tap = 0; tap < 9; ++tap) pk[((size_t)co * 9 + tap) * cin + ci] = w->data[((size_t)co * cin + ci) * 9 + tap];
+    o->w = put(e, pk.data(), pk.size());
+    o->cin = cin; o->cout = cout; o->k = 3;
+    return pack_vec(e, name + ".bias", cout, &o->b);
+}
+int pack_dense(dm_f32_net* e, const std::string& name, int cout, int cin, bool conv1x1, bool bias, Conv* o) {
+    HostT* w = conv1x1 ? get(e, name + ".weight", {cout, cin, 1, 1}) : get(e, name + ".weight", {cout, cin});
+    if (!w) return 1;
+    o->w = put(e, w->data.data(), (size_t)cout * cin);
+    o->cin = cin; o->cout = cout; o->k = 1; o->b = NONE;
+    return bias ? pack_vec(e, name + ".bias", cout, &o->b) : 0;
+}
+int pack_norm(dm_f32_net* e, const std::string& name, int c, Norm* o) {
+    o->c = c;
+    F_TRY(pack_vec(e, name + ".weight", c, &o->g));
+    return pack_vec(e, name + ".bias", c, &o->b);
+}
+int pack_stack(dm_f32_net* e, const std::vector<std::string>& names, int rows_each, int cin, Conv* o) {
+    std::vector<float> pk((size_t)names.size() * rows_each * cin);
+    for (size_t i = 0; i < names.size(); ++i) {
+        HostT* w = get(e, names[i] + ".weight", {rows_each, cin});
+        if (!w) return 1;
+        memcpy(pk.data() + i * (size_t)rows_each * cin, w->data.data(), (size_t)rows_each * cin * sizeof(float));
+    }
+    o->w = put(e, pk.data(), pk.size());
+    o->cin = cin; o->cout = (int)names.size() * rows_each; o->k = 1; o->b = NONE;
+    return 0;
+}
+int pack_res(dm_f32_net* e, const std::string& name, int cin, int cout, Res* r) {
+    F_TRY(pack_norm(e, name + ".norm1", cin, &r->n1));
+    F_TRY(pack_conv3(e, name + ".conv1", cout, cin, &r->c1));
+    HostT* w = get(e, name + ".time_emb_proj.weight", {cout, TEMB});
+    HostT* b = get(e, name + ".time_emb_proj.bias", {cout});
+    if (!w || !b) return 1;
+    r->temb_off = (int)e->tb.size();
+    e->tw.insert(e->tw.end(), w->data.begin(), w->data.end());
+    e->tb.insert(e->tb.end(), b->data.begin(), b->data.end());
+    F_TRY(pack_norm(e, name + ".norm2", cout, &r->n2));
+    F_TRY(pack_conv3(e, name + ".conv2", cout, cout, &r->c2));
+    r->has_sc = cin != cout;
+    if (r->has_sc) F_TRY(pack_dense(e, name + ".conv_shortcut", cout, cin, true, true, &r->sc));
+    return 0;
+}
+int pack_tfm(dm_f32_net* e, const std::string& name, int c, Tfm* t) {
+    t->c = c; t->layer = e->n_tf++;
+    e->tfs.push_back(t);
+    F_TRY(pack_norm(e, name + ".norm", c, &t->gn));
+    F_TRY(pack_dense(e, name + ".proj_in", c, c, true, true, &t->proj_in));
+    const std::string b = name + ".transformer_blocks.0";
+    F_TRY(pack_norm(e, b + ".norm1", c, &t->ln1));
+    F_TRY(pack_stack(e, {b + ".attn1.to_q", b + ".attn1.to_k", b + ".attn1.to_v"}, c, c, &t->qkv));
+    F_TRY(pack_dense(e, b + ".attn1.to_out.0", c, c, false, true, &t->o1));
+    F_TRY(pack_norm(e, b + ".norm2", c, &t->ln2));
+    F_TRY(pack_dense(e, b + ".attn2.to_q", c, c, false, false, &t->q2));
+    F_TRY(pack_stack(e, {b + ".attn2.to_k", b + ".attn2.to_v"}, c, CTX_DIM, &t->kv2));
+    F_TRY(pack_dense(e, b + ".attn2.to_out.0", c, c, false, true, &t->o2));
+    F_TRY(pack_norm(e, b + ".norm3", c, &t->ln3));
+    F_TRY(pack_dense(e, b + ".ff.net.0.proj", 8 * c, c, false, true, &t->ff1));
+    F_TRY(pack_dense(e, b + ".ff.net.2", c, 4 * c, false, true, &t->ff2));
+    F_TRY(pack_dense(e, name + ".proj_out", c, c, true, true, &t->proj_out));
+    return 0;
+}
+
+// ---- forward -----------------------------------------------------------------------------------------------------------------
+struct Fwd32 {
+    dm_f32_net* e; hipStream_t s; bool dry;
+    const float* P(size_t off) const { return off == NONE ? nullptr : e->slab + off; }
+
+    int alloc(T32* t, int N, int H, int W, int C) {
+        t->N = N; t->H = H; t->W = W; t->C = C;
+        const size_t bytes = (size_t)N * H * W * C * sizeof(float);
+        t->off = e->arena.alloc(bytes);
+        if (t->off == NONE) F_FAIL(e, "fp32 workspace arena exhausted (%zu bytes requested)", bytes);
+        t->p = reinterpret_cast<float*>(e->arena_base + t->off);
+        return 0;
+    }
+    void free(T32& t) { if (t.off != NONE) { e->arena.release(t.off); t.off = NONE; t.p = nullptr; } }
+    int prof_begin(int kind, double flops) {
+        if (!e->prof || dry) return 0;
+        Ev ev; ev.flops = flops; ev.kind = kind;
+        for (hipEvent_t* h : {&ev.a, &ev.b}) {
+            if (!e->ev_pool.empty()) { *h = e->ev_pool.back(); e->ev_pool.pop_back(); }
+            else F_HIP(e, hipEventCreate(h));
+        }
+        F_HIP(e, hipEventRecord(ev.a, s));
+        e->evs.push_back(ev);
+        return 0;
+    }
+    int prof_end() { if (e->prof && !dry) F_HIP(e, hipEventRecord(e->evs.back().b, s)); return 0; }
+
+    int gemm(const Conv& cv, int mode, const T32& x, const T32* x2, int OH, int OW, const float* temb, int temb_ld, const T32* res, T32* y) {
+        const int cin = x.C + (x2 ? x2->C : 0);
+        if (cin != cv.cin) F_FAIL(e, "gemm32: channel mismatch %d vs %d", cin, cv.cin);
+        F_TRY(alloc(y, x.N, OH, OW, cv.cout));
+        if (dry) return 0;
+        GemmParams p;
+        p.X = x.p; p.X2 = x2 ? x2->p : nullptr; p.Wp = P(cv.w); p.bias = P(cv.b); p.temb = temb; p.res = res ? res->p : nullptr; p.Y = y->p;
+        p.Cout = cv.cout; p.Cin = cin; p.C1 = x.C; p.mode = mode; p.ldy = cv.cout; p.ldres = res ? res->C : 0; p.temb_ld = temb_ld;
+        if (mode == 0) { p.M = (int)x.rows(); p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M; }
+        else { p.M = x.N * OH * OW; p.H = x.H; p.W = x.W; p.OH = OH; p.OW = OW; }
+        F_TRY(prof_begin(0, 2.0 * (double)p.M * cv.cout * (double)((mode == 0 ? 1 : 9) * cin)));
+        F_HIP(e, launch_gemm(p, s));
+        return prof_end();
+    }
+    int dense(const Conv& cv, const T32& x, const T32* x2, const T32* res, T32* y) { return gemm(cv, 0, x, x2, x.H, x.W, nullptr, 0, res, y); }
+    int groupnorm(const Norm& nw, const T32& x, const T32* x2, float eps, bool silu, T32* y) {
+        const int C = x.C + (x2 ? x2->C : 0);
+        if (C != nw.c) F_FAIL(e, "groupnorm32: channel mismatch %d vs %d", C, nw.c);
+        T32 st;
+        F_TRY(alloc(&st, 1, 1, x.N * GROUPS, 2));
+        F_TRY(alloc(y, x.N, x.H, x.W, C));
+        if (!dry) {
+            F_HIP(e, launch_gn_stats(x.p, x2 ? x2->p : nullptr, x.N, x.H * x.W, C, x.C, GROUPS, eps, st.p, s));
+            F_HIP(e, launch_gn_apply(x.p, x2 ? x2->p : nullptr, x.N, x.H * x.W, C, x.C, GROUPS, P(nw.g), P(nw.b), st.p, silu ? 1 : 0, y->p, s));
+        }
+        free(st);
+        return 0;
+    }
+    int layernorm(const Norm& nw, const T32& x, T32* y) {
+        F_TRY(alloc(y, x.N, x.H, x.W, x.C));
+        if (!dry) F_HIP(e, launch_layernorm(x.p, (int)x.rows(), x.C, P(nw.g), P(nw.b), LN_EPS, y->p, s));
+        return 0;
+    }
+    int resnet(const Res& r, const T32& x, const T32* x2, const float* tproj, T32* out) {      // ResnetBlock2D
+        T32 n1, h1, n2, sc;
+        F_TRY(groupnorm(r.n1, x, x2, GN_EPS, true, &n1));
+        F_TRY(gemm(r.c1, 1, n1, nullptr, x.H, x.W, tproj ? tproj + r.temb_off : nullptr, e->tproj_total, nullptr, &h1));
+        free(n1);
+        F_TRY(groupnorm(r.n2, h1, nullptr, GN_EPS, true, &n2));
+        free(h1);
+        const T32* resid = &x;
+        if (r.has_sc) { F_TRY(dense(r.sc, x, x2, nullptr, &sc)); resid = &sc; }
+        else if (x2) F_FAIL(e, "resnet32: concat input without shortcut conv");
+        F_TRY(gemm(r.c2, 1, n2, nullptr, x.H, x.W, nullptr, 0, resid, out));
+        free(n2);
+        if (r.has_sc) free(sc);
+        return 0;
+    }
+    int attention(const float* Q, int ldq, long long bsq, const float* K, const float* V, int ldkv, long long bskv, const int32_t* slots,
+                  int B, int Tq, int Tk, int C, float* O) {
+        AttnParams a;
+        a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.ldo = C;
+        a.bsq = bsq; a.bsk = bskv; a.bsv = bskv; a.bso = (long long)Tq * C;
+        a.kv_slot = slots; a.n_slots = e->n_prompts; a.B = B; a.heads = HEADS; a.Tq = Tq; a.Tk = Tk; a.D = C / HEADS;
+        a.scale = 1.0f / sqrtf((float)a.D);
+        F_TRY(prof_begin(1, 4.0 * B * HEADS * (double)Tq * Tk * a.D));
+        F_HIP(e, launch_attention(a, s));
+        return prof_end();
+    }
+    int transformer(const Tfm& t, const T32& x, const int32_t* slots, T32* out) {       // Transformer2DModel + BasicTransformerBlock
+        const int C = t.c, T = x.H * x.W, B = x.N;
+        T32 n, t0, ln, qkv, a, t1, q, t2, pr, ff, t3;
+        F_TRY(groupnorm(t.gn, x, nullptr, ATTN_GN_EPS, false, &n));
+        F_TRY(dense(t.proj_in, n, nullptr, nullptr, &t0));
+        free(n);
+        F_TRY(layernorm(t.ln1, t0, &ln));
+        F_TRY(dense(t.qkv, ln, nullptr, nullptr, &qkv));
+        free(ln);
+        F_TRY(alloc(&a, B, x.H, x.W, C));
+        if (!dry) F_TRY(attention(qkv.p, 3 * C, (long long)T * 3 * C, qkv.p + C, qkv.p + 2 * C, 3 * C, (long long)T * 3 * C, nullptr, B, T, T, C, a.p));
+        free(qkv);
+        F_TRY(dense(t.o1, a, nullptr, &t0, &t1));
+        free(a); free(t0);
+        F_TRY(layernorm(t.ln2, t1, &ln));
+        F_TRY(dense(t.q2, ln, nullptr, nullptr, &q));
+        free(ln);
+        F_TRY(alloc(&a, B, x.H, x.W, C));
+        if (!dry) {
+            const float* kv = e->kv_cache[t.layer];
+            F_TRY(attention(q.p, C, (long long)T * C, kv, kv + C, 2 * C, (long long)CTX_LEN * 2 * C, slots, B, T, CTX_LEN, C, a.p));
+        }
+        free(q);
+        F_TRY(dense(t.o2, a, nullptr, &t1, &t2));
+        free(a); free(t1);
+        F_TRY(layernorm(t.ln3, t2, &ln));
+        F_TRY(dense(t.ff1, ln, nullptr, nullptr, &pr));
+        free(ln);
+        F_TRY(alloc(&ff, B, x.H, x.W, 4 * C));
+        if (!dry) F_HIP(e, launch_geglu(pr.p, pr.rows(), 4 * C, ff.p, s));
+        free(pr);
+        F_TRY(dense(t.ff2, ff, nullptr, &t2, &t3));
+        free(ff); free(t2);
+        F_TRY(dense(t.proj_out, t3, nullptr, &x, out));
+        free(t3);
+        return 0;
+    }
+};
+
+struct Args32 {
+    const float* x; const int64_t* t; const int32_t* slots; int B, H, W; int up_ft_index;
+    float* out; float* feat; float* feat_mean; int ensemble;
+};
+
+int run_forward32(dm_f32_net* e, const Args32& A, hipStream_t s, bool dry) {
+    Fwd32 F{e, s, dry};
+    const int B = A.B;
+    T32 te0, e1, e1s, emb, embs, tproj;
+    F_TRY(F.alloc(&te0, 1, 1, B, BOC[0]));
+    if (!dry) F_HIP(e, launch_timestep_embed(A.t, B, BOC[0], te0.p, s));
+    F_TRY(F.dense(e->time1, te0, nullptr, nullptr, &e1));
+    F.free(te0);
+    F_TRY(F.alloc(&e1s, 1, 1, B, TEMB));
+    if (!dry) F_HIP(e, launch_silu(e1.p, e1s.p, (long long)B * TEMB, s));
+    F.free(e1);
+    F_TRY(F.dense(e->time2, e1s, nullptr, nullptr, &emb));
+    F.free(e1s);
+    F_TRY(F.alloc(&embs, 1, 1, B, TEMB));
+    if (!dry) F_HIP(e, launch_silu(emb.p, embs.p, (long long)B * TEMB, s));
+    F.free(emb);
+    F_TRY(F.dense(e->tproj_all, embs, nullptr, nullptr, &tproj));
+    F.free(embs);
+
+    T32 h;
+    F_TRY(F.alloc(&h, B, A.H, A.W, BOC[0]));
+    if (!dry) F_HIP(e, launch_conv_in(A.x, F.P(e->conv_in.w), F.P(e->conv_in.b), B, 4, A.H, A.W, BOC[0], h.p, s));
+    std::vector<T32> skips;
+    skips.push_back(h);
+    T32 cur = h;                     // aliases the newest skip (not freed here)
+    for (int i = 0; i < NB; ++i) {
+        const DownB& d = e->down[i];
+        for (int j = 0; j < LAYERS; ++j) {
+            T32 r;
+            F_TRY(F.resnet(d.res[j], cur, nullptr, tproj.p, &r));
+            if (d.attn) { T32 a; F_TRY(F.transformer(d.tf[j], r, A.slots, &a)); F.free(r); r = a; }
+            skips.push_back(r);
+            cur = r;
+        }
+        if (d.has_down) {
+            T32 dn;
+            F_TRY(F.gemm(d.down, 2, cur, nullptr, (cur.H + 1) / 2, (cur.W + 1) / 2, nullptr, 0, nullptr, &dn));
+            skips.push_back(dn);
+            cur = dn;
+        }
+    }
+    T32 m0, m1, m2;
+    F_TRY(F.resnet(e->mid_res[0], cur, nullptr, tproj.p, &m0));
+    F_TRY(F.transformer(e->mid_tf, m0, A.slots, &m1));
+    F.free(m0);
+    F_TRY(F.resnet(e->mid_res[1], m1, nullptr, tproj.p, &m2));
+    F.free(m1);
+    cur = m2;                        // owned from here on
+    const bool fwd_up_size = (A.H % 8 != 0) || (A.W % 8 != 0);          // dift.py:54-56
+    for (int i = 0; i < NB; ++i) {
+        if (A.up_ft_index >= 0 && i > A.up_ft_index) break;
+        const UpB& u = e->up[i];
+        for (int j = 0; j < LAYERS + 1; ++j) {
+            T32 skip = skips.back(); skips.pop_back();
+            T32 r;
+            F_TRY(F.resnet(u.res[j], cur, &skip, tproj.p, &r));
+            F.free(cur); F.free(skip);
+            if (u.attn) { T32 a; F_TRY(F.transformer(u.tf[j], r, A.slots, &a)); F.free(r); r = a; }
+            cur = r;
+        }
+        if (u.has_up) {
+            int OH = cur.H * 2, OW = cur.W * 2;
+            if (fwd_up_size && !skips.empty()) { OH = skips.back().H; OW = skips.back().W; }
+            T32 upc;
+            F_TRY(F.gemm(u.up, 3, cur, nullptr, OH, OW, nullptr, 0, nullptr, &upc));
+            F.free(cur);
+            cur = upc;
+        }
+        if (A.up_ft_index == i && !dry) {
+            if (A.feat) F_HIP(e, launch_nhwc_to_nchw(cur.p, cur.N, cur.H * cur.W, cur.C, A.feat, s));
+            if (A.feat_mean) F_HIP(e, launch_ensemble_mean(cur.p, cur.N / A.ensemble, A.ensemble, cur.H * cur.W, cur.C, A.feat_mean, s));
+        }
+    }
+    if (A.up_ft_index < 0) {
+        T32 nrm;
+        F_TRY(F.groupnorm(e->norm_out, cur, nullptr, GN_EPS, true, &nrm));
+        if (!dry) F_HIP(e, launch_conv_out(nrm.p, F.P(e->conv_out.w), F.P(e->conv_out.b), B, A.H, A.W, BOC[0], 4, A.out, s));
+        F.free(nrm);
+    }
+    F.free(cur);
+    for (auto& sk : skips) F.free(sk);
+    F.free(tproj);
+    return 0;
+}
+
+int ensure_arena32(dm_f32_net* e, const Args32& A, hipStream_t s) {
+    e->arena.reset((size_t)1 << 46, true);
+    F_TRY(run_forward32(e, A, s, true));
+    const size_t need = e->arena.peak + (1 << 20);
+    if (need > e->arena_cap) {
+        if (e->arena_base) { F_HIP(e, hipStreamSynchronize(s)); F_HIP(e, hipFree(e->arena_base)); e->arena_base = nullptr; e->arena_cap = 0; }
+        F_HIP(e, hipMalloc((void**)&e->arena_base, need));
+        e->arena_cap = need;
+    }
+    e->arena.reset(e->arena_cap, false);
+    return 0;
+}
+
+// samples per run: the widest intermediate is the GEGLU projection ([tokens][8 C] fp32 = 42 MB per sample at a 64 x 64 latent)
+int chunk32(int h, int w) {
+    const long long area = (long long)h * w;
+    long long c = 64LL * 4096 / (area > 0 ? area : 1);
+    return (int)(c < 1 ? 1 : (c > 1024 ? 1024 : c));
+}
+
+int run_chunked32(dm_f32_net* e, Args32 A, void* stream) {
+    if (!e->finalized) F_FAIL(e, "fp32 net not finalized");
+    if (e->n_prompts <= 0) F_FAIL(e, "dm_f32_set_prompts must be called first");
+    if (A.B <= 0 || A.H < 1 || A.W < 1) F_FAIL(e, "bad batch / latent size");
+    F_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    int chunk = chunk32(A.H, A.W);
+    if (A.feat_mean) {                       // an ensemble never straddles two runs
+        if (A.ensemble <= 0 || A.B % A.ensemble != 0) F_FAIL(e, "batch %d is not a multiple of ensemble %d", A.B, A.ensemble);
+        chunk = chunk >= A.ensemble ? chunk / A.ensemble * A.ensemble : A.ensemble;
+    }
+    int c_out = 0, oh = 0, ow = 0;
+    if (A.up_ft_index >= 0 && dm_dift_shape(A.H, A.W, A.up_ft_index, &c_out, &oh, &ow)) F_FAIL(e, "bad up_ft_index %d", A.up_ft_index);
+    const Args32 full = A;
+    for (int b0 = 0; b0 < full.B; b0 += chunk) {
+        Args32 C = full;
+        C.B = (full.B - b0 < chunk) ? full.B - b0 : chunk;
+        C.x = full.x + (size_t)b0 * 4 * full.H * full.W;
+        C.t = full.t + b0;
+        C.slots = full.slots + b0;
+        if (full.out) C.out = full.out + (size_t)b0 * 4 * full.H * full.W;
+        if (full.feat) C.feat = full.feat + (size_t)b0 * c_out * oh * ow;
+        if (full.feat_mean) C.feat_mean = full.feat_mean + (size_t)(b0 / full.ensemble) * c_out * oh * ow;
+        F_TRY(ensure_arena32(e, C, s));
+        F_TRY(run_forward32(e, C, s, false));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dm_f32_create(int device, dm_f32_net** out) {
+    if (!out) return 1;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { g_create_error32 = "no such HIP device"; return 1; }
+    dm_f32_net* e = new dm_f32_net();
+    e->device = device;
+    *out = e;
+    return 0;
+}
+
+void dm_f32_destroy(dm_f32_net* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    if (e->slab) (void)hipFree(e->slab);
+    if (e->arena_base) (void)hipFree(e->arena_base);
+    for (float* p : e->kv_cache) if (p) (void)hipFree(p);
+    for (auto& ev : e->evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (hipEvent_t h : e->ev_pool) (void)hipEventDestroy(h);
+    delete e;
+}
+
+const char* dm_f32_last_error(dm_f32_net* e) { return e ? e->err.c_str() : g_create_error32.c_str(); }
+
+int dm_f32_load_weight(dm_f32_net* e, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim) {
+    if (!e || !name || !host_ptr || !shape) return 1;
+    if (e->finalized) F_FAIL(e, "load_weight after finalize");
+    HostT t;
+    t.shape.assign(shape, shape + ndim);
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    t.data.resize(n);
+    if (dtype == DM_F32) memcpy(t.data.data(), host_ptr, n * sizeof(float));
+    else if (dtype == DM_F16) { const _Float16* h = (const _Float16*)host_ptr; for (size_t i = 0; i < n; ++i) t.data[i] = (float)h[i]; }
+    else F_FAIL(e, "unsupported dtype %d for %s", dtype, name);
+    e->host[name] = std::move(t);
+    return 0;
+}
+
+int dm_f32_finalize(dm_f32_net* e) {
+    if (!e) return 1;
+    if (e->finalized) return 0;
+    F_HIP(e, hipSetDevice(e->device));
+    {   // conv_in keeps the PyTorch layout (direct kernel); conv_out is packed (tap, c)
+        HostT* w = get(e, "conv_in.weight", {BOC[0], 4, 3, 3});
+        if (!w) return 1;
+        e->conv_in.w = put(e, w->data.data(), w->data.size());
+        e->conv_in.cin = 4; e->conv_in.cout = BOC[0]; e->conv_in.k = 3;
+        F_TRY(pack_vec(e, "conv_in.bias", BOC[0], &e->conv_in.b));
+    }
+    F_TRY(pack_dense(e, "time_embedding.linear_1", TEMB, BOC[0], false, true, &e->time1));
+    F_TRY(pack_dense(e, "time_embedding.linear_2", TEMB, TEMB, false, true, &e->time2));
+    int cin = BOC[0];
+    for (int i = 0; i < NB; ++i) {
+        DownB& d = e->down[i];
+        d.attn = DOWN_ATTN[i];
+        for (int j = 0; j < LAYERS; ++j) {
+            const std::string b = "down_blocks." + std::to_string(i);
+            F_TRY(pack_res(e, b + ".resnets." + std::to_string(j), cin, BOC[i], &d.res[j]));
+            if (d.attn) F_TRY(pack_tfm(e, b + ".attentions." + std::to_string(j), BOC[i], &d.tf[j]));
+            cin = BOC[i];
+        }
+        d.has_down = i != NB - 1;
+        if (d.has_down) F_TRY(pack_conv3(e, "down_blocks." + std::to_string(i) + ".downsamplers.0.conv", BOC[i], BOC[i], &d.down));
+    }
+    F_TRY(pack_res(e, "mid_block.resnets.0", BOC[NB - 1], BOC[NB - 1], &e->mid_res[0]));
+    F_TRY(pack_tfm(e, "mid_block.attentions.0", BOC[NB - 1], &e->mid_tf));
+    F_TRY(pack_res(e, "mid_block.resnets.1", BOC[NB - 1], BOC[NB - 1], &e->mid_res[1]));
+    // up blocks: reversed channel list; resnet j of block i takes cat([hidden, skip]) (UNet2DConditionModel.__init__)
+    int prev = BOC[NB - 1];
+    for (int i = 0; i < NB; ++i) {
+        UpB& u = e->up[i];
+        u.attn = UP_ATTN[i];
+        const int out_c = BOC[NB - 1 - i];
+        const int in_c = BOC[(NB - 2 - i) < 0 ? 0 : (NB - 2 - i)];
+        for (int j = 0; j < LAYERS + 1; ++j) {
+            const int skip_c = (j == LAYERS) ? in_c : out_c;
+            const int res_in = (j == 0) ? prev : out_c;
+            const std::string b = "up_blocks." + std::to_string(i);
+            F_TRY(pack_res(e, b + ".resnets." + std::to_string(j), res_in + skip_c, out_c, &u.res[j]));
+            if (u.attn) F_TRY(pack_tfm(e, b + ".attentions." + std::to_string(j), out_c, &u.tf[j]));
+        }
+        u.has_up = i != NB - 1;
+        if (u.has_up) F_TRY(pack_conv3(e, "up_blocks." + std::to_string(i) + ".upsamplers.0.conv", out_c, out_c, &u.up));
+        prev = out_c;
+    }
+    F_TRY(pack_norm(e, "conv_norm_out", BOC[0], &e->norm_out));
+    F_TRY(pack_conv3(e, "conv_out", 4, BOC[0], &e->conv_out));
+    e->tproj_total = (int)e->tb.size();
+    e->tproj_all.w = put(e, e->tw.data(), e->tw.size());
+    e->tproj_all.b = put(e, e->tb.data(), e->tb.size());
+    e->tproj_all.cin = TEMB; e->tproj_all.cout = e->tproj_total; e->tproj_all.k = 1;
+    e->tw.clear(); e->tw.shrink_to_fit(); e->tb.clear();
+    for (auto& kv : e->host)
+        if (!kv.second.used) F_FAIL(e, "unexpected tensor in the state dict: %s", kv.first.c_str());
+    e->slab_floats = e->blob.size();
+    F_HIP(e, hipMalloc((void**)&e->slab, e->slab_floats * sizeof(float)));
+    F_HIP(e, hipMemcpy(e->slab, e->blob.data(), e->slab_floats * sizeof(float), hipMemcpyHostToDevice));
+    e->blob.clear(); e->blob.shrink_to_fit();
+    e->host.clear();
+    e->finalized = true;
+    return 0;
+}
+
+/* ctx_dev [n_prompts][77][768] fp32: cross-attention K/V of the 16 transformer blocks for every prompt */
+int dm_f32_set_prompts(dm_f32_net* e, const void* ctx_dev, int n_prompts, void* stream) {
+    if (!e || !ctx_dev || n_prompts <= 0) return 1;
+    if (!e->finalized) F_FAIL(e, "set_prompts before finalize");
+    F_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (n_prompts > e->kv_capacity) {
+        F_HIP(e, hipStreamSynchronize(s));
+        for (float* p : e->kv_cache) if (p) F_HIP(e, hipFree(p));
+        int cap = e->kv_capacity > 0 ? e->kv_capacity : 4;
+        while (cap < n_prompts) cap *= 2;
+        e->kv_cache.assign(e->n_tf, nullptr);
+        for (int l = 0; l < e->n_tf; ++l) F_HIP(e, hipMalloc((void**)&e->kv_cache[l], (size_t)cap * CTX_LEN * 2 * e->tfs[l]->c * sizeof(float)));
+        e->kv_capacity = cap;
+    }
+    e->n_prompts = n_prompts;
+    const int M = n_prompts * CTX_LEN;
+    for (int l = 0; l < e->n_tf; ++l) {
+        const Conv& kv = e->tfs[l]->kv2;
+        GemmParams p;
+        p.X = (const float*)ctx_dev; p.Wp = e->slab + kv.w; p.Y = e->kv_cache[l];
+        p.M = M; p.Cout = kv.cout; p.Cin = CTX_DIM; p.C1 = CTX_DIM; p.H = 1; p.W = M; p.OH = 1; p.OW = M; p.mode = 0; p.ldy = kv.cout;
+        F_HIP(e, launch_gemm(p, s));
+    }
+    return 0;
+}
+
+int dm_f32_unet_forward(dm_f32_net* e, const void* sample_dev, const int64_t* t_dev, const int32_t* slot_dev, int batch, int h, int w,
+                        void* out_dev, void* stream) {
+    if (!e || !sample_dev || !t_dev || !slot_dev || !out_dev) return 1;
+    Args32 A{(const float*)sample_dev, t_dev, slot_dev, batch, h, w, -1, (float*)out_dev, nullptr, nullptr, 1};
+    return run_chunked32(e, A, stream);
+}
+
+int dm_f32_dift(dm_f32_net* e, const void* noisy_dev, const int64_t* t_dev, const int32_t* slot_dev, int batch, int h, int w,
+                int up_ft_index, void* feat_out_dev, void* mean_out_dev, int ensemble, void* stream) {
+    if (!e || !noisy_dev || !t_dev || !slot_dev || (!feat_out_dev && !mean_out_dev)) return 1;
+    if (up_ft_index < 0 || up_ft_index >= NB) F_FAIL(e, "up_ft_index %d out of range", up_ft_index);
+    Args32 A{(const float*)noisy_dev, t_dev, slot_dev, batch, h, w, up_ft_index, nullptr, (float*)feat_out_dev, (float*)mean_out_dev,
+             ensemble > 0 ? ensemble : 1};
+    return run_chunked32(e, A, stream);
+}
+
+int dm_f32_prof_enable(dm_f32_net* e, int on) {
+    if (!e) return 1;
+    e->prof = on != 0;
+    return 0;
+}
+
+int dm_f32_prof_read(dm_f32_net* e, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches, double* attn_ms, double* attn_flops,
+                     int64_t* attn_launches) {
+    if (!e) return 1;
+    F_HIP(e, hipSetDevice(e->device));
+    for (auto& ev : e->evs) {
+        F_HIP(e, hipEventSynchronize(ev.b));
+        float ms = 0.f;
+        F_HIP(e, hipEventElapsedTime(&ms, ev.a, ev.b));
+        e->prof_ms[ev.kind] += ms; e->prof_flops[ev.kind] += ev.flops; e->prof_n[ev.kind] += 1;
+        e->ev_pool.push_back(ev.a); e->ev_pool.push_back(ev.b);
+    }
+    e->evs.clear();
+    if (gemm_ms) *gemm_ms = e->prof_ms[0];
+    if (gemm_flops) *gemm_flops = e->prof_flops[0];
+    if (gemm_launches) *gemm_launches = e->prof_n[0];
+    if (attn_ms) *attn_ms = e->prof_ms[1];
+    if (attn_flops) *attn_flops = e->prof_flops[1];
+    if (attn_launches) *attn_launches = e->prof_n[1];
+    for (int k = 0; k < 2; ++k) { e->prof_ms[k] = 0; e->prof_flops[k] = 0; e->prof_n[k] = 0; }
+    return 0;
+}
+
+int dm_f32_memory(dm_f32_net* e, size_t* weights_bytes, size_t* arena_bytes) {
+    if (!e) return 1;
+    if (weights_bytes) *weights_bytes = e->slab_floats * sizeof(float);
+    if (arena_bytes) *arena_bytes = e->arena_cap;
+    return 0;
+}
+
+/* operator-level entry points of the parity tests (tests/test_gpu_f32.py) */
+int dm_f32_op_gemm(void* stream, const void* X, const void* X2, const void* Wp, const void* bias, const void* temb, const void* res, void* Y,
+                   int N, int H, int W, int OH, int OW, int Cin, int C1, int Cout, int mode, int temb_ld) {
+    GemmParams p;
+    p.X = (const float*)X; p.X2 = (const float*)X2; p.Wp = (const float*)Wp; p.bias = (const float*)bias; p.temb = (const float*)temb;
+    p.res = (const float*)res; p.Y = (float*)Y; p.Cout = Cout; p.Cin = Cin; p.C1 = C1; p.mode = mode; p.ldy = Cout; p.ldres = Cout; p.temb_ld = temb_ld;
+    if (mode == 0) { p.M = N * H * W; p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M; }
+    else { p.M = N * OH * OW; p.H = H; p.W = W; p.OH = OH; p.OW = OW; }
+    return launch_gemm(p, (hipStream_t)stream) == hipSuccess ? 0 : 1;
+}
+
+int dm_f32_op_attention(void* stream, const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv, int ldo,
+                        int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso, const int32_t* kv_slot, int n_slots, int B, int heads, int Tq,
+                        int Tk, int D, float scale) {
+    AttnParams a;
+    a.Q = (const float*)Q; a.K = (const float*)K; a.V = (const float*)V; a.O = (float*)O; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.bsq = bsq; a.bsk = bsk; a.bsv = bsv; a.bso = bso; a.kv_slot = kv_slot; a.n_slots = n_slots; a.B = B; a.heads = heads; a.Tq = Tq; a.Tk = Tk;
+    a.D = D; a.scale = scale;
+    return launch_attention(a, (hipStream_t)stream) == hipSuccess ? 0 : 1;
+}
+
+int dm_f32_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, int C, int C1, int G, float eps, const float* gamma,
+                        const float* beta, int silu, void* stats_work, void* Y) {
+    hipStream_t s = (hipStream_t)stream;
+    if (launch_gn_stats((const float*)X, (const float*)X2, N, HW, C, C1, G, eps, (float*)stats_work, s) != hipSuccess) return 1;
+    return launch_gn_apply((const float*)X, (const float*)X2, N, HW, C, C1, G, gamma, beta, (const float*)stats_work, silu, (float*)Y, s) == hipSuccess ? 0 : 1;
+}
+
+int dm_f32_op_layernorm(void* stream, const void* X, int rows, int C, const float* gamma, const float* beta, float eps, void* Y) {
+    return launch_layernorm((const float*)X, rows, C, gamma, beta, eps, (float*)Y, (hipStream_t)stream) == hipSuccess ? 0 : 1;
+}
+
+}  // extern "C"

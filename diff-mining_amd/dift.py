@@ -11,6 +11,12 @@ argument meaning and its output `[1, C, H/16, W/16]` (for up_ft_index=1):
     engine holds CLIP text weights, or the CLIP hidden states `[1,77,768]` themselves.
 `patch_embeddings` is the DIFT branch of `Cluster.compute_embeddings` (cluster.py:288-299) with a
 per-image cache of the feature map.
+
+Arithmetic: the reference's featuriser is fp32 end to end (dift.py:197-199: no torch_dtype; :191: no autocast).  Built over a
+`UNetEngineF32` the U-Net runs in that arithmetic (`self.dtype == torch.float32`, matches the CPU oracle in fp32 mode to ~1e-6); built over
+the fp16 `UNetEngine` it is the fast reduced-precision mode (descriptor cosine >= 1 - 5e-7), which also
+carries the VAE encoder and the CLIP text tower for image / string inputs.  `SDFeaturizer(f32_net, aux=fp16_engine)` combines
+them: fp32 U-Net, the fp16 engine only for `vae_encode` / `clip_encode` / `patch_embed`.
 """
 from __future__ import annotations
 
@@ -19,7 +25,7 @@ from typing import Optional, Sequence, Tuple
 
 import torch
 
-from .engine import UNetEngine
+from .engine import UNetEngine, UNetEngineF32
 
 
 def scheduler_alphas_cumprod(n: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012) -> torch.Tensor:
@@ -38,9 +44,13 @@ def feature_boxes(boxes_px: Sequence[Tuple[int, int, int, int]], image_hw: Tuple
 
 
 class SDFeaturizer:
-    def __init__(self, engine: UNetEngine, cache_size: int = 64, tokenizer=None):
-        """`tokenizer`: e.g. transformers' `CLIPTokenizer` (dift.py:203); only needed for string prompts."""
+    def __init__(self, engine, cache_size: int = 64, tokenizer=None, aux: Optional[UNetEngine] = None):
+        """`engine`: a `UNetEngineF32` (the reference's fp32 arithmetic) or a `UNetEngine` (fp16, faster); `aux`: the fp16
+        engine that holds the VAE encoder / CLIP text tower / patch kernel when `engine` is the fp32 net;
+        `tokenizer`: e.g. transformers' `CLIPTokenizer` (dift.py:203); only needed for string prompts."""
         self.engine = engine
+        self.dtype = torch.float32 if isinstance(engine, UNetEngineF32) else torch.float16
+        self.aux = aux if aux is not None else (engine if isinstance(engine, UNetEngine) else None)
         self.tokenizer = tokenizer
         self._prompt_cache: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         self.device = engine.device
@@ -60,14 +70,14 @@ class SDFeaturizer:
         if r is not None and r[0] == eng.prompt_generation:
             if r[1] is prompt_embeds and r[2] == prompt_embeds._version:          # the cached tensor of a string prompt
                 return
-            pe16 = prompt_embeds.reshape(1, 77, -1).to(self.device, torch.float16)
+            pe16 = prompt_embeds.reshape(1, 77, -1).to(self.device, self.dtype)
             if r[3].shape == pe16.shape and torch.equal(r[3], pe16):             # a caller's fresh tensor with the same values
                 self._registered = (r[0], prompt_embeds, prompt_embeds._version, r[3])
                 return
         pe = prompt_embeds.reshape(1, 77, -1)
         eng.set_prompts(pe)
         self.prompt_registrations += 1
-        self._registered = (eng.prompt_generation, prompt_embeds, prompt_embeds._version, pe.to(self.device, torch.float16).clone())
+        self._registered = (eng.prompt_generation, prompt_embeds, prompt_embeds._version, pe.to(self.device, self.dtype).clone())
 
     def add_noise(self, latents, noise, t):
         """DDIMScheduler.add_noise in the latents' dtype (dift.py:190; fp32 in the reference)."""
@@ -87,12 +97,12 @@ class SDFeaturizer:
         if hit is not None:
             self._prompt_cache.move_to_end(prompt)
             return hit
-        if self.tokenizer is None:
-            raise ValueError("a string prompt needs SDFeaturizer(engine, tokenizer=...) and CLIP text weights on the engine "
-                             "(engine.load_clip_state_dict); pass the [1,77,768] hidden states otherwise")
+        if self.tokenizer is None or self.aux is None:
+            raise ValueError("a string prompt needs SDFeaturizer(engine, tokenizer=...) and CLIP text weights on the fp16 engine "
+                             "(engine.load_clip_state_dict; `aux=` when `engine` is the fp32 net); pass the [1,77,768] hidden states otherwise")
         tok = self.tokenizer
         ids = tok([prompt], max_length=tok.model_max_length, padding="max_length", truncation=True, return_tensors="pt").input_ids
-        emb = self.engine.clip_encode(ids)
+        emb = self.aux.clip_encode(ids)
         self._prompt_cache[prompt] = emb
         while len(self._prompt_cache) > 256:
             self._prompt_cache.popitem(last=False)
@@ -120,7 +130,7 @@ class SDFeaturizer:
         noisy = self.add_noise(lat, noise.to(self.device, torch.float32), int(t))
         self._register_prompt(prompt_embeds)
         slots = torch.zeros(ensemble_size, dtype=torch.int32, device=self.device)
-        _, mean = self.engine.dift(noisy.to(torch.float16), torch.tensor(int(t)), slots, up_ft_index, ensemble_size)
+        _, mean = self.engine.dift(noisy.to(self.dtype), torch.tensor(int(t)), slots, up_ft_index, ensemble_size)
         return mean
 
     __call__ = forward
@@ -137,8 +147,10 @@ class SDFeaturizer:
         _, _, H, W = img.shape
         if vae_noise is None:
             vae_noise = torch.randn(ensemble_size, 4, H // 8, W // 8, generator=generator, dtype=torch.float32)
-        lat = self.engine.vae_encode(img, vae_noise.to(torch.float16), out_dtype=torch.float32,
-                                     draws_per_image=ensemble_size)
+        if self.aux is None:
+            raise ValueError("an image input needs the VAE encoder: SDFeaturizer(f32_net, aux=fp16_engine_with_vae_weights)")
+        lat = self.aux.vae_encode(img, vae_noise.to(torch.float16), out_dtype=torch.float32,
+                                  draws_per_image=ensemble_size)
         return self.forward(lat, prompt_embeds, t, up_ft_index, ensemble_size, noise=noise, generator=generator)
 
     # -- Cluster.compute_embeddings' DIFT branch (cluster.py:288-299) ------------------------------
@@ -162,4 +174,6 @@ class SDFeaturizer:
             else:
                 self._cache.move_to_end(feat_or_key)
         fh, fw = feat.shape[-2], feat.shape[-1]
-        return self.engine.patch_embed(feat, feature_boxes(boxes_px, image_hw, (fh, fw)))
+        if self.aux is None:
+            raise ValueError("patch_embeddings needs the fp16 engine's patch kernel: SDFeaturizer(f32_net, aux=fp16_engine)")
+        return self.aux.patch_embed(feat, feature_boxes(boxes_px, image_hw, (fh, fw)))

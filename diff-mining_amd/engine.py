@@ -27,6 +27,9 @@ SYMBOLS = [
     "dm_engine_load_clip_weight", "dm_engine_finalize_clip", "dm_clip_encode", "dm_op_igemm_splitk",
     "dm_op_ln_stats", "dm_op_igemm_ln", "dm_reduce_typicality_batched", "dm_op_igemm_tile", "dm_op_igemm_head_rows", "dm_set_option",
     "dm_engine_reserve", "dm_engine_stats", "dm_op_groupnorm_conv1x1", "dm_op_igemm_shortcut", "dm_normalize_map",
+    "dm_f32_create", "dm_f32_destroy", "dm_f32_last_error", "dm_f32_load_weight", "dm_f32_finalize", "dm_f32_set_prompts",
+    "dm_f32_unet_forward", "dm_f32_dift", "dm_f32_prof_enable", "dm_f32_prof_read", "dm_f32_memory", "dm_f32_op_gemm",
+    "dm_f32_op_attention", "dm_f32_op_groupnorm", "dm_f32_op_layernorm",
 ]
 
 
@@ -98,6 +101,25 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         lib.dm_engine_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     if hasattr(lib, "dm_normalize_map"):
         lib.dm_normalize_map.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
+    if hasattr(lib, "dm_f32_create"):            # the fp32 U-Net (DIFT arithmetic), r04
+        lib.dm_f32_create.argtypes = [i32, C.POINTER(vp)]
+        lib.dm_f32_destroy.argtypes = [vp]
+        lib.dm_f32_destroy.restype = None
+        lib.dm_f32_last_error.restype = C.c_char_p
+        lib.dm_f32_last_error.argtypes = [vp]
+        lib.dm_f32_load_weight.argtypes = [vp, C.c_char_p, vp, i32, C.POINTER(i64), i32]
+        lib.dm_f32_finalize.argtypes = [vp]
+        lib.dm_f32_set_prompts.argtypes = [vp, vp, i32, vp]
+        lib.dm_f32_unet_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
+        lib.dm_f32_dift.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
+        lib.dm_f32_prof_enable.argtypes = [vp, i32]
+        lib.dm_f32_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64),
+                                         C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
+        lib.dm_f32_memory.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        lib.dm_f32_op_gemm.argtypes = [vp] * 8 + [i32] * 10
+        lib.dm_f32_op_attention.argtypes = [vp] * 5 + [i32] * 4 + [i64] * 4 + [vp] + [i32] * 6 + [C.c_float]
+        lib.dm_f32_op_groupnorm.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, C.c_float, vp, vp, i32, vp, vp]
+        lib.dm_f32_op_layernorm.argtypes = [vp, vp, i32, i32, vp, vp, C.c_float, vp]
     if path is None:
         _lib = lib
     return lib
@@ -516,4 +538,117 @@ class UNetEngine:
     def memory(self) -> dict:
         a, b = C.c_size_t(), C.c_size_t()
         self._check(self.lib.dm_engine_memory(self._h, C.byref(a), C.byref(b)), "memory")
+        return {"weights_bytes": a.value, "arena_bytes": b.value}
+
+
+class UNetEngineF32:
+    """The SDv1.5 U-Net in plain fp32 on the fp32 matrix cores (C ABI: dm_f32_*) — the arithmetic of the reference's DIFT
+    featuriser, which loads its pipeline without torch_dtype and runs without autocast (dift.py:191,197-199).  Same
+    diffusers-named state dict and prompt-slot mechanism as `UNetEngine`; every tensor at this boundary is fp32.
+    No fallback: raises without the library or a GPU."""
+
+    def __init__(self, device: int = 0):
+        import torch
+        self._torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise EngineError("no GPU visible: the MI355X engine has no CPU fallback")
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        h = C.c_void_p()
+        if self.lib.dm_f32_create(self.device_index, C.byref(h)):
+            raise EngineError("dm_f32_create: " + self.lib.dm_f32_last_error(None).decode())
+        self._h = h
+        self.n_prompts = 0
+        self.prompt_generation = 0
+
+    def _check(self, rc: int, what: str):
+        if rc:
+            raise EngineError(f"{what}: {self.lib.dm_f32_last_error(self._h).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.dm_f32_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_state_dict(self, sd: Dict[str, "np.ndarray"]):
+        """sd: diffusers-named U-Net state dict (numpy or torch; fp32 kept as is, fp16 / bf16 widened exactly)."""
+        UNetEngine._load(self, self.lib.dm_f32_load_weight, sd, "f32_load_weight")
+        self._check(self.lib.dm_f32_finalize(self._h), "f32_finalize")
+
+    def load_safetensors(self, path: str):
+        from safetensors.numpy import load_file
+        self.load_state_dict(load_file(path))
+
+    def set_prompts(self, ctx):
+        """ctx [P,77,768] (`prompt_embeds`, dift.py:222-227), kept in fp32."""
+        torch = self._torch
+        ctx = ctx.to(self.device, torch.float32).contiguous()
+        assert ctx.dim() == 3 and ctx.shape[1] == 77 and ctx.shape[2] == 768, ctx.shape
+        self._check(self.lib.dm_f32_set_prompts(self._h, C.c_void_p(ctx.data_ptr()), ctx.shape[0], self._stream()), "f32_set_prompts")
+        self._ctx_keepalive = ctx
+        self.n_prompts = ctx.shape[0]
+        self.prompt_generation += 1
+
+    def _tsl(self, t, slots, B):
+        torch = self._torch
+        t = torch.as_tensor(t, device=self.device).to(torch.int64).reshape(-1)
+        if t.numel() == 1:
+            t = t.expand(B)
+        s = torch.as_tensor(slots)
+        assert s.shape == (B,) and t.shape == (B,), (s.shape, t.shape, B)
+        if s.numel() and not s.is_cuda:
+            lo, hi = int(s.min()), int(s.max())
+            if lo < 0 or hi >= self.n_prompts:
+                raise EngineError(f"prompt slot {lo if lo < 0 else hi} outside the {self.n_prompts} prompts registered by set_prompts")
+        return t.contiguous(), s.to(self.device, torch.int32).contiguous()
+
+    def unet(self, sample, t, slots):
+        """`unet(sample, t, ctx).sample` in fp32 -> [B,4,h,w] fp32."""
+        torch = self._torch
+        sample = sample.to(self.device, torch.float32).contiguous()
+        B, _, h, w = sample.shape
+        t, s = self._tsl(t, slots, B)
+        out = torch.empty(B, 4, h, w, dtype=torch.float32, device=self.device)
+        self._check(self.lib.dm_f32_unet_forward(self._h, C.c_void_p(sample.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(s.data_ptr()),
+                                                 B, h, w, C.c_void_p(out.data_ptr()), self._stream()), "dm_f32_unet_forward")
+        return out
+
+    def dift(self, noisy, t, slots, up_ft_index: int = 1, ensemble: Optional[int] = None):
+        """MyUNet2DConditionModel.forward tap (dift.py:24-169) in the reference's fp32.  Returns (features fp32 [B,C,h',w'],
+        ensemble mean fp32 [B/ens,C,h',w'] or None)."""
+        torch = self._torch
+        noisy = noisy.to(self.device, torch.float32).contiguous()
+        B, _, h, w = noisy.shape
+        t, s = self._tsl(t, slots, B)
+        c, oh, ow = dift_shape(h, w, up_ft_index)
+        feat = torch.empty(B, c, oh, ow, dtype=torch.float32, device=self.device)
+        mean = torch.empty(B // ensemble, c, oh, ow, dtype=torch.float32, device=self.device) if ensemble else None
+        self._check(self.lib.dm_f32_dift(self._h, C.c_void_p(noisy.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(s.data_ptr()), B, h, w,
+                                         up_ft_index, C.c_void_p(feat.data_ptr()), C.c_void_p(mean.data_ptr()) if mean is not None else None,
+                                         int(ensemble or 1), self._stream()), "dm_f32_dift")
+        return feat, mean
+
+    def prof_enable(self, on: bool = True):
+        self._check(self.lib.dm_f32_prof_enable(self._h, 1 if on else 0), "f32_prof_enable")
+
+    def prof_read(self) -> dict:
+        a, b, c2 = C.c_double(), C.c_double(), C.c_int64()
+        d, e, f = C.c_double(), C.c_double(), C.c_int64()
+        self._check(self.lib.dm_f32_prof_read(self._h, C.byref(a), C.byref(b), C.byref(c2), C.byref(d), C.byref(e), C.byref(f)), "f32_prof_read")
+        return {"igemm_ms": a.value, "igemm_flops": b.value, "igemm_launches": c2.value,
+                "attn_ms": d.value, "attn_flops": e.value, "attn_launches": f.value}
+
+    def memory(self) -> dict:
+        a, b = C.c_size_t(), C.c_size_t()
+        self._check(self.lib.dm_f32_memory(self._h, C.byref(a), C.byref(b)), "f32_memory")
         return {"weights_bytes": a.value, "arena_bytes": b.value}

@@ -307,6 +307,47 @@ int dm_op_igemm_shortcut(void* stream, const void* X, const void* X3, const void
 int dm_op_groupnorm_conv1x1(void* stream, const void* X, int N, int HW, int C, int G, float eps, const float* gamma,
                             const float* beta, const void* W, const void* bias, int Cout, void* Y);
 
+/* ---- fp32 U-Net: the arithmetic of the reference's DIFT featuriser ------------------------------------------------------
+ * `SDFeaturizer.__init__` (diffmining/typicality/dift.py:197-199) loads the pipeline WITHOUT torch_dtype and `forward`
+ * (dift.py:214-232 -> OneStepSDPipeline.__call__, :173-193 -> MyUNet2DConditionModel.forward, :24-169) runs WITHOUT autocast:
+ * every tensor and product of the DIFT path is fp32, unlike the typicality path (compute.py:98, fp16 autocast) that dm_engine
+ * serves.  dm_f32_net is that second arithmetic: fp32 weights (values given as fp16 are widened exactly), fp32 NHWC
+ * activations, fp32 matrix-core GEMMs (v_mfma_f32_16x16x4_f32, exact fp32 products) and attention.  Same U-Net, same
+ * diffusers-named state dict, same prompt-slot mechanism as dm_engine; all *_dev tensors at this boundary are fp32.
+ *   dm_f32_load_weight / dm_f32_finalize   replace from_pretrained's state-dict load (dift.py:197-199)
+ *   dm_f32_set_prompts   ctx_dev [n_prompts,77,768] fp32 = `prompt_embeds` (dift.py:222-227); K/V of the 16 blocks per prompt
+ *   dm_f32_dift          MyUNet2DConditionModel.forward(latents_noisy, t, [up_ft_index], prompt_embeds) (dift.py:24-169,191):
+ *                        feat_out_dev [batch,C_i,h_i,w_i] fp32 NCHW and / or the mean over consecutive groups of `ensemble`
+ *                        samples [batch/ensemble,C_i,h_i,w_i] (dift.py:231); shapes from dm_dift_shape()
+ *   dm_f32_unet_forward  `unet(sample, t, encoder_hidden_states).sample` in fp32: out_dev [batch,4,h,w] — the full-size fp32
+ *                        ground truth on the GPU for the fp16 engine's deviation measurements
+ *   dm_f32_prof_*        as dm_prof_*: HIP events around every GEMM / attention launch, for bench.py's roofline leg */
+typedef struct dm_f32_net dm_f32_net;
+int dm_f32_create(int device, dm_f32_net** out);
+void dm_f32_destroy(dm_f32_net* e);
+const char* dm_f32_last_error(dm_f32_net* e);   /* e may be NULL: last create() error */
+int dm_f32_load_weight(dm_f32_net* e, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim);
+int dm_f32_finalize(dm_f32_net* e);
+int dm_f32_set_prompts(dm_f32_net* e, const void* ctx_dev, int n_prompts, void* stream);
+int dm_f32_unet_forward(dm_f32_net* e, const void* sample_dev, const int64_t* t_dev, const int32_t* slot_dev, int batch,
+                        int h, int w, void* out_dev, void* stream);
+int dm_f32_dift(dm_f32_net* e, const void* noisy_dev, const int64_t* t_dev, const int32_t* slot_dev, int batch, int h, int w,
+                int up_ft_index, void* feat_out_dev, void* mean_out_dev, int ensemble, void* stream);
+int dm_f32_prof_enable(dm_f32_net* e, int on);
+int dm_f32_prof_read(dm_f32_net* e, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches, double* attn_ms,
+                     double* attn_flops, int64_t* attn_launches);
+int dm_f32_memory(dm_f32_net* e, size_t* weights_bytes, size_t* arena_bytes);
+/* operator-level entry points of the fp32 kernels (parity tests): NHWC fp32 tensors; modes as dm_op_igemm (0 dense, 1 conv3x3,
+ * 2 stride 2, 3 nearest-upsample to (OH, OW) + conv3x3, 4 stride 2 pad (0,1,0,1)); Wp [Cout][taps*Cin] k = (tap, cin); res [M][Cout] */
+int dm_f32_op_gemm(void* stream, const void* X, const void* X2, const void* Wp, const void* bias, const void* temb, const void* res,
+                   void* Y, int N, int H, int W, int OH, int OW, int Cin, int C1, int Cout, int mode, int temb_ld);
+int dm_f32_op_attention(void* stream, const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv, int ldo,
+                        int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso, const int32_t* kv_slot, int n_slots, int B, int heads,
+                        int Tq, int Tk, int D, float scale);
+int dm_f32_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, int C, int C1, int G, float eps,
+                        const float* gamma, const float* beta, int silu, void* stats_work, void* Y);
+int dm_f32_op_layernorm(void* stream, const void* X, int rows, int C, const float* gamma, const float* beta, float eps, void* Y);
+
 #ifdef __cplusplus
 }
 #endif
