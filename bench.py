@@ -40,6 +40,7 @@ import torch  # noqa: E402
 FLOP_PER_FORWARD_64 = 803.27e9          # SURVEY.md §8d (2 FLOP/MAC, attention included), nominal
 N_IMG, N_DRAWS, N_COND, LAT = 8, 10, 2, 64
 PEAK_TFLOPS = 2500.0                    # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
+PEAK_TFLOPS_F32 = 157.3                 # MI355X fp32 matrix (v_mfma_f32_*_f32: 256 FLOP/clk/CU; MI355X_MICROARCH.md "Peak FP32 (matrix)")
 STUB = os.environ.get("DM_BENCH_STUB", "0") not in ("", "0")     # CPU test of the launcher / gather path (gloo, no engine)
 
 
@@ -70,6 +71,9 @@ def main():
     ap.add_argument("--workload", choices=["typicality", "dift", "xray", "vae", "pixels"], default="typicality",
                     help="typicality = BASELINE configs[1]/[2] (the graded line); dift = configs[3]; xray = configs[4]; "
                          "vae = SURVEY 8f rank 2 (VAE encode of 8 images @512px); pixels = vae + typicality from images")
+    ap.add_argument("--dift-dtype", choices=["f32", "f16"], default="f32",
+                    help="--workload dift: f32 = the reference's arithmetic (dift.py:197-199: no torch_dtype, no autocast) on the fp32 "
+                         "matrix cores (the gradable line); f16 = the fp16 engine (reduced precision, labelled so)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ:
@@ -104,9 +108,9 @@ def main():
         def step():                       # stands in for the engine: rank-dependent fake T(x|c), same gather path
             return gather_scores(torch.arange(n_img, dtype=torch.float32) + 100.0 * rank, n_img * world, rank, world)
     else:
-        from diff_mining_amd.engine import UNetEngine
+        from diff_mining_amd.engine import UNetEngine, UNetEngineF32
         sd = synth.synth_state_dict(seed=0, dtype=np.float16)
-        eng = UNetEngine(local_rank)
+        eng = UNetEngineF32(local_rank) if (args.workload == "dift" and args.dift_dtype == "f32") else UNetEngine(local_rank)
         eng.load_state_dict(sd)
         if args.workload != "typicality":
             return side_workload(args, eng, dev, sd)
@@ -279,13 +283,15 @@ def side_workload(args, eng, dev, sd):
     HIP events over the timed steps (igemm family), `cpu_baseline` from the oracle on a bounded sample."""
     from diff_mining_amd import synth
     cfg, dtype_note = None, None
+    f32 = args.workload == "dift" and args.dift_dtype == "f32"
     if args.workload == "dift":
         n_lat, ens, lat = 8, 8, 64
         x, eps, _, c = synth.synth_inputs(n_lat, ens, lat, lat)
         xt = torch.from_numpy(x).float().to(dev).repeat_interleave(ens, 0)
         et = torch.from_numpy(eps).float().to(dev).repeat(n_lat, 1, 1, 1)
         a = 0.81210744                                          # acp[161]
-        noisy = ((a ** 0.5) * xt + ((1 - a) ** 0.5) * et).half()
+        noisy = ((a ** 0.5) * xt + ((1 - a) ** 0.5) * et)
+        noisy = noisy if f32 else noisy.half()
         eng.set_prompts(torch.from_numpy(c[:1]).to(dev))
         slots = torch.zeros(n_lat * ens, dtype=torch.int32, device=dev)
         tt = torch.tensor(161, device=dev)
@@ -296,7 +302,7 @@ def side_workload(args, eng, dev, sd):
         cfg = {"workload": "configs[3]: DIFT-161 feature extraction, single-timestep U-Net forward with the up_blocks[1] tap "
                            "(dift.py:133-165; BASELINE.json says 'mid-block': SURVEY F6a), batch 64 = 8 images x ensemble 8, 64x64 latent",
                "images_per_step": n_lat, "ensemble": ens, "t": 161, "up_ft_index": 1}
-        dtype_note = ("the engine computes this path in fp16 (fp32 accumulation / norms / softmax), the reference's SDFeaturizer runs "
+        dtype_note = None if f32 else ("the engine computes this path in fp16 (fp32 accumulation / norms / softmax), the reference's SDFeaturizer runs "
                       "the U-Net in fp32 (dift.py:197-199): a REDUCED-PRECISION number by the bench rule; descriptor deviation vs the "
                       "fp32 oracle: cosine >= 1 - 5e-7 (tests/test_gpu_e2e.py::test_dift_descriptor_deviation_vs_fp32_oracle)")
     elif args.workload in ("vae", "pixels"):
@@ -349,19 +355,23 @@ def side_workload(args, eng, dev, sd):
     val = units * args.steps / dt
     ig_tf = prof["igemm_flops"] / (prof["igemm_ms"] * 1e-3) / 1e12 if prof["igemm_ms"] > 0 else 0.0
     at_tf = prof["attn_flops"] / (prof["attn_ms"] * 1e-3) / 1e12 if prof["attn_ms"] > 0 else 0.0
+    # fp32 DIFT: the fp32 matrix cores (v_mfma_f32_16x16x4_f32), 256 FLOP/clk/CU = 157.3 TFLOP/s (MI355X_MICROARCH.md: "Peak FP32 (matrix)")
+    peak = PEAK_TFLOPS_F32 if f32 else PEAK_TFLOPS
     line = {"metric": name, "value": round(val, 4), "unit": "images/s", "n_gpus": 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic", "config": cfg,
-            "roofline": {"bound": "mfma", "kernel": "igemm family (igemm_pers_kernel + igemm_kernel)", "achieved": round(ig_tf, 2),
-                         "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ig_tf / PEAK_TFLOPS, 4), "traffic": None,
+            "vs_baseline": None, "dtype": "f32" if f32 else "f16", "data": "synthetic", "config": cfg,
+            "roofline": {"bound": "mfma", "kernel": "gemm32_kernel (fp32 implicit GEMM, 128x160x16 tile, v_mfma_f32_16x16x4_f32)" if f32 else
+                         "igemm family (igemm_pers_kernel + igemm_kernel)", "achieved": round(ig_tf, 2),
+                         "peak": peak, "unit": "TFLOP/s", "frac": round(ig_tf / peak, 4), "traffic": None,
                          "launches": prof["igemm_launches"], "kernel_ms_total": round(prof["igemm_ms"], 3),
                          "attention_tflops": round(at_tf, 2), "attention_ms_total": round(prof["attn_ms"], 3),
                          "whole_path_tflops_nominal": round(val * flop / 1e12, 2),
-                         "whole_path_frac_nominal": round(val * flop / 1e12 / PEAK_TFLOPS, 4)},
+                         "whole_path_frac_nominal": round(val * flop / 1e12 / peak, 4)},
             "out_shape": list(out.shape), "memory": eng.memory()}
+    if args.workload == "dift":
+        line["reference_dtype"] = "f32"
     if dtype_note:
         line["dtype_note"] = dtype_note
-        line["reference_dtype"] = "f32"
     if not args.no_cpu_baseline and args.workload in ("dift", "xray"):
         line["cpu_baseline"] = cpu_baseline_side(sd, args.workload)
     print(json.dumps(line), flush=True)

@@ -1,28 +1,39 @@
-// f32_gemm.hip — fp32 implicit GEMM on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), gfx950.
+// f32_gemm.hip — fp32 implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), gfx950.
 //
 // The arithmetic of the reference's DIFT featuriser: `SDFeaturizer` builds its pipeline without torch_dtype and calls the U-Net
 // without autocast (diffmining/typicality/dift.py:197-199, 191), i.e. every convolution / linear is an fp32 GEMM.  Same operator
 // as igemm_tile.h (3x3 convolution stride 1 / 2 / after nearest up-sampling, 1x1 convolution, linear; two concatenated sources;
 // bias + per-sample time embedding + residual in the epilogue) on fp32 tensors.
 //
-// Roofline: the fp32 MFMA rate is 256 FLOP/clk/CU (157 TFLOP/s) — 1/16 of the fp16 rate — so at this block tile (128 pixels x 160
-// channels x 16 k per step: 80 MFMAs of 32 cycles per wave and step against 9 ds_read_b128 and 4.5 16-byte global loads per
-// thread) the kernel is bound by the matrix pipe alone; nothing of the fp16 tile's LDS-DMA machinery is needed.
-//   block = 4 waves (2 x 2), wave tile 64 pixels x 80 channels = 4 x 5 MFMA tiles, accumulators 80 VGPRs
-//   MFMA operands: A = weights [channel i][k], B = activations [k][pixel j] -> D[i][j]: a lane holds 4 consecutive channels of one
-//   pixel, so the epilogue stores 16 bytes per lane into the NHWC row
-//   LDS: two stages of (160 + 128) rows x 16 floats (36 KiB), filled from registers (global loads of step t+1 in flight under the
-//   MFMAs of step t), one barrier per step; a fragment read is lane (c, g) -> row c, floats 4g..4g+3: the 64 lanes cover 1 KiB
-//   contiguously (conflict-free), register jj of the read pairs with k = 4g + jj in BOTH operands
+// Roofline: the fp32 MFMA rate is 256 FLOP/clk/CU (157.3 TFLOP/s; tools/probes/probe_peak_f32.hip reaches 154-156 with the 32x32x2
+// instruction from one wave per SIMD) — 1/16 of the fp16 rate —, so at this block tile (128 pixels x 160 channels x 32 k per step:
+// 80 MFMAs of 64 cycles per wave and step against 24 ds_read_b128, 9 ds_write_b128 and 9 16-byte global loads per lane) the
+// kernel is bound by the matrix pipe; nothing of the fp16 tile's LDS-DMA machinery is needed.  What does matter (measured r04,
+// DESIGN 4e): the two blocks of a CU run in lock step (their waves share a SIMD's matrix pipe one to one), so every non-MFMA
+// instruction a wave issues OUTSIDE the shadow of its own MFMAs idles the pipe — the first version (per-step address arithmetic
+// of ~400 VALU / SALU instructions in front of the MFMAs) ran at 0.73 of peak.  Hence:
+//   * per-lane source POINTERS, advanced by 32 floats per step; the row -> pixel arithmetic runs only when the tap or the
+//     concatenated source changes (every >= 5 steps); out-of-image rows and channels beyond Cout read a zero page (no branches)
+//   * the step's LDS stores (stage t+1) and global loads (step t+2) are issued BETWEEN its MFMA groups
+//   * fragments of k group g+1 are read under the MFMAs of group g
+// Geometry: block = 4 waves, wave w = pixels 32 w .. + 31 x all 160 channels = 5 accumulator tiles of 32 x 32 (80 VGPRs);
+// MFMA operands A = weights [channel][k], B = activations [k][pixel] -> D[channel][pixel]: a lane holds 4 consecutive channels of
+// one pixel per register quad, so the epilogue stores 16 bytes per lane into the NHWC row.  LDS: two stages of (160 + 128) rows x
+// 32 floats (72 KiB, two blocks per CU), 16-byte chunks XOR-swizzled by row.
 #include "f32_kernels.h"
 
 namespace dm32 {
 namespace {
 
-constexpr int BM = 128, BN = 160, BK = 16, NT = 256;
+constexpr int BM = 128, BN = 160, BK = 32, NT = 256;
+constexpr int CH = BK / 4;                               // 16-byte chunks per row and k step
+constexpr int XI = BM * CH / NT, WI = BN * CH / NT;      // 4 activation + 5 weight chunks per lane and step
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(NT, 2) void gemm32_kernel(GemmParams p, int tiles_m, int tiles_n, int per_xcd) {
+__device__ __attribute__((aligned(256))) float g_zero_page32[BK] = {0};
+
+__global__ __launch_bounds__(NT, 2) void gemm32_kernel(GemmParams p, int tiles_m, int tiles_n, int per_xcd, const float* zero_page) {
     __shared__ __attribute__((aligned(16))) float Ws[2][BN][BK];
     __shared__ __attribute__((aligned(16))) float Xs[2][BM][BK];
     // consecutive block ids land on different XCDs (8 L2s): give each XCD a contiguous range of tiles (channel tiles fastest: the
@@ -32,16 +43,16 @@ __global__ __launch_bounds__(NT, 2) void gemm32_kernel(GemmParams p, int tiles_m
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid & 1, wn = wid >> 1;
-    const int c = lane & 15, g = lane >> 4;
+    const int c32 = lane & 31, h32 = lane >> 5;
     const int K = (p.mode == 0 ? 1 : 9) * p.Cin;
     const int OHW = p.OH * p.OW;
+    const int lrow = tid / CH, lchunk = tid % CH;         // loader: rows lrow + 32 i, chunk lchunk
+    const float* zero = zero_page + 4 * lchunk;
 
-    // the two activation rows this thread loads (rows tid/4 and tid/4 + 64 of the tile, floats 4 (tid & 3) .. + 3 of a k step)
-    int xn[2], xoy[2], xox[2];
+    int xn[XI], xoy[XI], xox[XI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + (tid >> 2) + 64 * i;
+    for (int i = 0; i < XI; ++i) {
+        const int m = m0 + lrow + (NT / CH) * i;
         if (m < p.M) {
             if (p.mode == 0) { xn[i] = 0; xoy[i] = 0; xox[i] = m; }
             else { const int n = m / OHW, rem = m - n * OHW; xn[i] = n; xoy[i] = rem / p.OW; xox[i] = rem - xoy[i] * p.OW; }
@@ -49,17 +60,25 @@ __global__ __launch_bounds__(NT, 2) void gemm32_kernel(GemmParams p, int tiles_m
     }
     const float sh = (float)p.H / (float)p.OH, sw = (float)p.W / (float)p.OW;
 
-    auto gload = [&](int kt, v4f (&xr)[2], v4f (&wr)[3]) {
-        const int k0 = kt * BK;
-        int tap = 0, c0 = k0;
-        if (p.mode != 0) { tap = k0 / p.Cin; c0 = k0 - tap * p.Cin; }
-        const bool second = c0 >= p.C1;
+    const float* xsrc[XI]; int xinc[XI];
+    const float* wsrc[WI]; int winc[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int ch = n0 + lrow + (NT / CH) * i;
+        const bool ok = ch < p.Cout;
+        wsrc[i] = ok ? p.Wp + (size_t)ch * K + 4 * lchunk : zero;
+        winc[i] = ok ? BK : 0;
+    }
+    int ld_tap = 0, ld_c = 0;                              // loader position: tap and channel offset of the NEXT step to load
+    // pointers of the activation rows for the step at (ld_tap, ld_c): runs at a tap start and where the concatenated source changes
+    auto set_rows = [&]() {
+        const bool second = ld_c >= p.C1;
         const float* base = second ? p.X2 : p.X;
         const int cs = second ? p.Cin - p.C1 : p.C1;
-        const int cc = (second ? c0 - p.C1 : c0) + 4 * (tid & 3);
-        const int dy = tap / 3, dx = tap - dy * 3;
+        const int cc = (second ? ld_c - p.C1 : ld_c) + 4 * lchunk;
+        const int dy = ld_tap / 3, dx = ld_tap - dy * 3;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < XI; ++i) {
             long long off = -1;
             if (xn[i] >= 0) {
                 if (p.mode == 0) off = xox[i];
@@ -76,75 +95,110 @@ __global__ __launch_bounds__(NT, 2) void gemm32_kernel(GemmParams p, int tiles_m
                     if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) off = ((long long)xn[i] * p.H + ih) * p.W + iw;
                 }
             }
-            xr[i] = (off >= 0) ? *reinterpret_cast<const v4f*>(base + off * cs + cc) : v4f{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int idx = tid + NT * i;
-            v4f w = {0.f, 0.f, 0.f, 0.f};
-            if (idx < BN * 4) {
-                const int ch = n0 + (idx >> 2);
-                if (ch < p.Cout) w = *reinterpret_cast<const v4f*>(p.Wp + (size_t)ch * K + k0 + 4 * (idx & 3));
-            }
-            wr[i] = w;
+            xsrc[i] = (off >= 0) ? base + off * cs + cc : zero;
+            xinc[i] = (off >= 0) ? BK : 0;
         }
     };
-    auto lstore = [&](int buf, const v4f (&xr)[2], const v4f (&wr)[3]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<v4f*>(&Xs[buf][(tid >> 2) + 64 * i][4 * (tid & 3)]) = xr[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int idx = tid + NT * i;
-            if (idx < BN * 4) *reinterpret_cast<v4f*>(&Ws[buf][idx >> 2][4 * (idx & 3)]) = wr[i];
-        }
+    auto next_pos = [&]() {                                 // after a step's loads were issued: move the loader on
+        ld_c += BK;
+        if (ld_c == p.Cin) { ld_c = 0; ++ld_tap; set_rows(); }
+        else if (ld_c == p.C1) set_rows();
     };
+    // LDS rows hold 32 floats as 8 chunks of 16 bytes; chunk q of row r sits at position q ^ (r / 2 % 8): the 16 lanes of a
+    // ds_read_b128 group then touch 16 distinct 16-byte bank columns
+    auto pos = [&](int row, int q) { return q ^ ((row >> 1) & (CH - 1)); };
 
-    v4f acc[5][4];
+    v4f acc[5][4];          // [channel tile of 32][row group r / 4 of the 32 x 32 accumulator]
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / BK;
-    v4f xr[2], wr[3];
-    gload(0, xr, wr);
-    lstore(0, xr, wr);
+    v4f xr[XI], wr[WI];
+    auto gload_x = [&](int i) { xr[i] = *reinterpret_cast<const v4f*>(xsrc[i]); xsrc[i] += xinc[i]; };
+    auto gload_w = [&](int i) { wr[i] = *reinterpret_cast<const v4f*>(wsrc[i]); wsrc[i] += winc[i]; };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) { const int r = lrow + (NT / CH) * i; *reinterpret_cast<v4f*>(&Xs[buf][r][4 * pos(r, lchunk)]) = xr[i]; }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) { const int r = lrow + (NT / CH) * i; *reinterpret_cast<v4f*>(&Ws[buf][r][4 * pos(r, lchunk)]) = wr[i]; }
+    };
+    // A lane (c32, h32) = weights[channel c32][k = h32], B = activations[k = h32][pixel c32]; a 16-byte fragment read gives floats
+    // 4 h32 .. + 3 of an 8-float k group, register jj pairs k = 4 h32 + jj in both operands
+    auto frag = [&](int buf, int k8, v4f (&a)[5], v4f& b) {
+#pragma unroll
+        for (int ct = 0; ct < 5; ++ct) { const int r = ct * 32 + c32; a[ct] = *reinterpret_cast<const v4f*>(&Ws[buf][r][4 * pos(r, 2 * k8 + h32)]); }
+        const int r = wid * 32 + c32;
+        b = *reinterpret_cast<const v4f*>(&Xs[buf][r][4 * pos(r, 2 * k8 + h32)]);
+    };
+
+    set_rows();
+#pragma unroll
+    for (int i = 0; i < XI; ++i) gload_x(i);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) gload_w(i);
+    next_pos();
+    lstore(0);
+    if (nk > 1) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) gload_x(i);
+#pragma unroll
+        for (int i = 0; i < WI; ++i) gload_w(i);
+        next_pos();
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1, xr, wr);
-        v4f a[5], b[4];
+        const bool st = kt + 1 < nk, ld = kt + 2 < nk;        // uniform
+        v4f fa[5], fb;
+        frag(buf, 0, fa, fb);
 #pragma unroll
-        for (int ct = 0; ct < 5; ++ct) a[ct] = *reinterpret_cast<const v4f*>(&Ws[buf][wn * 80 + ct * 16 + c][4 * g]);
+        for (int k8 = 0; k8 < BK / 8; ++k8) {
+            v4f an[5], bn;
+            if (k8 + 1 < BK / 8) frag(buf, k8 + 1, an, bn);
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) b[pt] = *reinterpret_cast<const v4f*>(&Xs[buf][wm * 64 + pt * 16 + c][4 * g]);
+            for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+                for (int ct = 0; ct < 5; ++ct) {
+                    v16f& d = *reinterpret_cast<v16f*>(&acc[ct][0]);
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ct][jj], fb[jj], d, 0, 0, 0);
+                }
+                // the step's memory work, spread over the shadows of its 16 MFMA groups (stage t+1 was last read in step t-1, which
+                // every wave left through the barrier; the registers it is stored from were loaded during step t-1)
+                if (k8 == 0 && jj == 0 && st) lstore(buf ^ 1);
+                if (ld) {
+                    const int slot = k8 * 4 + jj - 2;             // slots 0..8 = the nine loads of step t+2, one per MFMA group
+                    if (slot >= 0 && slot < XI) gload_x(slot);
+                    if (slot >= XI && slot < XI + WI) gload_w(slot - XI);
+                    if (slot == XI + WI) next_pos();
+                }
+            }
+            if (k8 + 1 < BK / 8) {
 #pragma unroll
-            for (int ct = 0; ct < 5; ++ct)
-#pragma unroll
-                for (int pt = 0; pt < 4; ++pt)
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct][jj], b[pt][jj], acc[ct][pt], 0, 0, 0);
-        if (kt + 1 < nk) lstore(buf ^ 1, xr, wr);
+                for (int ct = 0; ct < 5; ++ct) fa[ct] = an[ct];
+                fb = bn;
+            }
+        }
         __syncthreads();
     }
 
-    // epilogue: lane (c, g) holds channels ch .. ch + 3 of pixel m for every (ct, pt)
-#pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-        const int m = m0 + wm * 64 + pt * 16 + c;
-        if (m >= p.M) continue;
+    // epilogue — 32 x 32 accumulator: lane (c32, h32), registers 4 q .. 4 q + 3 = channels 8 q + 4 h32 .. + 3 of pixel c32
+    const int m = m0 + wid * 32 + c32;
+    if (m < p.M) {
         const float* tb = p.temb ? p.temb + (size_t)(m / OHW) * p.temb_ld : nullptr;
 #pragma unroll
-        for (int ct = 0; ct < 5; ++ct) {
-            const int ch = n0 + wn * 80 + ct * 16 + 4 * g;
-            if (ch >= p.Cout) continue;
-            v4f v = acc[ct][pt];
-            if (p.bias) v += *reinterpret_cast<const v4f*>(p.bias + ch);
-            if (tb) v += *reinterpret_cast<const v4f*>(tb + ch);
-            if (p.res) v += *reinterpret_cast<const v4f*>(p.res + (size_t)m * p.ldres + ch);
-            *reinterpret_cast<v4f*>(p.Y + (size_t)m * p.ldy + ch) = v;
-        }
+        for (int ct = 0; ct < 5; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch = n0 + ct * 32 + 8 * q + 4 * h32;
+                if (ch >= p.Cout) continue;
+                v4f v = acc[ct][q];
+                if (p.bias) v += *reinterpret_cast<const v4f*>(p.bias + ch);
+                if (tb) v += *reinterpret_cast<const v4f*>(tb + ch);
+                if (p.res) v += *reinterpret_cast<const v4f*>(p.res + (size_t)m * p.ldres + ch);
+                *reinterpret_cast<v4f*>(p.Y + (size_t)m * p.ldy + ch) = v;
+            }
     }
 }
 
@@ -152,13 +206,16 @@ __global__ __launch_bounds__(NT, 2) void gemm32_kernel(GemmParams p, int tiles_m
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     const int taps = p.mode == 0 ? 1 : 9;
-    if (p.M <= 0 || p.Cout <= 0 || p.Cin % BK != 0 || p.C1 % BK != 0 || p.Cout % 4 != 0 || (p.C1 < p.Cin && !p.X2) ||
+    if (p.M <= 0 || p.Cout <= 0 || p.Cin % BK != 0 || p.C1 % BK != 0 || p.C1 <= 0 || p.Cout % 4 != 0 || (p.C1 < p.Cin && !p.X2) ||
         (long long)taps * p.Cin > (1LL << 30) || p.ldy % 4 != 0 || (p.res && p.ldres % 4 != 0) || (p.temb && p.temb_ld % 4 != 0))
         return hipErrorInvalidValue;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.Cout + BN - 1) / BN;
     const long long tiles = (long long)tiles_m * tiles_n;
     const int per_xcd = (int)((tiles + 7) / 8);
-    hipLaunchKernelGGL(gemm32_kernel, dim3((unsigned)(per_xcd * 8)), dim3(NT), 0, s, p, tiles_m, tiles_n, per_xcd);
+    float* zp = nullptr;
+    hipError_t e = hipGetSymbolAddress((void**)&zp, HIP_SYMBOL(g_zero_page32));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gemm32_kernel, dim3((unsigned)(per_xcd * 8)), dim3(NT), 0, s, p, tiles_m, tiles_n, per_xcd, (const float*)zp);
     return hipGetLastError();
 }
 

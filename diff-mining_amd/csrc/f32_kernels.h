@@ -45,7 +45,8 @@ hipError_t launch_silu(const float* in, float* out, long long n, hipStream_t s);
 hipError_t launch_geglu(const float* proj, long long M, int F, float* out, hipStream_t s);
 // Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): out [B][dim] = [cos | sin]
 hipError_t launch_timestep_embed(const int64_t* t, int B, int dim, float* out, hipStream_t s);
-// conv_in: sample NCHW [B,Cin<=4,H,W] (x) 3x3 pad 1 -> NHWC [B,H,W,Cout]; w [Cout][Cin][3][3] (PyTorch layout), bias [Cout]
+// conv_in: sample NCHW [B,Cin<=4,H,W] (x) 3x3 pad 1 -> NHWC [B,H,W,Cout]; w transposed [Cin*9][Cout] (k = (ci, dy, dx): consecutive
+// threads = consecutive output channels read consecutive weights), bias [Cout]
 hipError_t launch_conv_in(const float* x, const float* w, const float* bias, int B, int Cin, int H, int W, int Cout, float* y, hipStream_t s);
 // conv_out: NHWC [B,H,W,C] (x) 3x3 pad 1 -> NCHW [B,Cout<=8,H,W]; w packed [Cout][9*C] k = (tap, c)
 hipError_t launch_conv_out(const float* x, const float* w, const float* bias, int B, int H, int W, int C, int Cout, float* y, hipStream_t s);

@@ -250,7 +250,7 @@ __global__ void conv_in32_kernel(const float* x, const float* w, const float* bi
                 for (int dx = 0; dx < 3; ++dx) {
                     const int ix = ox + dx - 1;
                     if (ix < 0 || ix >= W) continue;
-                    acc += x[(((long long)n * Cin + ci) * H + iy) * W + ix] * w[((co * Cin + ci) * 3 + dy) * 3 + dx];
+                    acc += x[(((long long)n * Cin + ci) * H + iy) * W + ix] * w[((ci * 3 + dy) * 3 + dx) * Cout + co];
                 }
             }
         y[i] = acc + bias[co];

@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -49,7 +50,7 @@ struct T32 {                // NHWC fp32 activation in the arena
     size_t off = NONE; float* p = nullptr; int N = 0, H = 0, W = 0, C = 0;
     long long rows() const { return (long long)N * H * W; }
 };
-struct Ev { hipEvent_t a, b; double flops; int kind; };
+struct Ev { hipEvent_t a, b; double flops; int kind; int M = 0, N = 0, K = 0, mode = 0; };
 
 }  // namespace
 
@@ -185,9 +186,9 @@ struct Fwd32 {
         return 0;
     }
     void free(T32& t) { if (t.off != NONE) { e->arena.release(t.off); t.off = NONE; t.p = nullptr; } }
-    int prof_begin(int kind, double flops) {
+    int prof_begin(int kind, double flops, int M = 0, int N = 0, int K = 0, int mode = 0) {
         if (!e->prof || dry) return 0;
-        Ev ev; ev.flops = flops; ev.kind = kind;
+        Ev ev; ev.flops = flops; ev.kind = kind; ev.M = M; ev.N = N; ev.K = K; ev.mode = mode;
         for (hipEvent_t* h : {&ev.a, &ev.b}) {
             if (!e->ev_pool.empty()) { *h = e->ev_pool.back(); e->ev_pool.pop_back(); }
             else F_HIP(e, hipEventCreate(h));
@@ -208,7 +209,7 @@ struct Fwd32 {
         p.Cout = cv.cout; p.Cin = cin; p.C1 = x.C; p.mode = mode; p.ldy = cv.cout; p.ldres = res ? res->C : 0; p.temb_ld = temb_ld;
         if (mode == 0) { p.M = (int)x.rows(); p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M; }
         else { p.M = x.N * OH * OW; p.H = x.H; p.W = x.W; p.OH = OH; p.OW = OW; }
-        F_TRY(prof_begin(0, 2.0 * (double)p.M * cv.cout * (double)((mode == 0 ? 1 : 9) * cin)));
+        F_TRY(prof_begin(0, 2.0 * (double)p.M * cv.cout * (double)((mode == 0 ? 1 : 9) * cin), p.M, cv.cout, (mode == 0 ? 1 : 9) * cin, mode));
         F_HIP(e, launch_gemm(p, s));
         return prof_end();
     }
@@ -253,7 +254,7 @@ struct Fwd32 {
         a.bsq = bsq; a.bsk = bskv; a.bsv = bskv; a.bso = (long long)Tq * C;
         a.kv_slot = slots; a.n_slots = e->n_prompts; a.B = B; a.heads = HEADS; a.Tq = Tq; a.Tk = Tk; a.D = C / HEADS;
         a.scale = 1.0f / sqrtf((float)a.D);
-        F_TRY(prof_begin(1, 4.0 * B * HEADS * (double)Tq * Tk * a.D));
+        F_TRY(prof_begin(1, 4.0 * B * HEADS * (double)Tq * Tk * a.D, B * Tq, Tk, a.D, Tq == Tk ? 100 : 101));
         F_HIP(e, launch_attention(a, s));
         return prof_end();
     }
@@ -482,10 +483,13 @@ int dm_f32_finalize(dm_f32_net* e) {
     if (!e) return 1;
     if (e->finalized) return 0;
     F_HIP(e, hipSetDevice(e->device));
-    {   // conv_in keeps the PyTorch layout (direct kernel); conv_out is packed (tap, c)
+    {   // conv_in runs as a direct kernel on the NCHW sample: weights transposed to [(ci, dy, dx)][cout]
         HostT* w = get(e, "conv_in.weight", {BOC[0], 4, 3, 3});
         if (!w) return 1;
-        e->conv_in.w = put(e, w->data.data(), w->data.size());
+        std::vector<float> wt((size_t)36 * BOC[0]);
+        for (int co = 0; co < BOC[0]; ++co)
+            for (int k = 0; k < 36; ++k) wt[(size_t)k * BOC[0] + co] = w->data[(size_t)co * 36 + k];
+        e->conv_in.w = put(e, wt.data(), wt.size());
         e->conv_in.cin = 4; e->conv_in.cout = BOC[0]; e->conv_in.k = 3;
         F_TRY(pack_vec(e, "conv_in.bias", BOC[0], &e->conv_in.b));
     }
@@ -596,13 +600,17 @@ int dm_f32_prof_read(dm_f32_net* e, double* gemm_ms, double* gemm_flops, int64_t
                      int64_t* attn_launches) {
     if (!e) return 1;
     F_HIP(e, hipSetDevice(e->device));
+    FILE* dump = nullptr;          // DM_PROF_DUMP=<file>: one line per timed launch (kind M N K mode flops ms) for tools/prof_shapes.py
+    if (const char* dp = getenv("DM_PROF_DUMP")) dump = fopen(dp, "a");
     for (auto& ev : e->evs) {
         F_HIP(e, hipEventSynchronize(ev.b));
         float ms = 0.f;
         F_HIP(e, hipEventElapsedTime(&ms, ev.a, ev.b));
+        if (dump) fprintf(dump, "%d %d %d %d %d %.0f %.6f\n", ev.kind, ev.M, ev.N, ev.K, ev.mode, ev.flops, ms);
         e->prof_ms[ev.kind] += ms; e->prof_flops[ev.kind] += ev.flops; e->prof_n[ev.kind] += 1;
         e->ev_pool.push_back(ev.a); e->ev_pool.push_back(ev.b);
     }
+    if (dump) fclose(dump);
     e->evs.clear();
     if (gemm_ms) *gemm_ms = e->prof_ms[0];
     if (gemm_flops) *gemm_flops = e->prof_flops[0];

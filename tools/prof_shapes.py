@@ -10,6 +10,8 @@ import sys
 from collections import defaultdict
 
 path, steps = sys.argv[1], int(sys.argv[2])
+PEAK = float(sys.argv[3]) if len(sys.argv) > 3 else 2.5e15      # 157.3e12 for the fp32 net (bench.py --workload dift)
+EB = 4.0 if PEAK < 1e15 else 2.0                                 # bytes per element
 acc = defaultdict(lambda: [0, 0.0, 0.0])
 for line in open(path):
     kind, M, N, K, mode, flops, ms = line.split()
@@ -25,15 +27,15 @@ for (kind, M, N, K, mode), (n, ms, fl) in acc.items():
         epi = mode // 10
         taps = 1 if mode % 10 == 0 else 9
         nout = N // 2 if epi else N
-        byts = 2.0 * (M * (K // taps) + N * K + M * nout)
+        byts = EB * (M * (K // taps) + N * K + M * nout)
         hbm_ms = byts / 5e12 * 1e3
-        mfma_ms = 2.0 * M * N * K / 2.5e15 * 1e3
+        mfma_ms = 2.0 * M * N * K / PEAK * 1e3
         name = f"igemm mode{mode % 10}{' geglu' if epi else ''} M={M} N={N} K={K}"
         bound = max(hbm_ms, mfma_ms) * n_s
         rows.append((ms_s, name, n_s, tf, bound, "hbm" if hbm_ms > mfma_ms else "mfma"))
     else:
         name = f"attn {'self' if mode == 100 else 'cross'} rows={M} Tk={N} D={K}"
-        mfma_ms = fl / n / 2.5e15 * 1e3
+        mfma_ms = fl / n / PEAK * 1e3
         rows.append((ms_s, name, n_s, tf, mfma_ms * n_s, "mfma"))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
