@@ -227,3 +227,71 @@ def test_sdfeaturizer_fp32_is_the_default_arithmetic(net32, sd15_weights_f16, sd
     e16.close()
     print(f"SDFeaturizer fp32 net vs fp32 oracle {r:.2e}; fp16 engine vs fp32 oracle {r16:.2e}")
     assert out.shape == (1, 1280, h // 2, w // 2) and r < TOL_E2E and r16 < 4e-3
+
+
+def _grid32(net32, x, c, noises, ts):
+    """D.compute_losses (compute.py:134-160) in exact fp32 on the GPU: the reference's add_noise / MSE in torch fp32 around the
+    fp32 U-Net -> [N,2,4,h,w] fp32 (cond 0 = c, 1 = null) — what the CPU oracle computes with autocast=False, at any size."""
+    dev = net32.device
+    N = noises.shape[0]
+    acp = R.alphas_cumprod().to(dev)
+    xs, eps, t = x.to(dev).float().expand(N, -1, -1, -1), noises.to(dev).float(), ts.to(dev)
+    a = acp[t].view(N, 1, 1, 1)
+    noisy = (a ** 0.5) * xs + ((1 - a) ** 0.5) * eps
+    net32.set_prompts(c.float())
+    out = []
+    for k in range(2):
+        eh = net32.unet(noisy, t, torch.full((N,), k, dtype=torch.int32))
+        out.append((eh - eps) ** 2)
+    return torch.stack(out, dim=1)
+
+
+def test_gpu_fp32_ground_truth_agrees_with_the_cpu_oracle(net32, sd15_weights_torch):
+    """The loss grid of `_grid32` IS the fp32 oracle's (autocast=False): checked where the CPU oracle is affordable, so that the
+    full-size comparison below can stand on it."""
+    N, h, w = 3, 16, 16
+    x, _, _, c = synth.synth_inputs(1, 1, h, w, latent_dtype=np.float32)
+    x, c = torch.from_numpy(x), torch.from_numpy(c)
+    noises, ts = R.draw_noise_and_timesteps((1, 4, h, w), N, 0.1, 0.7, seed=42)
+    g = _grid32(net32, x, c, noises, ts).cpu()
+    # (R.compute_losses returns the reference's fp16 grid; the unrounded fp32 losses come from compute_loss on the tiled batch)
+    cc = torch.cat([c[k:k + 1].float().expand(N, -1, -1) for k in range(2)])
+    ref = R.compute_loss(sd15_weights_torch, x, torch.cat([noises] * 2), torch.cat([ts] * 2), cc, autocast=False)
+    ref = ref.view(2, N, 4, h, w).transpose(0, 1)
+    r = U.rel_l2(g, ref)
+    dT = abs(R.typicality_scalar(g).item() - R.typicality_scalar(ref).item()) / ref.mean().item()
+    print(f"fp32 grid on the GPU vs the fp32 CPU oracle @16x16 N=3: rel-L2 {r:.2e}, |dT|/mean loss {dT:.2e}")
+    assert g.shape == ref.shape and r < TOL_E2E and dT < 1e-6
+
+
+def test_fp16_engine_vs_fp32_ground_truth_at_the_baseline_configuration(net32, sd15_weights_f16):
+    """BASELINE configs[1] itself — 512 px (64 x 64 latent), N = 10 draws x 2 prompts per image — for four images: the fp16 engine's
+    grid and T(x|c) against the exact-fp32 evaluation of the same U-Net on the same inputs (the CPU oracle reaches this size only
+    for single forwards).  Bounds: the loss-grid and T(x|c) tolerances of tests/test_gpu_e2e.py (1.5 x the autocast oracle's own
+    spread under re-ordering; the fp32 truth is one more sample of that cloud's centre)."""
+    from diff_mining_amd.engine import UNetEngine
+    from diff_mining_amd.typicality import TypicalityScorer
+    import json
+    import os
+    floor = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_T_floor.json")))
+    N, h, w, n_img = 10, 64, 64, 4
+    e16 = UNetEngine(0)
+    e16.load_state_dict(sd15_weights_f16)
+    sc = TypicalityScorer(e16, seed=42, N=N, t_min=0.1, t_max=0.7)
+    xs, _, _, c = synth.synth_inputs(n_img, 1, h, w, latent_dtype=np.float32)
+    xs, c = torch.from_numpy(xs), torch.from_numpy(c)
+    worst = [0.0, 0.0, 0.0]
+    for i in range(n_img):
+        x = xs[i:i + 1]
+        noises, ts = sc.draw(x.shape)
+        grid = sc.compute_losses(x, c, noises=noises, timesteps=ts, to_host=False).float()
+        ref = _grid32(net32, x, c, noises, ts)
+        rl = U.rel_l2(grid.cpu(), ref.cpu())
+        T, T_ref, ml = R.typicality_scalar(grid.cpu()).item(), R.typicality_scalar(ref.cpu()).item(), ref.mean().item()
+        d = (rl, abs(T - T_ref) / abs(T_ref), abs(T - T_ref) / ml)
+        worst = [max(a, b) for a, b in zip(worst, d)]
+        print(f"[64x64 N=10 image {i}] fp16 grid vs fp32 truth rel-L2 {rl:.2e}; T engine {T:.6f} fp32 {T_ref:.6f} mean loss {ml:.4f}: "
+              f"|dT|/|T| {d[1]:.2e}  |dT|/mean-loss {d[2]:.2e}")
+    e16.close()
+    assert worst[0] < 1.5 * 1.23e-3                                   # TOL_LOSS of test_gpu_e2e.py
+    assert worst[2] <= 1.5 * floor["max_dT_over_mean_loss"] * 1.5     # T10 bound of test_gpu_e2e.py; x 1.5: the grid is fp16-rounded, the truth is not
