@@ -17,7 +17,8 @@ import torch  # noqa: E402
 
 from diff_mining_amd import synth  # noqa: E402
 from diff_mining_amd.engine import UNetEngine, UNetEngineF32  # noqa: E402
-from diff_mining_amd.typicality import TypicalityScorer, scheduler_alphas_cumprod  # noqa: E402
+from diff_mining_amd.dift import scheduler_alphas_cumprod  # noqa: E402
+from diff_mining_amd.typicality import TypicalityScorer  # noqa: E402
 
 
 def main():
