@@ -30,7 +30,7 @@ struct AttnParams {
     long long bsq, bsk, bsv, bso;      // batch strides in elements
     const int32_t* kv_slot = nullptr;  // optional: K/V batch index per sample (prompt slot), clamped to [0, n_slots)
     int n_slots = 0;
-    int B, heads, Tq, Tk, D;           // D in {40, 80, 160}
+    int B, heads, Tq, Tk, D;           // D in {40, 80, 160, 512}
     float scale;
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
@@ -51,6 +51,9 @@ hipError_t launch_conv_in(const float* x, const float* w, const float* bias, int
 // conv_out: NHWC [B,H,W,C] (x) 3x3 pad 1 -> NCHW [B,Cout<=8,H,W]; w packed [Cout][9*C] k = (tap, c)
 hipError_t launch_conv_out(const float* x, const float* w, const float* bias, int B, int H, int W, int C, int Cout, float* y, hipStream_t s);
 hipError_t launch_nhwc_to_nchw(const float* X, int N, int HW, int C, float* Y, hipStream_t s);
+// quant_conv (1x1, 8 -> 8) on Hm [B*HW][8] + `draws` posterior samples per image * scaling (NCHW outputs: latent [B*draws,4,HW], moments [B,8,HW])
+hipError_t launch_posterior(const float* Hm, const float* qw, const float* qb, const float* noise, int B, int draws, int HW, float scaling,
+                            float* latent, float* moments, hipStream_t s);
 // mean over groups of `ens` consecutive samples, NHWC -> NCHW
 hipError_t launch_ensemble_mean(const float* X, int groups, int ens, int HW, int C, float* Y, hipStream_t s);
 

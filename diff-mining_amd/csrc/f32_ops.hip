@@ -10,7 +10,7 @@ namespace {
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 // ---- attention -----------------------------------------------------------------------------------------------------------------
-// One block = 128 queries of one (sample, head): 4 waves x 32 queries (two 16-query MFMA tiles).  Key tiles of KT keys are staged
+// One block = 64 QT queries of one (sample, head): 4 waves x QT 16-query MFMA tiles (QT = 2; 1 for the VAE's head_dim 512).  Key tiles of KT keys are staged
 // in LDS as [key][D + 4] fp32 rows (the + 4 makes every fragment read below bank-conflict-free for D = 40 / 80 / 160: 16 rows
 // x 4 column groups hit 64 distinct banks).
 //   S^T[key][query] = K Q^T   : A = K rows  (lane (c, g): key c, d = 4 s + g),  B = Q^T (query c, d = 4 s + g), D/4 k steps — head_dim
@@ -19,14 +19,14 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 //   O^T[d][query] += V^T P^T   : B = P^T is the S^T accumulator AS IT LIES (register r <-> key 4 g + r, lane <-> query c) — P never
 //                                leaves its lane —, A = V^T (lane (c, g): d = 16 dt + c, key 4 g + r)
 // Online softmax (running maximum / sum, exp2 on pre-scaled scores), exact fp32 products and accumulation.
-template <int D, int KT>
+template <int D, int KT, int QT>
 __global__ __launch_bounds__(256) void attn32_kernel(AttnParams p) {
     constexpr int LD = D + 4, DT = (D + 15) / 16, KS = D / 4, NKT = KT / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
     float* Vs = smem + KT * LD;            // + 16 floats of slack after it: the last d tile of D = 40 reads columns 40..47
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wid * 32;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (64 * QT) + wid * (16 * QT);
     int kb = b;
     if (p.kv_slot) { kb = p.kv_slot[b]; kb = kb < 0 ? 0 : (kb >= p.n_slots ? p.n_slots - 1 : kb); }
     const float* Qb = p.Q + (long long)b * p.bsq + h * D;
@@ -34,17 +34,21 @@ __global__ __launch_bounds__(256) void attn32_kernel(AttnParams p) {
     const float* Vb = p.V + (long long)kb * p.bsv + h * D;
     const float qscale = p.scale * 1.44269504088896340736f;
 
-    float qf[2][KS];
+    float qf[QT][KS];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         int qi = q0 + qt * 16 + c; qi = qi < p.Tq ? qi : p.Tq - 1;
 #pragma unroll
         for (int s = 0; s < KS; ++s) qf[qt][s] = Qb[(long long)qi * p.ldq + 4 * s + g] * qscale;
     }
-    v4f o[DT][2];
+    v4f o[DT][QT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) { o[dt][0] = v4f{0.f, 0.f, 0.f, 0.f}; o[dt][1] = v4f{0.f, 0.f, 0.f, 0.f}; }
-    float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[dt][qt] = v4f{0.f, 0.f, 0.f, 0.f};
+    float mrun[QT], lrun[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { mrun[qt] = -INFINITY; lrun[qt] = 0.f; }
 
     for (int k0 = 0; k0 < p.Tk; k0 += KT) {
         __syncthreads();
@@ -59,19 +63,21 @@ __global__ __launch_bounds__(256) void attn32_kernel(AttnParams p) {
             *reinterpret_cast<v4f*>(Vs + r * LD + 4 * c4) = vv;
         }
         __syncthreads();
-        v4f sacc[NKT][2];
+        v4f sacc[NKT][QT];
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) { sacc[kt][0] = v4f{0.f, 0.f, 0.f, 0.f}; sacc[kt][1] = v4f{0.f, 0.f, 0.f, 0.f}; }
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) sacc[kt][qt] = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
                 const float a = Ks[(kt * 16 + c) * LD + 4 * s + g];
-                sacc[kt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qf[0][s], sacc[kt][0], 0, 0, 0);
-                sacc[kt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qf[1][s], sacc[kt][1], 0, 0, 0);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) sacc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qf[qt][s], sacc[kt][qt], 0, 0, 0);
             }
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             float mx = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
@@ -107,12 +113,12 @@ __global__ __launch_bounds__(256) void attn32_kernel(AttnParams p) {
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     const float a = Vs[(kt * 16 + 4 * g + r) * LD + dt * 16 + c];
-                    o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sacc[kt][0][r], o[dt][0], 0, 0, 0);
-                    o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sacc[kt][1][r], o[dt][1], 0, 0, 0);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sacc[kt][qt][r], o[dt][qt], 0, 0, 0);
                 }
     }
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         float l = lrun[qt];
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
@@ -128,12 +134,12 @@ __global__ __launch_bounds__(256) void attn32_kernel(AttnParams p) {
     }
 }
 
-template <int D, int KT>
+template <int D, int KT, int QT>
 hipError_t launch_attn_t(const AttnParams& p, hipStream_t s) {
     const size_t lds = (size_t)(2 * KT * (D + 4) + 16) * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn32_kernel<D, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn32_kernel<D, KT, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((attn32_kernel<D, KT>), dim3((p.Tq + 127) / 128, p.heads, p.B), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((attn32_kernel<D, KT, QT>), dim3((p.Tq + 64 * QT - 1) / (64 * QT), p.heads, p.B), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
@@ -304,6 +310,37 @@ __global__ void ensemble_mean32_kernel(const float* X, int groups, int ens, int 
     }
 }
 
+// quant_conv (1x1, 8 -> 8) on Hm [B*HW][8] + DiagonalGaussianDistribution.sample() with the draw injected, times scaling_factor,
+// all fp32: latent = (mean + exp(0.5 clamp(logvar, -30, 20)) * noise) * scaling; noise == nullptr -> the mode.  `draws` samples per
+// image: output sample b * draws + d reads the moments of image b.  NCHW outputs.
+__global__ void posterior32_kernel(const float* Hm, const float* qw, const float* qb, const float* noise, int B, int draws, int HW,
+                                   float scaling, float* latent, float* moments) {
+    const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (long long)B * draws * HW) return;
+    const int bo = (int)(pix / HW), rem = (int)(pix - (long long)bo * HW), b = bo / draws;
+    const float* hv = Hm + ((size_t)b * HW + rem) * 8;
+    float m[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += qw[o * 8 + i] * hv[i];
+        m[o] = acc + qb[o];
+        if (moments && bo == b * draws) moments[((size_t)b * 8 + o) * HW + rem] = m[o];
+    }
+    if (!latent) return;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float v = m[c];
+        if (noise) {
+            float lv = m[4 + c];
+            lv = lv < -30.f ? -30.f : (lv > 20.f ? 20.f : lv);
+            v += expf(0.5f * lv) * noise[((size_t)bo * 4 + c) * HW + rem];
+        }
+        latent[((size_t)bo * 4 + c) * HW + rem] = v * scaling;
+    }
+}
+
 inline unsigned grid_for(long long n, int block = 256) {
     long long g = (n + block - 1) / block;
     return (unsigned)(g < 1 ? 1 : (g > 65536 * 16 ? 65536 * 16 : g));
@@ -314,9 +351,10 @@ inline unsigned grid_for(long long n, int block = 256) {
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.Tq <= 0 || p.Tk <= 0 || (p.ldq | p.ldk | p.ldv | p.ldo) % 4 != 0) return hipErrorInvalidValue;
     switch (p.D) {
-        case 40: return launch_attn_t<40, 64>(p, s);
-        case 80: return launch_attn_t<80, 64>(p, s);
-        case 160: return launch_attn_t<160, 64>(p, s);
+        case 40: return launch_attn_t<40, 64, 2>(p, s);
+        case 80: return launch_attn_t<80, 64, 2>(p, s);
+        case 160: return launch_attn_t<160, 64, 2>(p, s);
+        case 512: return launch_attn_t<512, 16, 1>(p, s);       // AutoencoderKL mid-block attention (one head)
         default: return hipErrorInvalidValue;
     }
 }
@@ -358,6 +396,12 @@ hipError_t launch_conv_out(const float* x, const float* w, const float* bias, in
     if (Cout > 8) return hipErrorInvalidValue;
     const long long px = (long long)B * H * W;
     hipLaunchKernelGGL(conv_out32_kernel, dim3((unsigned)((px + 3) / 4)), dim3(256), 0, s, x, w, bias, B, H, W, C, Cout, y);
+    return hipGetLastError();
+}
+hipError_t launch_posterior(const float* Hm, const float* qw, const float* qb, const float* noise, int B, int draws, int HW, float scaling,
+                            float* latent, float* moments, hipStream_t s) {
+    const long long total = (long long)B * draws * HW;
+    hipLaunchKernelGGL(posterior32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Hm, qw, qb, noise, B, draws, HW, scaling, latent, moments);
     return hipGetLastError();
 }
 hipError_t launch_nhwc_to_nchw(const float* X, int N, int HW, int C, float* Y, hipStream_t s) {

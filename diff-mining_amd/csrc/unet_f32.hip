@@ -46,6 +46,19 @@ struct Tfm { Norm gn, ln1, ln2, ln3; Conv proj_in, proj_out, qkv, o1, q2, kv2, o
 struct DownB { Res res[2]; Tfm tf[2]; bool attn = false; Conv down; bool has_down = false; };
 struct UpB { Res res[3]; Tfm tf[3]; bool attn = false; Conv up; bool has_up = false; };
 
+// SDv1.5 AutoencoderKL encoder (block_out_channels 128/256/512/512, two resnets per block, no time embedding)
+constexpr int VNB = 4;
+const int VBOC[VNB] = {128, 256, 512, 512};
+constexpr float VAE_EPS = 1e-6f;
+struct Vae32 {
+    Conv conv_in;                  // transposed [27][128] for the direct kernel
+    Res down[VNB][2]; Conv ds[VNB - 1];
+    Res mid[2];
+    Norm attn_gn; Conv qkv, o;     // single-head attention, to_q / to_k / to_v stacked [1536][512]
+    Norm norm_out; Conv conv_out;  // [8][9*512]
+    size_t qw = NONE, qb = NONE;   // quant_conv [8][8], [8]
+};
+
 struct T32 {                // NHWC fp32 activation in the arena
     size_t off = NONE; float* p = nullptr; int N = 0, H = 0, W = 0, C = 0;
     long long rows() const { return (long long)N * H * W; }
@@ -61,6 +74,11 @@ struct dm_f32_net {
     bool finalized = false;
     std::vector<float> blob;           // host staging of the slab (freed after upload)
     float* slab = nullptr; size_t slab_floats = 0;
+    // optional VAE encoder (dm_f32_load_vae_weight / dm_f32_finalize_vae): the reference's featuriser encodes the image in fp32 too
+    std::map<std::string, HostT> host_vae;
+    std::map<std::string, HostT>* cur_host = nullptr;      // the map the pack functions read (U-Net or VAE)
+    float* vslab = nullptr; size_t vslab_floats = 0;
+    Vae32 vae; bool vae_ready = false;
     Conv conv_in, conv_out, time1, time2, tproj_all;
     Norm norm_out;
     DownB down[NB]; Res mid_res[2]; Tfm mid_tf; UpB up[NB];
@@ -85,8 +103,9 @@ namespace {
 
 // ---- packing ---------------------------------------------------------------------------------------------------------------
 HostT* get(dm_f32_net* e, const std::string& name, std::initializer_list<int64_t> shape) {
-    auto it = e->host.find(name);
-    if (it == e->host.end()) { e->err = "missing tensor: " + name; return nullptr; }
+    std::map<std::string, HostT>& m = e->cur_host ? *e->cur_host : e->host;
+    auto it = m.find(name);
+    if (it == m.end()) { e->err = "missing tensor: " + name; return nullptr; }
     if (it->second.shape != std::vector<int64_t>(shape)) { e->err = "shape mismatch for " + name; return nullptr; }
     it->second.used = true;
     return &it->second;
@@ -152,6 +171,15 @@ int pack_res(dm_f32_net* e, const std::string& name, int cin, int cout, Res* r) 
     if (r->has_sc) F_TRY(pack_dense(e, name + ".conv_shortcut", cout, cin, true, true, &r->sc));
     return 0;
 }
+int pack_vae_res(dm_f32_net* e, const std::string& name, int cin, int cout, Res* r) {
+    F_TRY(pack_norm(e, name + ".norm1", cin, &r->n1));
+    F_TRY(pack_conv3(e, name + ".conv1", cout, cin, &r->c1));
+    F_TRY(pack_norm(e, name + ".norm2", cout, &r->n2));
+    F_TRY(pack_conv3(e, name + ".conv2", cout, cout, &r->c2));
+    r->has_sc = cin != cout;
+    if (r->has_sc) F_TRY(pack_dense(e, name + ".conv_shortcut", cout, cin, true, true, &r->sc));
+    return 0;
+}
 int pack_tfm(dm_f32_net* e, const std::string& name, int c, Tfm* t) {
     t->c = c; t->layer = e->n_tf++;
     e->tfs.push_back(t);
@@ -175,7 +203,9 @@ int pack_tfm(dm_f32_net* e, const std::string& name, int c, Tfm* t) {
 // ---- forward -----------------------------------------------------------------------------------------------------------------
 struct Fwd32 {
     dm_f32_net* e; hipStream_t s; bool dry;
-    const float* P(size_t off) const { return off == NONE ? nullptr : e->slab + off; }
+    const float* base = nullptr;     // weight slab the offsets refer to (U-Net or VAE)
+    float res_eps = GN_EPS;          // GroupNorm eps of the ResNet blocks (U-Net 1e-5, VAE 1e-6)
+    const float* P(size_t off) const { return off == NONE ? nullptr : base + off; }
 
     int alloc(T32* t, int N, int H, int W, int C) {
         t->N = N; t->H = H; t->W = W; t->C = C;
@@ -234,10 +264,10 @@ struct Fwd32 {
     }
     int resnet(const Res& r, const T32& x, const T32* x2, const float* tproj, T32* out) {      // ResnetBlock2D
         T32 n1, h1, n2, sc;
-        F_TRY(groupnorm(r.n1, x, x2, GN_EPS, true, &n1));
+        F_TRY(groupnorm(r.n1, x, x2, res_eps, true, &n1));
         F_TRY(gemm(r.c1, 1, n1, nullptr, x.H, x.W, tproj ? tproj + r.temb_off : nullptr, e->tproj_total, nullptr, &h1));
         free(n1);
-        F_TRY(groupnorm(r.n2, h1, nullptr, GN_EPS, true, &n2));
+        F_TRY(groupnorm(r.n2, h1, nullptr, res_eps, true, &n2));
         free(h1);
         const T32* resid = &x;
         if (r.has_sc) { F_TRY(dense(r.sc, x, x2, nullptr, &sc)); resid = &sc; }
@@ -248,13 +278,13 @@ struct Fwd32 {
         return 0;
     }
     int attention(const float* Q, int ldq, long long bsq, const float* K, const float* V, int ldkv, long long bskv, const int32_t* slots,
-                  int B, int Tq, int Tk, int C, float* O) {
+                  int B, int Tq, int Tk, int C, float* O, int heads = HEADS) {
         AttnParams a;
         a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.ldo = C;
         a.bsq = bsq; a.bsk = bskv; a.bsv = bskv; a.bso = (long long)Tq * C;
-        a.kv_slot = slots; a.n_slots = e->n_prompts; a.B = B; a.heads = HEADS; a.Tq = Tq; a.Tk = Tk; a.D = C / HEADS;
+        a.kv_slot = slots; a.n_slots = e->n_prompts; a.B = B; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.D = C / heads;
         a.scale = 1.0f / sqrtf((float)a.D);
-        F_TRY(prof_begin(1, 4.0 * B * HEADS * (double)Tq * Tk * a.D, B * Tq, Tk, a.D, Tq == Tk ? 100 : 101));
+        F_TRY(prof_begin(1, 4.0 * B * heads * (double)Tq * Tk * a.D, B * Tq, Tk, a.D, Tq == Tk ? 100 : 101));
         F_HIP(e, launch_attention(a, s));
         return prof_end();
     }
@@ -303,7 +333,7 @@ struct Args32 {
 };
 
 int run_forward32(dm_f32_net* e, const Args32& A, hipStream_t s, bool dry) {
-    Fwd32 F{e, s, dry};
+    Fwd32 F{e, s, dry, e->slab};
     const int B = A.B;
     T32 te0, e1, e1s, emb, embs, tproj;
     F_TRY(F.alloc(&te0, 1, 1, B, BOC[0]));
@@ -387,9 +417,64 @@ int run_forward32(dm_f32_net* e, const Args32& A, hipStream_t s, bool dry) {
     return 0;
 }
 
-int ensure_arena32(dm_f32_net* e, const Args32& A, hipStream_t s) {
+int ensure_arena32(dm_f32_net* e, const Args32& A, hipStream_t s);
+
+// ---- VAE encoder: image -> moments -> latent (dift.py:187: `pipe.vae.encode(img).latent_dist.sample() * scaling_factor`, fp32) ----
+struct VaeArgs32 { const float* image; const float* noise; int B, draws, H, W; float scaling; float* latent; float* moments; };
+
+int run_vae32(dm_f32_net* e, const VaeArgs32& A, hipStream_t s, bool dry) {
+    Fwd32 F{e, s, dry, e->vslab};
+    F.res_eps = VAE_EPS;
+    const Vae32& v = e->vae;
+    T32 cur;
+    F_TRY(F.alloc(&cur, A.B, A.H, A.W, VBOC[0]));
+    if (!dry) F_HIP(e, launch_conv_in(A.image, F.P(v.conv_in.w), F.P(v.conv_in.b), A.B, 3, A.H, A.W, VBOC[0], cur.p, s));
+    for (int i = 0; i < VNB; ++i) {
+        for (int j = 0; j < 2; ++j) {
+            T32 r;
+            F_TRY(F.resnet(v.down[i][j], cur, nullptr, nullptr, &r));
+            F.free(cur);
+            cur = r;
+        }
+        if (i != VNB - 1) {      // Downsample2D(padding=0): F.pad(x, (0,1,0,1)) + conv3x3 stride 2
+            T32 dn;
+            F_TRY(F.gemm(v.ds[i], 4, cur, nullptr, cur.H / 2, cur.W / 2, nullptr, 0, nullptr, &dn));
+            F.free(cur);
+            cur = dn;
+        }
+    }
+    {
+        T32 m0, n, qkv, a, m1, m2;
+        F_TRY(F.resnet(v.mid[0], cur, nullptr, nullptr, &m0));
+        F.free(cur);
+        const int C = VBOC[VNB - 1], T = m0.H * m0.W;
+        F_TRY(F.groupnorm(v.attn_gn, m0, nullptr, VAE_EPS, false, &n));
+        F_TRY(F.dense(v.qkv, n, nullptr, nullptr, &qkv));
+        F.free(n);
+        F_TRY(F.alloc(&a, m0.N, m0.H, m0.W, C));
+        if (!dry) F_TRY(F.attention(qkv.p, 3 * C, (long long)T * 3 * C, qkv.p + C, qkv.p + 2 * C, 3 * C, (long long)T * 3 * C, nullptr,
+                                    m0.N, T, T, C, a.p, 1));
+        F.free(qkv);
+        F_TRY(F.dense(v.o, a, nullptr, &m0, &m1));
+        F.free(a); F.free(m0);
+        F_TRY(F.resnet(v.mid[1], m1, nullptr, nullptr, &m2));
+        F.free(m1);
+        cur = m2;
+    }
+    T32 nrm, co;
+    F_TRY(F.groupnorm(v.norm_out, cur, nullptr, VAE_EPS, true, &nrm));
+    F.free(cur);
+    F_TRY(F.gemm(v.conv_out, 1, nrm, nullptr, nrm.H, nrm.W, nullptr, 0, nullptr, &co));
+    F.free(nrm);
+    if (!dry) F_HIP(e, launch_posterior(co.p, F.P(v.qw), F.P(v.qb), A.noise, A.B, A.draws, co.H * co.W, A.scaling, A.latent, A.moments, s));
+    F.free(co);
+    return 0;
+}
+
+template <class RunDry>
+int ensure_arena_for32(dm_f32_net* e, hipStream_t s, RunDry run_dry) {
     e->arena.reset((size_t)1 << 46, true);
-    F_TRY(run_forward32(e, A, s, true));
+    F_TRY(run_dry());
     const size_t need = e->arena.peak + (1 << 20);
     if (need > e->arena_cap) {
         if (e->arena_base) { F_HIP(e, hipStreamSynchronize(s)); F_HIP(e, hipFree(e->arena_base)); e->arena_base = nullptr; e->arena_cap = 0; }
@@ -405,6 +490,10 @@ int chunk32(int h, int w) {
     const long long area = (long long)h * w;
     long long c = 64LL * 4096 / (area > 0 ? area : 1);
     return (int)(c < 1 ? 1 : (c > 1024 ? 1024 : c));
+}
+
+int ensure_arena32(dm_f32_net* e, const Args32& A, hipStream_t s) {
+    return ensure_arena_for32(e, s, [&]() { return run_forward32(e, A, s, true); });
 }
 
 int run_chunked32(dm_f32_net* e, Args32 A, void* stream) {
@@ -455,6 +544,7 @@ void dm_f32_destroy(dm_f32_net* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     if (e->slab) (void)hipFree(e->slab);
+    if (e->vslab) (void)hipFree(e->vslab);
     if (e->arena_base) (void)hipFree(e->arena_base);
     for (float* p : e->kv_cache) if (p) (void)hipFree(p);
     for (auto& ev : e->evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
@@ -590,6 +680,118 @@ int dm_f32_dift(dm_f32_net* e, const void* noisy_dev, const int64_t* t_dev, cons
     return run_chunked32(e, A, stream);
 }
 
+int dm_f32_load_vae_weight(dm_f32_net* e, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim) {
+    if (!e || !name || !host_ptr || !shape) return 1;
+    if (e->vae_ready) F_FAIL(e, "load_vae_weight after finalize_vae");
+    std::string nm(name);
+    if (nm.rfind("vae.", 0) == 0) nm = nm.substr(4);
+    if (nm.rfind("decoder.", 0) == 0 || nm.rfind("post_quant_conv.", 0) == 0) return 0;     // not on the path
+    // pre-0.15 diffusers names of the mid-block attention, stored as 1x1 convolutions
+    static const char* legacy[4][2] = {{".query.", ".to_q."}, {".key.", ".to_k."}, {".value.", ".to_v."}, {".proj_attn.", ".to_out.0."}};
+    for (auto& l : legacy) { const size_t at = nm.find(l[0]); if (at != std::string::npos) nm.replace(at, strlen(l[0]), l[1]); }
+    HostT t;
+    t.shape.assign(shape, shape + ndim);
+    if (nm.find(".attentions.0.to_") != std::string::npos && ndim == 4 && shape[2] == 1 && shape[3] == 1) t.shape.resize(2);
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    t.data.resize(n);
+    if (dtype == DM_F32) memcpy(t.data.data(), host_ptr, n * sizeof(float));
+    else if (dtype == DM_F16) { const _Float16* h = (const _Float16*)host_ptr; for (size_t i = 0; i < n; ++i) t.data[i] = (float)h[i]; }
+    else F_FAIL(e, "unsupported dtype %d for %s", dtype, name);
+    e->host_vae[nm] = std::move(t);
+    return 0;
+}
+
+int dm_f32_finalize_vae(dm_f32_net* e) {
+    if (!e) return 1;
+    if (e->vae_ready) return 0;
+    F_HIP(e, hipSetDevice(e->device));
+    e->cur_host = &e->host_vae;
+    e->blob.clear();
+    struct Reset { dm_f32_net* e; ~Reset() { e->cur_host = nullptr; } } reset{e};
+    Vae32& v = e->vae;
+    {
+        HostT* w = get(e, "encoder.conv_in.weight", {VBOC[0], 3, 3, 3});
+        if (!w) return 1;
+        std::vector<float> wt((size_t)27 * VBOC[0]);
+        for (int co = 0; co < VBOC[0]; ++co)
+            for (int k = 0; k < 27; ++k) wt[(size_t)k * VBOC[0] + co] = w->data[(size_t)co * 27 + k];
+        v.conv_in.w = put(e, wt.data(), wt.size());
+        v.conv_in.cin = 3; v.conv_in.cout = VBOC[0]; v.conv_in.k = 3;
+        F_TRY(pack_vec(e, "encoder.conv_in.bias", VBOC[0], &v.conv_in.b));
+    }
+    int cin = VBOC[0];
+    for (int i = 0; i < VNB; ++i) {
+        const int cout = VBOC[i];
+        const std::string bn = "encoder.down_blocks." + std::to_string(i);
+        for (int j = 0; j < 2; ++j) F_TRY(pack_vae_res(e, bn + ".resnets." + std::to_string(j), j == 0 ? cin : cout, cout, &v.down[i][j]));
+        if (i != VNB - 1) F_TRY(pack_conv3(e, bn + ".downsamplers.0.conv", cout, cout, &v.ds[i]));
+        cin = cout;
+    }
+    const int C = VBOC[VNB - 1];
+    F_TRY(pack_vae_res(e, "encoder.mid_block.resnets.0", C, C, &v.mid[0]));
+    {
+        const std::string a = "encoder.mid_block.attentions.0";
+        F_TRY(pack_norm(e, a + ".group_norm", C, &v.attn_gn));
+        F_TRY(pack_stack(e, {a + ".to_q", a + ".to_k", a + ".to_v"}, C, C, &v.qkv));
+        std::vector<float> qb;
+        for (const char* leaf : {".to_q", ".to_k", ".to_v"}) {
+            HostT* b = get(e, a + leaf + ".bias", {C});
+            if (!b) return 1;
+            qb.insert(qb.end(), b->data.begin(), b->data.end());
+        }
+        v.qkv.b = put(e, qb.data(), qb.size());
+        F_TRY(pack_dense(e, a + ".to_out.0", C, C, false, true, &v.o));
+    }
+    F_TRY(pack_vae_res(e, "encoder.mid_block.resnets.1", C, C, &v.mid[1]));
+    F_TRY(pack_norm(e, "encoder.conv_norm_out", C, &v.norm_out));
+    F_TRY(pack_conv3(e, "encoder.conv_out", 8, C, &v.conv_out));
+    {
+        HostT* qw = get(e, "quant_conv.weight", {8, 8, 1, 1});
+        HostT* qb = get(e, "quant_conv.bias", {8});
+        if (!qw || !qb) return 1;
+        v.qw = put(e, qw->data.data(), 64);
+        v.qb = put(e, qb->data.data(), 8);
+    }
+    for (auto& kv : e->host_vae)
+        if (!kv.second.used) F_FAIL(e, "unexpected tensor in the VAE state dict: %s", kv.first.c_str());
+    if (e->host_vae.size() != 108) F_FAIL(e, "expected 108 VAE encoder tensors, got %zu", e->host_vae.size());
+    e->vslab_floats = e->blob.size();
+    F_HIP(e, hipMalloc((void**)&e->vslab, e->vslab_floats * sizeof(float)));
+    F_HIP(e, hipMemcpy(e->vslab, e->blob.data(), e->vslab_floats * sizeof(float), hipMemcpyHostToDevice));
+    e->blob.clear(); e->blob.shrink_to_fit();
+    e->host_vae.clear();
+    e->vae_ready = true;
+    return 0;
+}
+
+/* `vae.encode(image).latent_dist.sample() * scaling_factor` in fp32 (dift.py:187; the featuriser's pipeline is fp32, dift.py:197-199):
+ * image_dev [batch,3,H,W] fp32 in [-1,1]; noise_dev [batch*draws,4,H/8,W/8] fp32 N(0,1) draws or NULL (posterior mode);
+ * latent_dev [batch*draws,4,H/8,W/8] fp32 and / or moments_dev [batch,8,H/8,W/8] fp32 */
+int dm_f32_vae_encode(dm_f32_net* e, const void* image_dev, const void* noise_dev, int batch, int draws_per_image, int H, int W,
+                      float scaling_factor, void* latent_dev, void* moments_dev, void* stream) {
+    if (!e || !image_dev || (!latent_dev && !moments_dev)) return 1;
+    if (!e->vae_ready) F_FAIL(e, "no VAE weights (dm_f32_load_vae_weight / dm_f32_finalize_vae)");
+    if (batch <= 0 || H < 8 || W < 8 || draws_per_image < 1) F_FAIL(e, "bad batch / image size");
+    F_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int h = H / 8, w = W / 8;
+    const long long area = (long long)H * W;
+    long long chunk = 8LL * 512 * 512 / area;                 // ~0.6 GB of fp32 activations per 512 x 512 image
+    chunk = chunk < 1 ? 1 : chunk;
+    for (int b0 = 0; b0 < batch; b0 += (int)chunk) {
+        VaeArgs32 A;
+        A.B = batch - b0 < chunk ? batch - b0 : (int)chunk; A.draws = draws_per_image; A.H = H; A.W = W; A.scaling = scaling_factor;
+        A.image = (const float*)image_dev + (size_t)b0 * 3 * H * W;
+        A.noise = noise_dev ? (const float*)noise_dev + (size_t)b0 * draws_per_image * 4 * h * w : nullptr;
+        A.latent = latent_dev ? (float*)latent_dev + (size_t)b0 * draws_per_image * 4 * h * w : nullptr;
+        A.moments = moments_dev ? (float*)moments_dev + (size_t)b0 * 8 * h * w : nullptr;
+        F_TRY(ensure_arena_for32(e, s, [&]() { return run_vae32(e, A, s, true); }));
+        F_TRY(run_vae32(e, A, s, false));
+    }
+    return 0;
+}
+
 int dm_f32_prof_enable(dm_f32_net* e, int on) {
     if (!e) return 1;
     e->prof = on != 0;
@@ -624,7 +826,7 @@ int dm_f32_prof_read(dm_f32_net* e, double* gemm_ms, double* gemm_flops, int64_t
 
 int dm_f32_memory(dm_f32_net* e, size_t* weights_bytes, size_t* arena_bytes) {
     if (!e) return 1;
-    if (weights_bytes) *weights_bytes = e->slab_floats * sizeof(float);
+    if (weights_bytes) *weights_bytes = (e->slab_floats + e->vslab_floats) * sizeof(float);
     if (arena_bytes) *arena_bytes = e->arena_cap;
     return 0;
 }

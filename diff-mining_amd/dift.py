@@ -147,10 +147,13 @@ class SDFeaturizer:
         _, _, H, W = img.shape
         if vae_noise is None:
             vae_noise = torch.randn(ensemble_size, 4, H // 8, W // 8, generator=generator, dtype=torch.float32)
-        if self.aux is None:
-            raise ValueError("an image input needs the VAE encoder: SDFeaturizer(f32_net, aux=fp16_engine_with_vae_weights)")
-        lat = self.aux.vae_encode(img, vae_noise.to(torch.float16), out_dtype=torch.float32,
-                                  draws_per_image=ensemble_size)
+        if self.dtype == torch.float32 and getattr(self.engine, "_vae_ready", False):
+            # the reference's arithmetic end to end: fp32 VAE encoder (dift.py:187 on the fp32 pipeline of dift.py:197-199)
+            lat = self.engine.vae_encode(img, vae_noise, draws_per_image=ensemble_size)
+        elif self.aux is not None:
+            lat = self.aux.vae_encode(img, vae_noise.to(torch.float16), out_dtype=torch.float32, draws_per_image=ensemble_size)
+        else:
+            raise ValueError("an image input needs VAE weights: f32_net.load_vae_state_dict(...) or SDFeaturizer(f32_net, aux=fp16_engine)")
         return self.forward(lat, prompt_embeds, t, up_ft_index, ensemble_size, noise=noise, generator=generator)
 
     # -- Cluster.compute_embeddings' DIFT branch (cluster.py:288-299) ------------------------------

@@ -29,7 +29,8 @@ SYMBOLS = [
     "dm_engine_reserve", "dm_engine_stats", "dm_op_groupnorm_conv1x1", "dm_op_igemm_shortcut", "dm_normalize_map",
     "dm_f32_create", "dm_f32_destroy", "dm_f32_last_error", "dm_f32_load_weight", "dm_f32_finalize", "dm_f32_set_prompts",
     "dm_f32_unet_forward", "dm_f32_dift", "dm_f32_prof_enable", "dm_f32_prof_read", "dm_f32_memory", "dm_f32_op_gemm",
-    "dm_f32_op_attention", "dm_f32_op_groupnorm", "dm_f32_op_layernorm",
+    "dm_f32_op_attention", "dm_f32_op_groupnorm", "dm_f32_op_layernorm", "dm_f32_load_vae_weight", "dm_f32_finalize_vae",
+    "dm_f32_vae_encode",
 ]
 
 
@@ -120,6 +121,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         lib.dm_f32_op_attention.argtypes = [vp] * 5 + [i32] * 4 + [i64] * 4 + [vp] + [i32] * 6 + [C.c_float]
         lib.dm_f32_op_groupnorm.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, C.c_float, vp, vp, i32, vp, vp]
         lib.dm_f32_op_layernorm.argtypes = [vp, vp, i32, i32, vp, vp, C.c_float, vp]
+        lib.dm_f32_load_vae_weight.argtypes = [vp, C.c_char_p, vp, i32, C.POINTER(i64), i32]
+        lib.dm_f32_finalize_vae.argtypes = [vp]
+        lib.dm_f32_vae_encode.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.c_float, vp, vp, vp]
     if path is None:
         _lib = lib
     return lib
@@ -588,6 +592,31 @@ class UNetEngineF32:
     def load_safetensors(self, path: str):
         from safetensors.numpy import load_file
         self.load_state_dict(load_file(path))
+
+    def load_vae_state_dict(self, sd: Dict[str, "np.ndarray"]):
+        """sd: `AutoencoderKL.state_dict()` (`pipe.vae`); only `encoder.*` and `quant_conv.*` are used.  Optional."""
+        UNetEngine._load(self, self.lib.dm_f32_load_vae_weight, sd, "f32_load_vae_weight")
+        self._check(self.lib.dm_f32_finalize_vae(self._h), "f32_finalize_vae")
+        self._vae_ready = True
+
+    def vae_encode(self, image, noise=None, scaling_factor: float = 0.18215, return_moments=False, draws_per_image: int = 1):
+        """`vae.encode(image).latent_dist.sample() * scaling_factor` in fp32 (dift.py:187) with the N(0,1) draw injected (`noise`
+        [B*D,4,H/8,W/8]; None -> posterior mode).  image [B,3,H,W] in [-1,1].  Returns latents [B*D,4,H/8,W/8] fp32 [, moments
+        fp32 [B,8,H/8,W/8]]; the encoder runs once per image whatever D is."""
+        torch = self._torch
+        image = image.to(self.device, torch.float32).contiguous()
+        B, c, H, W = image.shape
+        assert c == 3 and H >= 8 and W >= 8, image.shape
+        h, w = H // 8, W // 8
+        if noise is not None:
+            noise = noise.to(self.device, torch.float32).contiguous()
+            assert noise.shape == (B * draws_per_image, 4, h, w), noise.shape
+        lat = torch.empty(B * draws_per_image, 4, h, w, dtype=torch.float32, device=self.device)
+        mom = torch.empty(B, 8, h, w, dtype=torch.float32, device=self.device) if return_moments else None
+        self._check(self.lib.dm_f32_vae_encode(self._h, C.c_void_p(image.data_ptr()), C.c_void_p(noise.data_ptr()) if noise is not None else None,
+                                               B, int(draws_per_image), H, W, float(scaling_factor), C.c_void_p(lat.data_ptr()),
+                                               C.c_void_p(mom.data_ptr()) if mom is not None else None, self._stream()), "dm_f32_vae_encode")
+        return (lat, mom) if return_moments else lat
 
     def set_prompts(self, ctx):
         """ctx [P,77,768] (`prompt_embeds`, dift.py:222-227), kept in fp32."""

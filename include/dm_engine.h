@@ -333,6 +333,14 @@ int dm_f32_unet_forward(dm_f32_net* e, const void* sample_dev, const int64_t* t_
                         int h, int w, void* out_dev, void* stream);
 int dm_f32_dift(dm_f32_net* e, const void* noisy_dev, const int64_t* t_dev, const int32_t* slot_dev, int batch, int h, int w,
                 int up_ft_index, void* feat_out_dev, void* mean_out_dev, int ensemble, void* stream);
+/* optional AutoencoderKL encoder in fp32: `pipe.vae.encode(img_tensor).latent_dist.sample() * scaling_factor` of the featuriser
+ * (dift.py:187) — image_dev [batch,3,H,W] fp32 in [-1,1]; noise_dev [batch*draws_per_image,4,H/8,W/8] fp32 N(0,1) draws or NULL
+ * (posterior mode); latent_dev [batch*draws_per_image,4,H/8,W/8] fp32 and / or moments_dev [batch,8,H/8,W/8] fp32 (either may be
+ * NULL).  State-dict names as dm_engine_load_vae_weight (decoder tensors ignored, legacy attention names accepted). */
+int dm_f32_load_vae_weight(dm_f32_net* e, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim);
+int dm_f32_finalize_vae(dm_f32_net* e);
+int dm_f32_vae_encode(dm_f32_net* e, const void* image_dev, const void* noise_dev, int batch, int draws_per_image, int H, int W,
+                      float scaling_factor, void* latent_dev, void* moments_dev, void* stream);
 int dm_f32_prof_enable(dm_f32_net* e, int on);
 int dm_f32_prof_read(dm_f32_net* e, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches, double* attn_ms,
                      double* attn_flops, int64_t* attn_launches);

@@ -295,3 +295,50 @@ def test_fp16_engine_vs_fp32_ground_truth_at_the_baseline_configuration(net32, s
     e16.close()
     assert worst[0] < 1.5 * 1.23e-3                                   # TOL_LOSS of test_gpu_e2e.py
     assert worst[2] <= 1.5 * floor["max_dT_over_mean_loss"] * 1.5     # T10 bound of test_gpu_e2e.py; x 1.5: the grid is fp16-rounded, the truth is not
+
+
+@pytest.fixture(scope="module")
+def vae_sd():
+    return synth.synth_vae_state_dict(seed=0, dtype=np.float16)
+
+
+@pytest.mark.parametrize("B,H,W,draws", [(2, 64, 64, 1), (1, 100, 68, 3), (1, 85, 131, 1)])
+def test_vae32_vs_fp32_oracle(net32, vae_sd, B, H, W, draws):
+    """`vae.encode(img).latent_dist.sample() * scaling_factor` of the featuriser's fp32 pipeline (dift.py:187,197-199), incl. image
+    sizes that are not multiples of 8, against the VAE oracle in fp32 mode."""
+    from oracle import vae_ref as V
+    if not getattr(net32, "_vae_ready", False):
+        net32.load_vae_state_dict(vae_sd)
+    sdt = {k: torch.from_numpy(v).float() for k, v in vae_sd.items()}
+    img = torch.from_numpy(synth.synth_image(B, H, W)).float()
+    noise = _randn(B * draws, 4, H // 8, W // 8, seed=9)
+    lat, mom = net32.vae_encode(img, noise, return_moments=True, draws_per_image=draws)
+    m_ref = V.vae_moments(sdt, img, autocast=False)
+    l_ref = V.posterior_sample(m_ref.repeat_interleave(draws, 0), noise)
+    rm, rl = U.rel_l2(mom.cpu(), m_ref), U.rel_l2(lat.cpu(), l_ref)
+    mode = net32.vae_encode(img, None).cpu()
+    print(f"vae32 {B}x{H}x{W} draws {draws}: moments rel-L2 {rm:.2e}, latents {rl:.2e}")
+    assert mom.shape == m_ref.shape and lat.shape == l_ref.shape and rm < TOL_E2E and rl < TOL_E2E
+    assert U.rel_l2(mode, V.posterior_sample(m_ref, None)) < TOL_E2E
+
+
+def test_sdfeaturizer_from_pixels_in_fp32(net32, vae_sd, sd15_weights_torch):
+    """SDFeaturizer.forward(img_tensor, prompt_embeds, t=261, up_ft_index=1, ensemble_size) from PIXELS, every stage in the
+    reference's fp32: VAE encode -> ensemble of posterior samples -> add_noise -> U-Net tap -> ensemble mean (dift.py:214-232,173-193)."""
+    from diff_mining_amd.dift import SDFeaturizer
+    from oracle import vae_ref as V
+    if not getattr(net32, "_vae_ready", False):
+        net32.load_vae_state_dict(vae_sd)
+    H = W = 128
+    ens = 2
+    img = torch.from_numpy(synth.synth_image(1, H, W)).float()
+    pe = torch.from_numpy(synth.synth_inputs(1, 1, 8, 8)[3][:1]).float()
+    vn, n = _randn(ens, 4, H // 8, W // 8, seed=11), _randn(ens, 4, H // 8, W // 8, seed=12)
+    out = SDFeaturizer(net32).forward(img, pe, t=261, up_ft_index=1, ensemble_size=ens, noise=n, vae_noise=vn)
+    sdv = {k: torch.from_numpy(v).float() for k, v in vae_sd.items()}
+    lat = V.posterior_sample(V.vae_moments(sdv, img, autocast=False).repeat_interleave(ens, 0), vn)
+    noisy = R.add_noise(lat, n, torch.tensor(261), R.alphas_cumprod())
+    _, mean_ref = R.dift_features(sd15_weights_torch, noisy, 261, pe.expand(ens, -1, -1), 1)
+    r = U.rel_l2(out.cpu(), mean_ref)
+    print(f"SDFeaturizer from pixels, fp32 end to end: rel-L2 vs the fp32 oracles {r:.2e}")
+    assert out.shape == mean_ref.shape and r < TOL_E2E
