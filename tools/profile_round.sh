@@ -29,6 +29,14 @@ python tools/pmc_shapes.py parse $OUT/pmcs_fetch $OUT/pmcs_write > $OUT/pmc_shap
 rm -rf $OUT/pmcs_fetch $OUT/pmcs_write
 # the side workloads (BASELINE configs[3], [4]) with the same keys as the graded line, and the cost of the live events
 for w in dift xray; do python bench.py --workload $w --steps 5 --warmup 2 >> $OUT/side_workloads.jsonl 2>> $OUT/bench.err; done
+python bench.py --workload dift --dift-dtype f16 --steps 5 --warmup 2 --no-cpu-baseline >> $OUT/side_workloads.jsonl 2>> $OUT/bench.err
+# configs[3] in the reference's fp32 (the fp32 net): per-shape table and rocprofv3 kernel stats of the same command
+DM_PROF_DUMP=$OUT/dift32_raw.txt python bench.py --workload dift --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python tools/prof_shapes.py $OUT/dift32_raw.txt 3 157.3e12 > $OUT/dift_f32_shapes.txt; rm -f $OUT/dift32_raw.txt
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats32 -o stats -- python bench.py --workload dift --steps 5 --warmup 2 --no-cpu-baseline \
+    > $OUT/dift_f32_bench_under_rocprof.json 2>> $OUT/rocprof.err
+find $OUT/stats32 -name '*kernel_stats.csv' -exec cp {} $OUT/dift_f32_kernel_stats.csv \; ; rm -rf $OUT/stats32
+python tools/t_deviation_gpu.py 16 > $OUT/T_deviation_baseline_size_fp32.txt 2>> $OUT/bench.err
 for w in vae pixels; do python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline >> $OUT/side_workloads.jsonl 2>> $OUT/bench.err; done
 DM_BENCH_NOPROF=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_noprof.json 2>> $OUT/bench.err
 find $OUT/stats -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
