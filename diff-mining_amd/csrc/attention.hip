@@ -343,7 +343,7 @@ hipError_t launch_t(const AttnParams& p, hipStream_t s) {
     if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute((const void*)attn_kernel<D, QF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    hipLaunchKernelGGL((attn_kernel<D, QF>), grid, block, lds, s, p);
+    launch_timed((attn_kernel<D, QF>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 

@@ -258,7 +258,7 @@ hipError_t launch_cross_t(const AttnParams& p, hipStream_t s) {
     const long long units = (long long)p.B * nsplit;
     dim3 grid((unsigned)(((units + 7) / 8) * 8 * p.heads)), block(NT);
     constexpr size_t lds = XGeo<D>::LDS;
-    hipLaunchKernelGGL(attn_cross_kernel<D>, grid, block, lds, s, p, nsplit);
+    launch_timed(attn_cross_kernel<D>, grid, block, lds, s, p, nsplit);
     return hipGetLastError();
 }
 

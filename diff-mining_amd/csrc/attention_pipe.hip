@@ -372,7 +372,7 @@ hipError_t launch_attention_pipe(const AttnParams& p, hipStream_t s) {
     constexpr int QBLK = 64 * QF;
     dim3 grid(((p.Tq + QBLK - 1) / QBLK) * p.heads * p.B), block(NT);
     const size_t lds = NSTG * (size_t)STAGE;
-    hipLaunchKernelGGL(attn_pipe_kernel, grid, block, lds, s, p);
+    launch_timed(attn_pipe_kernel, grid, block, lds, s, p);
     return hipGetLastError();
 }
 

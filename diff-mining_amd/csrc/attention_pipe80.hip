@@ -455,8 +455,8 @@ hipError_t launch_attention_pipe80(const AttnParams& p, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)attn_pipe80_kernel<80, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo<80, 1>::LDS);
     }
     constexpr size_t lds0 = Geo<80, 0>::LDS, lds1 = Geo<80, 1>::LDS;
-    if (option(OPT_ATTN_PIPE) == 3) hipLaunchKernelGGL((attn_pipe80_kernel<80, 1>), grid, block, lds1, s, p);   // A/B: rows with constant chunks
-    else hipLaunchKernelGGL((attn_pipe80_kernel<80, 0>), grid, block, lds0, s, p);
+    if (option(OPT_ATTN_PIPE) == 3) launch_timed((attn_pipe80_kernel<80, 1>), grid, block, lds1, s, p);   // A/B: rows with constant chunks
+    else launch_timed((attn_pipe80_kernel<80, 0>), grid, block, lds0, s, p);
     return hipGetLastError();
 }
 

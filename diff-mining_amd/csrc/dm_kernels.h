@@ -2,9 +2,11 @@
 // The public boundary is include/dm_engine.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <atomic>
+#include <vector>
 
 namespace dm {
 
@@ -30,6 +32,30 @@ inline int device_cu_count() {
         n_cu[dev & 63].store(v, std::memory_order_relaxed);
     }
     return v;
+}
+
+// Per-dispatch timing for bench.py's live roofline (dm_prof_enable).  While a LaunchTimer is installed on the calling thread, every
+// dispatch of the igemm / attention launchers goes out through hipExtLaunchKernelGGL with its own (start, stop) event pair — the
+// timestamps of the dispatch's own completion signal — instead of being bracketed by hipEventRecord calls, each of which is an extra
+// barrier packet in the queue (r04: the bracketing cost 1.7 ms per 140 ms step).  The pairs of one launch_* call are
+// collected in `pairs`; its duration is the sum of its dispatches' kernel times.  Events come from / return to the engine's pool.
+struct LaunchTimer {
+    std::vector<hipEvent_t>* pool;
+    std::vector<hipEvent_t> pairs;      // start, stop, start, stop, ...
+    hipError_t err = hipSuccess;
+};
+extern thread_local LaunchTimer* g_launch_timer;          // engine.hip
+template <typename F, typename... Args>
+inline void launch_timed(F kernel, const dim3& grid, const dim3& block, size_t lds, hipStream_t s, Args... args) {
+    LaunchTimer* t = g_launch_timer;
+    if (!t) { hipLaunchKernelGGL(kernel, grid, block, lds, s, args...); return; }
+    hipEvent_t ev[2];
+    for (hipEvent_t& h : ev) {
+        if (!t->pool->empty()) { h = t->pool->back(); t->pool->pop_back(); }
+        else { const hipError_t r = hipEventCreate(&h); if (r != hipSuccess) { t->err = r; hipLaunchKernelGGL(kernel, grid, block, lds, s, args...); return; } }
+    }
+    hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, s, ev[0], ev[1], 0, args...);
+    t->pairs.push_back(ev[0]); t->pairs.push_back(ev[1]);
 }
 
 // Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of

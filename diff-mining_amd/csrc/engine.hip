@@ -24,6 +24,9 @@ using namespace dm;
 namespace {
 
 thread_local std::string g_create_error;
+}
+namespace dm { thread_local LaunchTimer* g_launch_timer = nullptr; }
+namespace {
 
 // ------------------------------------------------------------------------------------------------
 // architecture constants (public SDv1.5 unet/config.json)
@@ -95,7 +98,7 @@ struct Tensor {            // NHWC activation in the arena
     long long rows() const { return (long long)N * H * W; }
 };
 
-struct ProfEv { hipEvent_t a, b; double flops; int kind; int M = 0, N = 0, K = 0, mode = 0; };
+struct ProfEv { std::vector<hipEvent_t> pairs; double flops; int kind; int M = 0, N = 0, K = 0, mode = 0; };      // (start, stop) per dispatch
 
 }  // namespace
 
@@ -498,20 +501,23 @@ struct Fwd {
     void free(Tensor& t) { if (!t.view && t.off != (size_t)-1) { e->arena.release(t.off); t.off = (size_t)-1; t.p = nullptr; } }
     void free_raw(size_t off) { e->arena.release(off); }
 
+    // live roofline events (dm_prof_enable): the launchers' dispatches between prof_begin and prof_end carry their own (start, stop)
+    // event pairs (dm::launch_timed) — no hipEventRecord barrier packets between the kernels
+    LaunchTimer timer;
+    ~Fwd() { if (g_launch_timer == &timer) g_launch_timer = nullptr; }       // an error return between begin and end must not leave it installed
     int prof_begin(int kind, double flops, int M = 0, int N = 0, int K = 0, int mode = 0) {
         if (!e->prof || dry) return 0;
         ProfEv ev; ev.flops = flops; ev.kind = kind; ev.M = M; ev.N = N; ev.K = K; ev.mode = mode;
-        for (hipEvent_t* h : {&ev.a, &ev.b}) {
-            if (!e->ev_pool.empty()) { *h = e->ev_pool.back(); e->ev_pool.pop_back(); }
-            else DM_HIP(e, hipEventCreate(h));
-        }
-        DM_HIP(e, hipEventRecord(ev.a, s));
-        e->prof_ev.push_back(ev);
+        e->prof_ev.push_back(std::move(ev));
+        timer.pool = &e->ev_pool; timer.pairs.clear(); timer.err = hipSuccess;
+        g_launch_timer = &timer;
         return 0;
     }
     int prof_end() {
         if (!e->prof || dry) return 0;
-        DM_HIP(e, hipEventRecord(e->prof_ev.back().b, s));
+        g_launch_timer = nullptr;
+        e->prof_ev.back().pairs.swap(timer.pairs);
+        DM_HIP(e, timer.err);
         return 0;
     }
 
@@ -1236,7 +1242,7 @@ void dm_engine_destroy(dm_engine* e) {
     if (e->sb32_tab) (void)hipFree(e->sb32_tab);
     for (auto p : e->kv_cache) if (p) (void)hipFree(p);
     for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
-    for (auto& ev : e->prof_ev) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto& ev : e->prof_ev) for (hipEvent_t h : ev.pairs) (void)hipEventDestroy(h);
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     delete e;
 }
@@ -1877,10 +1883,14 @@ int dm_prof_read(dm_engine* e, double* igemm_ms, double* igemm_flops, int64_t* i
     if (const char* dp = getenv("DM_PROF_DUMP")) dump = fopen(dp, "a");
     for (auto& ev : e->prof_ev) {
         float ms = 0.f;
-        DM_HIP(e, hipEventElapsedTime(&ms, ev.a, ev.b));
+        for (size_t i = 0; i + 1 < ev.pairs.size(); i += 2) {          // a launch = the sum of its dispatches' kernel times
+            float d = 0.f;
+            DM_HIP(e, hipEventElapsedTime(&d, ev.pairs[i], ev.pairs[i + 1]));
+            ms += d;
+        }
         if (dump) fprintf(dump, "%d %d %d %d %d %.0f %.6f\n", ev.kind, ev.M, ev.N, ev.K, ev.mode, ev.flops, ms);
         e->prof_ms[ev.kind] += ms; e->prof_flops[ev.kind] += ev.flops; e->prof_n[ev.kind] += 1;
-        e->ev_pool.push_back(ev.a); e->ev_pool.push_back(ev.b);
+        for (hipEvent_t h : ev.pairs) e->ev_pool.push_back(h);
     }
     if (dump) fclose(dump);
     e->prof_ev.clear();

@@ -666,12 +666,12 @@ static hipError_t launch_igemm_pers_t(const IGemmParams& p, hipStream_t s) {
     static std::atomic<unsigned> launch_no{0};
     const int cset = (int)(launch_no.fetch_add(1) % CSETS);
     const dim3 g(grid), b(512);
-    if (p.epi == EPI_GEGLU) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_GEGLU, LN, PX_NONE>), g, b, lds, s, with_zero_page(p), ntiles, cset); return hipGetLastError(); }
+    if (p.epi == EPI_GEGLU) { launch_timed((igemm_pers_kernel<EPI_GEGLU, LN, PX_NONE>), g, b, lds, s, with_zero_page(p), ntiles, cset); return hipGetLastError(); }
     if constexpr (!LN) {        // the folded-LayerNorm layers never carry a time embedding or a residual (igemm_pers_ok)
-        if (p.temb) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_TEMB>), g, b, lds, s, with_zero_page(p), ntiles, cset); return hipGetLastError(); }
-        if (p.res) { hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_RES>), g, b, lds, s, with_zero_page(p), ntiles, cset); return hipGetLastError(); }
+        if (p.temb) { launch_timed((igemm_pers_kernel<EPI_PLAIN, false, PX_TEMB>), g, b, lds, s, with_zero_page(p), ntiles, cset); return hipGetLastError(); }
+        if (p.res) { launch_timed((igemm_pers_kernel<EPI_PLAIN, false, PX_RES>), g, b, lds, s, with_zero_page(p), ntiles, cset); return hipGetLastError(); }
     }
-    hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, LN, PX_NONE>), g, b, lds, s, with_zero_page(p), ntiles, cset);
+    launch_timed((igemm_pers_kernel<EPI_PLAIN, LN, PX_NONE>), g, b, lds, s, with_zero_page(p), ntiles, cset);
     return hipGetLastError();
 }
 
@@ -692,8 +692,8 @@ static hipError_t launch_igemm_pers_sc_t(const IGemmParams& p, hipStream_t s) {
     }
     static std::atomic<unsigned> launch_no{0};
     const int cset = (int)(launch_no.fetch_add(1) % CSETS);
-    if (p.res) hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_RES, false, true>), dim3(grid), dim3(512), lds, s, with_zero_page(p), ntiles, cset);
-    else hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, false, PX_NONE, false, true>), dim3(grid), dim3(512), lds, s, with_zero_page(p), ntiles, cset);
+    if (p.res) launch_timed((igemm_pers_kernel<EPI_PLAIN, false, PX_RES, false, true>), dim3(grid), dim3(512), lds, s, with_zero_page(p), ntiles, cset);
+    else launch_timed((igemm_pers_kernel<EPI_PLAIN, false, PX_NONE, false, true>), dim3(grid), dim3(512), lds, s, with_zero_page(p), ntiles, cset);
     return hipGetLastError();
 }
 #endif
@@ -713,7 +713,7 @@ static hipError_t launch_igemm_pers_ws_t(const IGemmParams& p, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, true, PX_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     static std::atomic<unsigned> launch_no{0};
     const int cset = (int)(launch_no.fetch_add(1) % CSETS);
-    hipLaunchKernelGGL((igemm_pers_kernel<EPI_PLAIN, true, PX_NONE, true>), dim3(grid), dim3(512), lds, s, with_zero_page(p), ntiles, cset);
+    launch_timed((igemm_pers_kernel<EPI_PLAIN, true, PX_NONE, true>), dim3(grid), dim3(512), lds, s, with_zero_page(p), ntiles, cset);
     return hipGetLastError();
 }
 #endif
@@ -730,7 +730,7 @@ static hipError_t launch_igemm_pers_partial_t(const IGemmParams& p, hipStream_t 
         (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PARTIAL, false, PX_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     static std::atomic<unsigned> launch_no{0};
     const int cset = (int)(launch_no.fetch_add(1) % CSETS);
-    hipLaunchKernelGGL((igemm_pers_kernel<EPI_PARTIAL, false, PX_NONE>), dim3(grid), dim3(512), lds, s, with_zero_page(p), units, cset);
+    launch_timed((igemm_pers_kernel<EPI_PARTIAL, false, PX_NONE>), dim3(grid), dim3(512), lds, s, with_zero_page(p), units, cset);
     return hipGetLastError();
 }
 

@@ -490,7 +490,7 @@ static hipError_t launch_tr_up64(const IGemmParams& p, hipStream_t s) {      // 
         (void)hipFuncSetAttribute((const void*)igemm_pers_tr_kernel<PX_NONE, 64, U, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     static std::atomic<unsigned> launch_no{0};
     const int cset = (int)(launch_no.fetch_add(1) % CSETS);
-    hipLaunchKernelGGL((igemm_pers_tr_kernel<PX_NONE, 64, U, true>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), lds, s, with_zero_page(p), ntiles, cset);
+    launch_timed((igemm_pers_tr_kernel<PX_NONE, 64, U, true>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), lds, s, with_zero_page(p), ntiles, cset);
     return hipGetLastError();
 }
 
@@ -498,7 +498,7 @@ template <int EXTRA, int WIMG>
 static void launch_tr_k(const IGemmParams& p, int ntiles, int cset, dim3 g, size_t lds, hipStream_t s, bool set_attr) {
     constexpr bool U = TrUnroll<EXTRA, WIMG>::value;
     if (set_attr) (void)hipFuncSetAttribute((const void*)igemm_pers_tr_kernel<EXTRA, WIMG, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    else hipLaunchKernelGGL((igemm_pers_tr_kernel<EXTRA, WIMG, U>), g, dim3(512), lds, s, with_zero_page(p), ntiles, cset);
+    else launch_timed((igemm_pers_tr_kernel<EXTRA, WIMG, U>), g, dim3(512), lds, s, with_zero_page(p), ntiles, cset);
 }
 
 template <int WIMG>

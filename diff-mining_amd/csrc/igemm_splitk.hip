@@ -60,7 +60,7 @@ hipError_t launch_igemm_splitk(const IGemmParams& p, hipStream_t s) {
     if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_PLAIN, NI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    hipLaunchKernelGGL((igemm_kernel<WC, EPI_PLAIN, NI, true>), dim3(tiles * p.ksplit), dim3(128 * WC), lds, s, p);
+    launch_timed((igemm_kernel<WC, EPI_PLAIN, NI, true>), dim3(tiles * p.ksplit), dim3(128 * WC), lds, s, p);
     return launch_splitk_reduce(p, s);
 }
 
@@ -68,7 +68,7 @@ hipError_t launch_igemm_splitk(const IGemmParams& p, hipStream_t s) {
 hipError_t launch_splitk_reduce(const IGemmParams& p, hipStream_t s) {
     const long long MN = (long long)p.M * p.Cout;
     const int OHW = p.OH * p.OW;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, p.partial, p.ksplit, MN, p.M,
+    launch_timed(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, p.partial, p.ksplit, MN, p.M,
                        p.Cout, OHW > 0 ? OHW : 1, p.bias, p.temb, p.temb_ld, p.res, p.ldres, p.Y, p.ldy);
     return hipGetLastError();
 }

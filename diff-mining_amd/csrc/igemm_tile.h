@@ -498,9 +498,9 @@ static hipError_t launch_t(const IGemmParams& p, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)igemm_kernel<WC, EPI_GEGLU, NI, false, LN, WS, SC, KO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     if (p.epi == EPI_GEGLU)
-        hipLaunchKernelGGL((igemm_kernel<WC, EPI_GEGLU, NI, false, LN, WS, SC, KO>), grid, block, lds, s, p);
+        launch_timed((igemm_kernel<WC, EPI_GEGLU, NI, false, LN, WS, SC, KO>), grid, block, lds, s, p);
     else
-        hipLaunchKernelGGL((igemm_kernel<WC, EPI_PLAIN, NI, false, LN, WS, SC, KO>), grid, block, lds, s, p);
+        launch_timed((igemm_kernel<WC, EPI_PLAIN, NI, false, LN, WS, SC, KO>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 

@@ -255,7 +255,7 @@ hipError_t launch_attention512(const f16* Q, const f16* K, const f16* V, f16* O,
     if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute((const void*)attn512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN512_LDS);
     }
-    hipLaunchKernelGGL(attn512_kernel, dim3((T + AQ - 1) / AQ, B), dim3(256), ATTN512_LDS, s, Q, K, V, O, T, ld, ldo, scale);
+    launch_timed(attn512_kernel, dim3((T + AQ - 1) / AQ, B), dim3(256), ATTN512_LDS, s, Q, K, V, O, T, ld, ldo, scale);
     return hipGetLastError();
 }
 
