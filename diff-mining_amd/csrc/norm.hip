@@ -159,7 +159,7 @@ __global__ void gn_apply_kernel(const f16* __restrict__ X, const f16* __restrict
 __global__ __launch_bounds__(384, 4)
 void gn_fused_kernel(const f16* __restrict__ X, const f16* __restrict__ X2, int HW, int C, int C1, int G, int R, int GN_PIX,
                      double* __restrict__ partial, double* __restrict__ stats, int* __restrict__ ctr, double count, float eps,
-                     const float* __restrict__ gamma, const float* __restrict__ beta, int silu, f16* __restrict__ Y, int* __restrict__ err) {
+                     const float* __restrict__ gamma, const float* __restrict__ beta, int silu, f16* __restrict__ Y, int* __restrict__ err, int dbg) {
     extern __shared__ float sh[];               // [R][2][C] (as gn_stats_partial)
     __shared__ double sh_part[2 * 384];
     __shared__ int sh_last;
@@ -195,6 +195,10 @@ void gn_fused_kernel(const f16* __restrict__ X, const f16* __restrict__ X2, int 
         }
     }
     __syncthreads();
+    // Everything blocks exchange goes through agent-scope RELAXED atomics (sc1 loads / stores: coherent across the eight XCD L2s by
+    // themselves) ordered by s_waitcnt — NOT through release / acquire fences: on gfx950 an agent-scope release is a write-back of
+    // the XCD's whole L2 (buffer_wbl2) and an acquire an invalidation of it (buffer_inv sc1); with those the kernel measured
+    // 6x SLOWER than the two-pass pair (r04: a bench step 139 -> 178 ms).
     if (t < G) {
         const int cpg = C / G;
         double ds = 0.0, dq = 0.0;
@@ -204,20 +208,23 @@ void gn_fused_kernel(const f16* __restrict__ X, const f16* __restrict__ X2, int 
                 dq += (double)sh[((size_t)r * 2 + 1) * C + t * cpg + k];
             }
         double* out = partial + (((size_t)n * chunks + chunk) * G + t) * 2;
-        out[0] = ds; out[1] = dq;
-        __threadfence();
+        __hip_atomic_store(&out[0], ds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&out[1], dq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);          // the write-through stores are acknowledged before the block counts itself in
     }
     __syncthreads();
-    if (t == 0) sh_last = __hip_atomic_fetch_add(&ctr[3 * n], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == chunks - 1;
+    if (t == 0) sh_last = dbg ? 1 : (__hip_atomic_fetch_add(&ctr[3 * n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == chunks - 1);
     __syncthreads();
     if (sh_last) {
-        // the sample's last publisher: every chunk's partial sums are visible (acquire above + fence); combine in gn_apply's order
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        // the sample's last publisher: every other chunk was stored before its block's increment; combine in gn_apply's order
         const int S = (int)blockDim.x / G, g = t % G, sl = t / G;
         double ds = 0.0, dq = 0.0;
         if (sl < S) {
-            const double* in = partial + ((size_t)n * chunks * G + g) * 2;
-            for (int k = sl; k < chunks; k += S) { ds += in[(size_t)k * G * 2]; dq += in[(size_t)k * G * 2 + 1]; }
+            double* in = partial + ((size_t)n * chunks * G + g) * 2;
+            for (int k = sl; k < chunks; k += S) {
+                ds += __hip_atomic_load(&in[(size_t)k * G * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dq += __hip_atomic_load(&in[(size_t)k * G * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             sh_part[2 * t] = ds; sh_part[2 * t + 1] = dq;
         }
         __syncthreads();
@@ -227,38 +234,41 @@ void gn_fused_kernel(const f16* __restrict__ X, const f16* __restrict__ X2, int 
             const double mean = ds / count;
             double var = dq / count - mean * mean;
             var = var > 0.0 ? var : 0.0;
-            stats[((size_t)n * G + t) * 2] = mean;
-            stats[((size_t)n * G + t) * 2 + 1] = 1.0 / sqrt(var + (double)eps);
-            __threadfence();
+            __hip_atomic_store(&stats[((size_t)n * G + t) * 2], mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&stats[((size_t)n * G + t) * 2 + 1], 1.0 / sqrt(var + (double)eps), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);
         }
         __syncthreads();
-        if (t == 0) __hip_atomic_store(&ctr[3 * n + 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0 && !dbg) __hip_atomic_store(&ctr[3 * n + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         if (t == 0) {
             int spins = 0;
-            while (__hip_atomic_load(&ctr[3 * n + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            while (__hip_atomic_load(&ctr[3 * n + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                 __builtin_amdgcn_s_sleep(16);
                 if (++spins > (1 << 21)) { *err = 1; break; }
             }
         }
         __syncthreads();
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);     // the statistics were written by another CU: not from a stale L1 line
     }
     const int cpg = C / G;
     float a[8], b[8];
     if (active) {
+        const int g0 = c / cpg, g1 = (c + 7) / cpg;                   // a thread's 8 channels touch at most two groups (cpg >= 10)
+        const double m0 = __hip_atomic_load(&stats[((size_t)n * G + g0) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double r0 = __hip_atomic_load(&stats[((size_t)n * G + g0) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double m1 = __hip_atomic_load(&stats[((size_t)n * G + g1) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double r1 = __hip_atomic_load(&stats[((size_t)n * G + g1) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int g = (c + k) / cpg;
-            const double mean = stats[((size_t)n * G + g) * 2], rstd = stats[((size_t)n * G + g) * 2 + 1];
-            const double ad = rstd * (double)gamma[c + k];
+            const bool hi = (c + k) / cpg != g0;
+            const double ad = (hi ? r1 : r0) * (double)gamma[c + k];
             a[k] = (float)ad;
-            b[k] = (float)((double)beta[c + k] - mean * ad);
+            b[k] = (float)((double)beta[c + k] - (hi ? m1 : m0) * ad);
         }
     }
     __syncthreads();     // every thread of the block has read the statistics
-    if (t == 0) {        // the last block of the sample to get here re-arms its counters
-        const int done = __hip_atomic_fetch_add(&ctr[3 * n + 2], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0 && !dbg) {        // the last block of the sample to get here re-arms its counters
+        const int done = __hip_atomic_fetch_add(&ctr[3 * n + 2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (done == chunks - 1) {
             __hip_atomic_store(&ctr[3 * n], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ctr[3 * n + 1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -552,7 +562,7 @@ hipError_t launch_gn_fused(const f16* X, const f16* X2, int N, int HW, int C, in
     const size_t lds = (size_t)R * C * 2 * sizeof(float);
     double* stats = partial + (size_t)N * chunks * G * 2;          // gn_partial_doubles() leaves room for it
     hipLaunchKernelGGL(gn_fused_kernel, dim3(chunks, N), dim3(threads), lds, s, X, X2 ? X2 : X, HW, C, C1, G, R, pix, partial, stats,
-                       ctr, (double)HW * (double)(C / G), eps, gamma, beta, silu, Y, err);
+                       ctr, (double)HW * (double)(C / G), eps, gamma, beta, silu, Y, err, option(OPT_GN_FUSED) == 2 ? 1 : 0);
     return hipGetLastError();
 }
 size_t gn_partial_doubles(int N, int HW, int C, int G) { return ((size_t)N * gn_stats_chunks(HW, C) * G + (size_t)N * G) * 2; }
