@@ -60,7 +60,7 @@ inline void launch_timed(F kernel, const dim3& grid, const dim3& block, size_t l
 
 // Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of
 // the same name in upper case with a DM_ prefix (DM_IGEMM_PERSIST=0 ...), changeable through dm_set_option().
-enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_TAP_REUSE, OPT_GN_FUSED, OPT_COUNT };
+enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_TAP_REUSE, OPT_COUNT };
 int option(Option o);                       // engine.hip
 int set_option(const char* name, int value);   // 0 on success
 
@@ -182,17 +182,9 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 // then the apply kernel, whose prologue combines them into the per-channel affine y = x * a + b (+ SiLU) — second read, one write.
 hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G,
                            double* partial /* [N][chunks][G][2] */, hipStream_t s);
-int gn_stats_chunks(int HW, int C);
-size_t gn_partial_doubles(int N, int HW, int C, int G);     // workspace of the statistics (both forms)
+int gn_stats_chunks(int HW);
 hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, float eps, const float* gamma,
                            const float* beta, const double* partial, int silu, f16* Y, hipStream_t s);
-// The same GroupNorm (+ SiLU) in ONE pass over HBM (r04, option gn_fused): blocks keep their slab in registers between the statistics
-// and the normalisation and meet through per-sample counters ctr [ctr_samples][3] (zero between launches; an engine owns its own);
-// `partial` must hold gn_partial_doubles(N, HW, C, G) doubles (the per-chunk sums + the per-group statistics);
-// *err is set if a block gave up waiting (bounded).  hipErrorNotSupported: shape outside the kernel's limits -> use the pair above.
-// Bit-identical to launch_gn_stats + launch_gn_apply.
-hipError_t launch_gn_fused(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, float eps, const float* gamma,
-                           const float* beta, double* partial, int* ctr, int ctr_samples, int* err, int silu, f16* Y, hipStream_t s);
 // GroupNorm (no activation) folded into the following 1x1 convolution W [Cout][C], bias [Cout]: from the same partial sums,
 // Wn [N][Cout][C] = fp16(W[o][c] * a[n][c]) and tn [N][Cout] = bias[o] + sum_c W[o][c] * b[n][c]  (fp32), y = x * a + b being the
 // normalisation's per-(sample, channel) affine.  The convolution then runs on the RAW x with per-sample weights: the

@@ -41,7 +41,6 @@ constexpr int GROUPS = 32;
 constexpr int TEMB = 1280;
 constexpr int NTRAIN = 1000;
 constexpr float GN_EPS = 1e-5f, ATTN_GN_EPS = 1e-6f, LN_EPS = 1e-5f;
-constexpr int GN_CTR_SAMPLES = 16384;       // samples per GroupNorm launch the single-pass kernel has counters for (more: two-pass)
 const bool DOWN_ATTN[NB] = {true, true, true, false};
 const bool UP_ATTN[NB] = {false, true, true, true};
 
@@ -148,7 +147,6 @@ struct dm_engine {
     long long n_dry_runs = 0;
     int kv_capacity = 0;                                   // prompts the K/V cache buffers hold
     int* tile_ctr = nullptr;                               // tile hand-out counters of the persistent igemm (this engine's own)
-    int* gn_ctr = nullptr;                                 // single-pass GroupNorm: [GN_CTR_SAMPLES][3] per-sample counters + 1 error flag
     // hipGraph replay of a whole U-Net run (option "graph"): one executable graph per (schedule key, every pointer argument),
     // captured on the second call with that key (the first one sets function attributes and sizes the arena, which a capture
     // cannot contain); dropped when the arena or the K/V cache move
@@ -571,22 +569,14 @@ struct Fwd {
         const int C = x.C + (x2 ? x2->C : 0);
         if (C != nw.c) DM_FAIL(e, "groupnorm: channel mismatch %d vs %d", C, nw.c);
         const int HW = x.H * x.W;
-        const int chunks = gn_stats_chunks(HW, C);
+        const int chunks = gn_stats_chunks(HW);
         size_t poff; void* pp;
-        (void)chunks;
-        DM_TRY(alloc_raw(gn_partial_doubles(x.N, HW, C, GROUPS) * sizeof(double), &poff, &pp));
+        DM_TRY(alloc_raw((size_t)x.N * chunks * GROUPS * 2 * sizeof(double), &poff, &pp));
         DM_TRY(alloc(y, x.N, x.H, x.W, C));
         if (!dry) {
-            // one pass over HBM where the kernel's limits allow (option gn_fused; bit-identical to the pair below)
-            hipError_t r = hipErrorNotSupported;
-            if (option(OPT_GN_FUSED) && e->gn_ctr)
-                r = launch_gn_fused(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, GROUPS, eps, nw.g, nw.b, (double*)pp, e->gn_ctr, GN_CTR_SAMPLES,
-                                    e->gn_ctr + 3 * GN_CTR_SAMPLES, silu ? 1 : 0, y->p, s);
-            if (r == hipErrorNotSupported) {
-                DM_HIP(e, launch_gn_stats(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, GROUPS, (double*)pp, s));
-                DM_HIP(e, launch_gn_apply(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, GROUPS, eps, nw.g, nw.b, (const double*)pp,
-                                          silu ? 1 : 0, y->p, s));
-            } else DM_HIP(e, r);
+            DM_HIP(e, launch_gn_stats(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, GROUPS, (double*)pp, s));
+            DM_HIP(e, launch_gn_apply(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, GROUPS, eps, nw.g, nw.b, (const double*)pp,
+                                      silu ? 1 : 0, y->p, s));
         }
         free_raw(poff);
         return 0;
@@ -603,7 +593,7 @@ struct Fwd {
     }
     int gn_dense(const NormW& nw, const ConvW& cv, const Tensor& x, float eps, Tensor* y) {
         const int C = x.C, HW = x.H * x.W;
-        const int chunks = gn_stats_chunks(HW, C);
+        const int chunks = gn_stats_chunks(HW);
         size_t poff, woff, toff; void *pp, *wp, *tp;
         DM_TRY(alloc_raw((size_t)x.N * chunks * GROUPS * 2 * sizeof(double), &poff, &pp));
         DM_TRY(alloc_raw((size_t)x.N * cv.cout * C * sizeof(f16), &woff, &wp));
@@ -805,7 +795,6 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
     // the persistent igemm kernel leaves its tile hand-out counters at zero — unless a launch faulted or was aborted; a run
     // starts from a known state either way (1 KB, stream-ordered)
     if (!dry && e->tile_ctr) DM_HIP(e, hipMemsetAsync(e->tile_ctr, 0, IGEMM_TILE_CTR_INTS * sizeof(int), s));
-    if (!dry && e->gn_ctr) DM_HIP(e, hipMemsetAsync(e->gn_ctr, 0, 3 * GN_CTR_SAMPLES * sizeof(int), s));      // (the error flag behind them is sticky)
     // ---- time embedding: sinusoid row -> MLP -> SiLU -> all 22 time_emb_proj in one GEMM --------
     Tensor te0, e1, e1s, emb, embs, tprojU, tproj;
     DM_TRY(F.alloc(&te0, 1, 1, U, BOC[0]));
@@ -959,7 +948,6 @@ struct VaeArgs {
 int run_vae(dm_engine* e, const VaeArgs& A, hipStream_t s, bool dry) {
     Fwd F{e, s, dry};
     F.res_eps = VAE_EPS;
-    if (!dry && e->gn_ctr) DM_HIP(e, hipMemsetAsync(e->gn_ctr, 0, 3 * GN_CTR_SAMPLES * sizeof(int), s));
     const VaeW& v = e->vae;
     Tensor cur;
     {
@@ -1096,25 +1084,6 @@ std::vector<long long> fwd_key(const FwdArgs& A) {
             A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD), option(OPT_FF_FOLD)};
 }
 
-// per-sample counters of the single-pass GroupNorm + its error flag: this engine's own, zero between launches
-int ensure_gn_ctr(dm_engine* e) {
-    if (e->gn_ctr) return 0;
-    DM_MALLOC(e, &e->gn_ctr, (3 * GN_CTR_SAMPLES + 1) * sizeof(int));
-    DM_HIP(e, hipMemset(e->gn_ctr, 0, (3 * GN_CTR_SAMPLES + 1) * sizeof(int)));
-    return 0;
-}
-// sticky flag: a single-pass GroupNorm block gave up waiting for its sample's other chunks (results of that run are invalid)
-int check_gn_err(dm_engine* e) {
-    if (!e->gn_ctr) return 0;
-    int flag = 0;
-    DM_HIP(e, hipMemcpy(&flag, e->gn_ctr + 3 * GN_CTR_SAMPLES, sizeof(int), hipMemcpyDeviceToHost));
-    if (flag) {
-        (void)hipMemset(e->gn_ctr, 0, (3 * GN_CTR_SAMPLES + 1) * sizeof(int));
-        DM_FAIL(e, "single-pass GroupNorm: a block gave up waiting for the other chunks of its sample (DM_GN_FUSED=0 selects the two-pass kernels)");
-    }
-    return 0;
-}
-
 int ensure_arena(dm_engine* e, const FwdArgs& A, hipStream_t s) {
     return ensure_arena_for(e, s, fwd_key(A), [&]() { return run_forward(e, A, s, true); });
 }
@@ -1198,7 +1167,7 @@ namespace {
 struct OptDef { const char* name; const char* env; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
-    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1}, {"tap_reuse", "DM_TAP_REUSE", 1}, {"gn_fused", "DM_GN_FUSED", 1},
+    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1}, {"tap_reuse", "DM_TAP_REUSE", 1},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<int> g_opt_init{0};
@@ -1266,7 +1235,6 @@ void dm_engine_destroy(dm_engine* e) {
     if (e->cslab) (void)hipFree(e->cslab);
     if (e->arena_base) (void)hipFree(e->arena_base);
     if (e->tile_ctr) (void)hipFree(e->tile_ctr);
-    if (e->gn_ctr) (void)hipFree(e->gn_ctr);
     if (e->sin_table) (void)hipFree(e->sin_table);
     if (e->sa_tab) (void)hipFree(e->sa_tab);
     if (e->sb_tab) (void)hipFree(e->sb_tab);
@@ -1442,7 +1410,6 @@ int dm_engine_finalize(dm_engine* e) {
     // counter), so two engines / streams on one device never share them; a launch leaves them at zero
     DM_MALLOC(e, &e->tile_ctr, IGEMM_TILE_CTR_INTS * sizeof(int));
     DM_HIP(e, hipMemset(e->tile_ctr, 0, IGEMM_TILE_CTR_INTS * sizeof(int)));
-    DM_TRY(ensure_gn_ctr(e));
     e->finalized = true;
     return 0;
 }
@@ -1550,7 +1517,6 @@ int dm_engine_finalize_vae(dm_engine* e) {
     }
     rebase_res(v.mid[0], base); rebase_res(v.mid[1], base);
     e->host_vae.clear();
-    DM_TRY(ensure_gn_ctr(e));
     e->vae_ready = true;
     return 0;
 }
@@ -1912,7 +1878,6 @@ int dm_prof_read(dm_engine* e, double* igemm_ms, double* igemm_flops, int64_t* i
     if (!e) return 1;
     DM_HIP(e, hipSetDevice(e->device));
     DM_HIP(e, hipDeviceSynchronize());
-    DM_TRY(check_gn_err(e));
     // DM_PROF_DUMP=<file>: append one line per timed launch (kind M N K mode flops ms) for tools/prof_shapes.py
     FILE* dump = nullptr;
     if (const char* dp = getenv("DM_PROF_DUMP")) dump = fopen(dp, "a");
@@ -1941,7 +1906,6 @@ int dm_prof_read(dm_engine* e, double* igemm_ms, double* igemm_flops, int64_t* i
 
 int dm_engine_stats(dm_engine* e, int64_t* device_allocs, int64_t* schedule_dry_runs, int64_t* graph_launches) {
     if (!e) return 1;
-    DM_TRY(check_gn_err(e));
     if (device_allocs) *device_allocs = e->n_device_allocs;
     if (schedule_dry_runs) *schedule_dry_runs = e->n_dry_runs;
     if (graph_launches) *graph_launches = e->n_graph_launches;
@@ -2024,38 +1988,13 @@ int dm_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, 
                     const float* gamma, const float* beta, int silu, void* Y) {
     hipStream_t s = (hipStream_t)stream;
     double* partial = nullptr;
-    const int chunks = gn_stats_chunks(HW, C);
+    const int chunks = gn_stats_chunks(HW);
     if (hipMalloc((void**)&partial, (size_t)N * chunks * G * 2 * sizeof(double)) != hipSuccess) return 1;
     hipError_t r = launch_gn_stats((const f16*)X, (const f16*)X2, N, HW, C, C1, G, partial, s);
     if (r == hipSuccess) r = launch_gn_apply((const f16*)X, (const f16*)X2, N, HW, C, C1, G, eps, gamma, beta, partial, silu, (f16*)Y, s);
     (void)hipStreamSynchronize(s);
     (void)hipFree(partial);
     return r == hipSuccess ? 0 : 1;
-}
-
-/* the single-pass form of the same operator (bit-identical); returns 2 when the shape is outside the kernel's limits, 3 when a block
- * gave up waiting.  Counters of this entry point are allocated per call (parity tests only). */
-int dm_op_groupnorm_fused(void* stream, const void* X, const void* X2, int N, int HW, int C, int C1, int G, float eps,
-                          const float* gamma, const float* beta, int silu, void* Y) {
-    hipStream_t s = (hipStream_t)stream;
-    double* partial = nullptr;
-    int* ctr = nullptr;
-    const int chunks = gn_stats_chunks(HW, C);
-    (void)chunks;
-    if (hipMalloc((void**)&partial, gn_partial_doubles(N, HW, C, G) * sizeof(double)) != hipSuccess) return 1;
-    if (hipMalloc((void**)&ctr, ((size_t)3 * N + 1) * sizeof(int)) != hipSuccess) { (void)hipFree(partial); return 1; }
-    (void)hipMemsetAsync(ctr, 0, ((size_t)3 * N + 1) * sizeof(int), s);
-    const hipError_t r = launch_gn_fused((const f16*)X, (const f16*)X2, N, HW, C, C1, G, eps, gamma, beta, partial, ctr, N, ctr + 3 * N, silu, (f16*)Y, s);
-    (void)hipStreamSynchronize(s);
-    int flag = 0, left = 0;
-    if (r == hipSuccess) {
-        (void)hipMemcpy(&flag, ctr + 3 * N, sizeof(int), hipMemcpyDeviceToHost);
-        std::vector<int> c(3 * (size_t)N);
-        (void)hipMemcpy(c.data(), ctr, c.size() * sizeof(int), hipMemcpyDeviceToHost);
-        for (int v : c) left |= v;               // the kernel re-arms its counters
-    }
-    (void)hipFree(partial); (void)hipFree(ctr);
-    return r == hipErrorNotSupported ? 2 : (r != hipSuccess ? 1 : (flag ? 3 : (left ? 4 : 0)));
 }
 
 int dm_op_igemm_shortcut(void* stream, const void* X, const void* X3, const void* X4, const void* Wp, const void* bias, const void* res,
@@ -2074,7 +2013,7 @@ int dm_op_groupnorm_conv1x1(void* stream, const void* X, int N, int HW, int C, i
                             const float* beta, const void* W, const void* bias, int Cout, void* Y) {
     hipStream_t s = (hipStream_t)stream;
     double* partial = nullptr; f16* wn = nullptr; float* tn = nullptr;
-    const int chunks = gn_stats_chunks(HW, C);
+    const int chunks = gn_stats_chunks(HW);
     if (hipMalloc((void**)&partial, (size_t)N * chunks * G * 2 * sizeof(double)) != hipSuccess) return 1;
     if (hipMalloc((void**)&wn, (size_t)N * Cout * C * sizeof(f16)) != hipSuccess) { (void)hipFree(partial); return 1; }
     if (hipMalloc((void**)&tn, (size_t)N * Cout * sizeof(float)) != hipSuccess) { (void)hipFree(partial); (void)hipFree(wn); return 1; }

@@ -16,7 +16,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int GN_PIX_MAX = 256;     // pixels per stats block (fewer when the image is small)
-constexpr int GNF_PPT = 16;         // single-pass kernel: pixels a thread keeps in registers (16 x 8 channels = 64 VGPRs: three blocks per CU)
 
 // grid (chunks, N); block = (C/8 column threads) x R row groups, <= 320 threads.
 // The channel concat cat([X, X2]) of the up blocks is read in place (never materialised).
@@ -141,153 +140,6 @@ __global__ void gn_apply_kernel(const f16* __restrict__ X, const f16* __restrict
             o[k] = (f16)y;
         }
         *reinterpret_cast<half8*>(Y + pix * C + c) = o;
-    }
-}
-
-
-// GroupNorm in ONE pass over HBM (r04): a block = one statistics chunk (gn_pix pixels x all channels of a sample) keeps its slab in
-// registers — GNF_PPT pixels x 8 channels per thread —, forms the same per-(chunk, group) fp64 partial sums as gn_stats_partial
-// (same per-thread order, same LDS reduction) and publishes them; the block that publishes a sample's LAST chunk combines them
-// exactly as gn_apply_kernel's prologue does (same block size, same slice order) into (mean, rstd) per group and raises the
-// sample's ready flag; every block then normalises from registers: one read + one write of the tensor instead of two reads +
-// one write, bit-identical to the two-pass pair.  The wait is safe because workgroups are dispatched in block-id order on every
-// XCD and the chunks of a sample are consecutive ids: the blocks of the lowest unfinished sample are always resident (<= 128
-// chunks against >= 768 slots), so they finish and free their slots — and it is BOUNDED: a block that does not see the flag
-// within ~0.2 s raises *err and stops waiting (wrong numbers and a sticky error, never a hang).
-// ctr[3n] = chunks published, ctr[3n + 1] = ready flag, ctr[3n + 2] = blocks that have read the statistics; the last of those
-// puts all three back to zero for the next launch.  stats [N][G][2] fp64 sits behind the partial sums.
-__global__ __launch_bounds__(384, 4)
-void gn_fused_kernel(const f16* __restrict__ X, const f16* __restrict__ X2, int HW, int C, int C1, int G, int R, int GN_PIX,
-                     double* __restrict__ partial, double* __restrict__ stats, int* __restrict__ ctr, double count, float eps,
-                     const float* __restrict__ gamma, const float* __restrict__ beta, int silu, f16* __restrict__ Y, int* __restrict__ err, int dbg) {
-    extern __shared__ float sh[];               // [R][2][C] (as gn_stats_partial)
-    __shared__ double sh_part[2 * 384];
-    __shared__ int sh_last;
-    const int cols = C >> 3;
-    const int n = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
-    const int t = threadIdx.x;
-    const int col = t % cols, rg = t / cols;
-    const int px0 = chunk * GN_PIX;
-    const int px1 = min(HW, px0 + GN_PIX);
-    const int c = col * 8;
-    const int C2 = C - C1;
-    const bool active = rg < R;
-    half8 v[GNF_PPT];
-    if (active) {
-        const f16* base = (c < C1) ? (X + (size_t)n * HW * C1 + c) : (X2 + (size_t)n * HW * C2 + (c - C1));
-        const size_t cs = (c < C1) ? (size_t)C1 : (size_t)C2;
-#pragma unroll
-        for (int i = 0; i < GNF_PPT; ++i) {
-            const int px = px0 + rg + i * R;
-            v[i] = (px < px1) ? *reinterpret_cast<const half8*>(base + (size_t)px * cs) : half8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-        float s[8], q[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { s[k] = 0.f; q[k] = 0.f; }
-#pragma unroll
-        for (int i = 0; i < GNF_PPT; ++i)          // px ascending, as gn_stats_partial (a padded pixel adds exact zeros)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { const float f = (float)v[i][k]; s[k] += f; q[k] += f * f; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            sh[((size_t)rg * 2 + 0) * C + c + k] = s[k];
-            sh[((size_t)rg * 2 + 1) * C + c + k] = q[k];
-        }
-    }
-    __syncthreads();
-    // Everything blocks exchange goes through agent-scope RELAXED atomics (sc1 loads / stores: coherent across the eight XCD L2s by
-    // themselves) ordered by s_waitcnt — NOT through release / acquire fences: on gfx950 an agent-scope release is a write-back of
-    // the XCD's whole L2 (buffer_wbl2) and an acquire an invalidation of it (buffer_inv sc1); with those the kernel measured
-    // 6x SLOWER than the two-pass pair (r04: a bench step 139 -> 178 ms).
-    if (t < G) {
-        const int cpg = C / G;
-        double ds = 0.0, dq = 0.0;
-        for (int r = 0; r < R; ++r)
-            for (int k = 0; k < cpg; ++k) {
-                ds += (double)sh[((size_t)r * 2 + 0) * C + t * cpg + k];
-                dq += (double)sh[((size_t)r * 2 + 1) * C + t * cpg + k];
-            }
-        double* out = partial + (((size_t)n * chunks + chunk) * G + t) * 2;
-        __hip_atomic_store(&out[0], ds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&out[1], dq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_waitcnt(0);          // the write-through stores are acknowledged before the block counts itself in
-    }
-    __syncthreads();
-    if (t == 0) sh_last = dbg ? 1 : (__hip_atomic_fetch_add(&ctr[3 * n], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == chunks - 1);
-    __syncthreads();
-    if (sh_last) {
-        // the sample's last publisher: every other chunk was stored before its block's increment; combine in gn_apply's order
-        const int S = (int)blockDim.x / G, g = t % G, sl = t / G;
-        double ds = 0.0, dq = 0.0;
-        if (sl < S) {
-            double* in = partial + ((size_t)n * chunks * G + g) * 2;
-            for (int k = sl; k < chunks; k += S) {
-                ds += __hip_atomic_load(&in[(size_t)k * G * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                dq += __hip_atomic_load(&in[(size_t)k * G * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            sh_part[2 * t] = ds; sh_part[2 * t + 1] = dq;
-        }
-        __syncthreads();
-        if (t < G) {
-            ds = 0.0; dq = 0.0;
-            for (int k = 0; k < S; ++k) { ds += sh_part[2 * (k * G + t)]; dq += sh_part[2 * (k * G + t) + 1]; }
-            const double mean = ds / count;
-            double var = dq / count - mean * mean;
-            var = var > 0.0 ? var : 0.0;
-            __hip_atomic_store(&stats[((size_t)n * G + t) * 2], mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&stats[((size_t)n * G + t) * 2 + 1], 1.0 / sqrt(var + (double)eps), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_s_waitcnt(0);
-        }
-        __syncthreads();
-        if (t == 0 && !dbg) __hip_atomic_store(&ctr[3 * n + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        if (t == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(&ctr[3 * n + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                __builtin_amdgcn_s_sleep(16);
-                if (++spins > (1 << 21)) { *err = 1; break; }
-            }
-        }
-        __syncthreads();
-    }
-    const int cpg = C / G;
-    float a[8], b[8];
-    if (active) {
-        const int g0 = c / cpg, g1 = (c + 7) / cpg;                   // a thread's 8 channels touch at most two groups (cpg >= 10)
-        const double m0 = __hip_atomic_load(&stats[((size_t)n * G + g0) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double r0 = __hip_atomic_load(&stats[((size_t)n * G + g0) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double m1 = __hip_atomic_load(&stats[((size_t)n * G + g1) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double r1 = __hip_atomic_load(&stats[((size_t)n * G + g1) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const bool hi = (c + k) / cpg != g0;
-            const double ad = (hi ? r1 : r0) * (double)gamma[c + k];
-            a[k] = (float)ad;
-            b[k] = (float)((double)beta[c + k] - (hi ? m1 : m0) * ad);
-        }
-    }
-    __syncthreads();     // every thread of the block has read the statistics
-    if (t == 0 && !dbg) {        // the last block of the sample to get here re-arms its counters
-        const int done = __hip_atomic_fetch_add(&ctr[3 * n + 2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == chunks - 1) {
-            __hip_atomic_store(&ctr[3 * n], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ctr[3 * n + 1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ctr[3 * n + 2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if (!active) return;
-#pragma unroll
-    for (int i = 0; i < GNF_PPT; ++i) {
-        const int px = px0 + rg + i * R;
-        if (px >= px1) break;
-        half8 o;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float y = fmaf((float)v[i][k], a[k], b[k]);
-            if (silu) y = silu_f(y);
-            o[k] = (f16)y;
-        }
-        *reinterpret_cast<half8*>(Y + ((size_t)n * HW + px) * C + c) = o;
     }
 }
 
@@ -512,30 +364,22 @@ __global__ void ln_stats_g_kernel(const f16* __restrict__ X, int rows, float eps
 
 }  // namespace
 
+static int gn_pix(int HW) { int p = GN_PIX_MAX; while (p > 32 && HW / p < 16) p >>= 1; return p; }
+int gn_stats_chunks(int HW) { const int p = gn_pix(HW); return (HW + p - 1) / p; }
+
 static void gn_geometry(int C, int* R, int* threads) {
     const int cols = C / 8;
     int r = 320 / cols; if (r < 1) r = 1; if (r > 8) r = 8;
     *R = r; *threads = ((cols * r + 63) / 64) * 64;
 }
-// pixels per statistics block: at most 256, at least 16 blocks per sample where the image allows it, and (r04) at most
-// GNF_PPT = 16 pixels per thread, so that the single-pass kernel can keep a block's slab in registers — one rule for the two-pass
-// and the single-pass form: their partial sums, hence their bits, are the same
-static int gn_pix(int HW, int C) {
-    int p = GN_PIX_MAX;
-    while (p > 32 && HW / p < 16) p >>= 1;
-    int R, threads; gn_geometry(C, &R, &threads);
-    while (p > GNF_PPT * R) p >>= 1;
-    return p;
-}
-int gn_stats_chunks(int HW, int C) { const int p = gn_pix(HW, C); return (HW + p - 1) / p; }
 
 hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, double* partial, hipStream_t s) {
     if (C % 8 || C % G || C1 % 8 || G > 64) return hipErrorInvalidValue;
     int R, threads; gn_geometry(C, &R, &threads);
     if (threads > 1024) return hipErrorInvalidValue;
-    const int chunks = gn_stats_chunks(HW, C);
+    const int chunks = gn_stats_chunks(HW);
     const size_t lds = (size_t)R * C * 2 * sizeof(float);
-    hipLaunchKernelGGL(gn_stats_partial, dim3(chunks, N), dim3(threads), lds, s, X, X2 ? X2 : X, HW, C, C1, G, R, gn_pix(HW, C), partial);
+    hipLaunchKernelGGL(gn_stats_partial, dim3(chunks, N), dim3(threads), lds, s, X, X2 ? X2 : X, HW, C, C1, G, R, gn_pix(HW), partial);
     return hipGetLastError();
 }
 
@@ -548,29 +392,14 @@ hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, in
     int ppb = 256;
     while (ppb > 8 && (long long)N * ((HW + ppb - 1) / ppb) < 2048) ppb >>= 1;
     hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + ppb - 1) / ppb, N), dim3(threads), 0, s, X, X2 ? X2 : X, HW, C, C1, R,
-                       ppb, partial, gn_stats_chunks(HW, C), G, (double)HW * (double)(C / G), eps, gamma, beta, silu, Y);
+                       ppb, partial, gn_stats_chunks(HW), G, (double)HW * (double)(C / G), eps, gamma, beta, silu, Y);
     return hipGetLastError();
 }
-
-hipError_t launch_gn_fused(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, float eps, const float* gamma,
-                           const float* beta, double* partial, int* ctr, int ctr_samples, int* err, int silu, f16* Y, hipStream_t s) {
-    if (C % 8 || C % G || C1 % 8 || G > 64) return hipErrorInvalidValue;
-    int R, threads; gn_geometry(C, &R, &threads);
-    if (threads < G) threads = 64;
-    const int pix = gn_pix(HW, C), chunks = gn_stats_chunks(HW, C);
-    if (threads > 384 || N > ctr_samples || pix > GNF_PPT * R || !ctr || !err) return hipErrorNotSupported;     // caller falls back to the two-pass pair
-    const size_t lds = (size_t)R * C * 2 * sizeof(float);
-    double* stats = partial + (size_t)N * chunks * G * 2;          // gn_partial_doubles() leaves room for it
-    hipLaunchKernelGGL(gn_fused_kernel, dim3(chunks, N), dim3(threads), lds, s, X, X2 ? X2 : X, HW, C, C1, G, R, pix, partial, stats,
-                       ctr, (double)HW * (double)(C / G), eps, gamma, beta, silu, Y, err, option(OPT_GN_FUSED) == 2 ? 1 : 0);
-    return hipGetLastError();
-}
-size_t gn_partial_doubles(int N, int HW, int C, int G) { return ((size_t)N * gn_stats_chunks(HW, C) * G + (size_t)N * G) * 2; }
 
 hipError_t launch_gn_fold(const double* partial, int N, int HW, int C, int G, float eps, const float* gamma, const float* beta,
                           const f16* W, const f16* bias, int Cout, f16* Wn, float* tn, hipStream_t s) {
     if (C % 8 || C % G || C > 2560 || G > 64 || 256 % G) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gn_fold_kernel, dim3((Cout + GNF_ROWS - 1) / GNF_ROWS, N), dim3(256), 0, s, partial, gn_stats_chunks(HW, C), G, C,
+    hipLaunchKernelGGL(gn_fold_kernel, dim3((Cout + GNF_ROWS - 1) / GNF_ROWS, N), dim3(256), 0, s, partial, gn_stats_chunks(HW), G, C,
                        (double)HW * (double)(C / G), eps, gamma, beta, W, bias, Cout, Wn, tn);
     return hipGetLastError();
 }

@@ -30,7 +30,7 @@ SYMBOLS = [
     "dm_f32_create", "dm_f32_destroy", "dm_f32_last_error", "dm_f32_load_weight", "dm_f32_finalize", "dm_f32_set_prompts",
     "dm_f32_unet_forward", "dm_f32_dift", "dm_f32_prof_enable", "dm_f32_prof_read", "dm_f32_memory", "dm_f32_op_gemm",
     "dm_f32_op_attention", "dm_f32_op_groupnorm", "dm_f32_op_layernorm", "dm_f32_load_vae_weight", "dm_f32_finalize_vae",
-    "dm_f32_vae_encode", "dm_op_groupnorm_fused",
+    "dm_f32_vae_encode",
 ]
 
 
@@ -102,8 +102,6 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         lib.dm_engine_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     if hasattr(lib, "dm_normalize_map"):
         lib.dm_normalize_map.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
-    if hasattr(lib, "dm_op_groupnorm_fused"):
-        lib.dm_op_groupnorm_fused.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, C.c_float, vp, vp, i32, vp]
     if hasattr(lib, "dm_f32_create"):            # the fp32 U-Net (DIFT arithmetic), r04
         lib.dm_f32_create.argtypes = [i32, C.POINTER(vp)]
         lib.dm_f32_destroy.argtypes = [vp]

@@ -292,11 +292,6 @@ int dm_op_attention512(void* stream, const void* Q, const void* K, const void* V
                        int ldo, float scale);
 int dm_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, int C, int C1, int G, float eps,
                     const float* gamma, const float* beta, int silu, void* Y);
-/* dm_op_groupnorm in ONE pass over HBM (r04; option gn_fused): blocks keep their slab in registers between the statistics and the
- * normalisation and meet through per-sample counters; bit-identical to dm_op_groupnorm.  Returns 2 for a shape outside the
- * kernel's limits, 3 if a block gave up waiting (bounded), 4 if the counters were not re-armed. */
-int dm_op_groupnorm_fused(void* stream, const void* X, const void* X2, int N, int HW, int C, int C1, int G, float eps,
-                          const float* gamma, const float* beta, int silu, void* Y);
 int dm_op_layernorm(void* stream, const void* X, int rows, int C, const float* gamma, const float* beta, float eps,
                     void* Y);
 /* A GEMM with a second GEMM on another tensor folded into its k loop: after its own taps on X [N,H,W,Cin] (mode 1: 3x3 stride 1;

@@ -1096,37 +1096,3 @@ def test_igemm_tap_reuse_upsample():
         ref = F.conv2d(up, w.float(), b.float(), padding=1)
         U.assert_close_fp16(U.to_nchw(out[1][n:n + 1]), ref, f"tap-reuse upsample conv n={n}")
     assert (std.float() - out[1].float()).abs().max().item() <= 2e-3 * std.float().abs().max().item()
-
-
-@pytest.mark.parametrize("N,H,W,C1,C2,silu", [
-    (160, 64, 64, 320, 0, 1),        # the bench's largest GroupNorm: 5120 blocks, several rounds of resident blocks
-    (23, 64, 64, 640, 320, 1),       # concat 960 @64x64: 128 chunks per sample
-    (160, 32, 32, 640, 0, 1), (40, 32, 32, 1280, 640, 1), (160, 16, 16, 1280, 1280, 1), (160, 8, 8, 1280, 0, 1),
-    (3, 9, 7, 1280, 640, 0), (5, 12, 10, 320, 0, 1), (2, 33, 21, 640, 320, 0),       # odd images: a ragged last chunk
-    (700, 8, 8, 2560, 0, 1),
-])
-def test_groupnorm_single_pass_is_bit_identical(N, H, W, C1, C2, silu):
-    """r04: GroupNorm in one pass over HBM (a block keeps its slab in registers between the statistics and the normalisation; the blocks
-    of a sample meet through per-sample counters) against the two-pass pair: the same partial sums in the same order, so the SAME bits —
-    at the bench's batch (thousands of blocks: the wait must never stall), on concatenated sources, on ragged chunks; the kernel
-    re-arms its counters (rc 4 otherwise) and never gives up waiting (rc 3)."""
-    from diff_mining_amd import engine as E
-    lib = E.load_library()
-    d = U.dev()
-    g = torch.Generator().manual_seed(N + C1)
-    x1 = (torch.randn(N, H, W, C1, generator=g) * 1.5 + 0.3).half().to(d)
-    x2 = (torch.randn(N, H, W, C2, generator=g) * 0.7 - 0.5).half().to(d) if C2 else None
-    Ct = C1 + C2
-    gamma = (1 + 0.1 * torch.randn(Ct, generator=g)).float().to(d)
-    beta = (0.1 * torch.randn(Ct, generator=g)).float().to(d)
-    ref = U.op_groupnorm(x1, gamma, beta, 32, 1e-5, silu, X2=x2)
-    for rep in range(3):
-        y = torch.full((N, H, W, Ct), float("nan"), dtype=torch.float16, device=d)
-        rc = lib.dm_op_groupnorm_fused(U.stream(), U.ptr(x1), U.ptr(x2), N, H * W, Ct, C1, 32, 1e-5, U.ptr(gamma), U.ptr(beta), silu, U.ptr(y))
-        assert rc == 0, f"dm_op_groupnorm_fused rc {rc}"
-        torch.cuda.synchronize()
-        assert torch.equal(y, ref), f"rep {rep}: {(y.float() - ref.float()).abs().max().item()}"
-    if N <= 5:
-        cat = torch.cat([x1, x2], 3) if C2 else x1
-        want = F.group_norm(U.to_nchw(cat.float().cpu()), 32, gamma.cpu(), beta.cpu(), 1e-5)
-        U.assert_close_fp16(U.to_nchw(ref), F.silu(want) if silu else want, "groupnorm single pass")
