@@ -50,7 +50,7 @@ class SDFeaturizer:
         `tokenizer`: e.g. transformers' `CLIPTokenizer` (dift.py:203); only needed for string prompts."""
         self.engine = engine
         self.dtype = torch.float32 if isinstance(engine, UNetEngineF32) else torch.float16
-        self.aux = aux if aux is not None else (engine if isinstance(engine, UNetEngine) else None)
+        self.aux = aux if aux is not None else (None if isinstance(engine, UNetEngineF32) else engine)
         self.tokenizer = tokenizer
         self._prompt_cache: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         self.device = engine.device

@@ -232,6 +232,7 @@ def test_dift_featurizer_registers_a_prompt_once():
     eng = _E()
     f = SDFeaturizer.__new__(SDFeaturizer)
     f.engine, f.device, f.tokenizer = eng, torch.device("cpu"), None
+    f.dtype, f.aux = torch.float16, None          # the fp16 engine's mode (r04: the featuriser runs in its engine's dtype)
     f._registered, f.prompt_registrations = None, 0
     f.acp = torch.linspace(0.999, 0.01, 1000)
     p = torch.randn(1, 77, 768)
