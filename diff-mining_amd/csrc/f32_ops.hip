@@ -50,19 +50,52 @@ __global__ __launch_bounds__(256) void attn32_kernel(AttnParams p) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) { mrun[qt] = -INFINITY; lrun[qt] = 0.f; }
 
+    // K / V tiles go global -> registers -> LDS; where the registers allow (head_dim <= 80) the loads of tile t+1 are issued before the
+    // MFMAs of tile t, so their latency is covered by the block's own matrix work instead of by other blocks' (r04: +x % at 4096 keys)
+    constexpr int NLD = (KT * (D / 4) + 255) / 256;
+    constexpr bool PF = D <= 80;
+    v4f kreg[PF ? NLD : 1], vreg[PF ? NLD : 1];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < (PF ? NLD : 0); ++j) {
+            const int i = tid + 256 * j;
+            const int r = i / (D / 4), c4 = i - r * (D / 4), key = k0 + r;
+            kreg[j] = v4f{0.f, 0.f, 0.f, 0.f}; vreg[j] = v4f{0.f, 0.f, 0.f, 0.f};
+            if (i < KT * (D / 4) && key < p.Tk) {
+                kreg[j] = *reinterpret_cast<const v4f*>(Kb + (long long)key * p.ldk + 4 * c4);
+                vreg[j] = *reinterpret_cast<const v4f*>(Vb + (long long)key * p.ldv + 4 * c4);
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < (PF ? NLD : 0); ++j) {
+            const int i = tid + 256 * j;
+            if (i < KT * (D / 4)) {
+                const int r = i / (D / 4), c4 = i - r * (D / 4);
+                *reinterpret_cast<v4f*>(Ks + r * LD + 4 * c4) = kreg[j];
+                *reinterpret_cast<v4f*>(Vs + r * LD + 4 * c4) = vreg[j];
+            }
+        }
+    };
+    if (PF) gload(0);
     for (int k0 = 0; k0 < p.Tk; k0 += KT) {
         __syncthreads();
-        for (int i = tid; i < KT * (D / 4); i += 256) {
-            const int r = i / (D / 4), c4 = i - r * (D / 4), key = k0 + r;
-            v4f kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (key < p.Tk) {
-                kv = *reinterpret_cast<const v4f*>(Kb + (long long)key * p.ldk + 4 * c4);
-                vv = *reinterpret_cast<const v4f*>(Vb + (long long)key * p.ldv + 4 * c4);
+        if (!PF) {
+            for (int i = tid; i < KT * (D / 4); i += 256) {
+                const int r = i / (D / 4), c4 = i - r * (D / 4), key = k0 + r;
+                v4f kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+                if (key < p.Tk) {
+                    kv = *reinterpret_cast<const v4f*>(Kb + (long long)key * p.ldk + 4 * c4);
+                    vv = *reinterpret_cast<const v4f*>(Vb + (long long)key * p.ldv + 4 * c4);
+                }
+                *reinterpret_cast<v4f*>(Ks + r * LD + 4 * c4) = kv;
+                *reinterpret_cast<v4f*>(Vs + r * LD + 4 * c4) = vv;
             }
-            *reinterpret_cast<v4f*>(Ks + r * LD + 4 * c4) = kv;
-            *reinterpret_cast<v4f*>(Vs + r * LD + 4 * c4) = vv;
         }
+        lstore();
         __syncthreads();
+        if (PF && k0 + KT < p.Tk) gload(k0 + KT);
         v4f sacc[NKT][QT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)

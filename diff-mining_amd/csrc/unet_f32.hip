@@ -88,6 +88,7 @@ struct dm_f32_net {
     int n_prompts = 0, kv_capacity = 0;
     std::vector<float*> kv_cache;      // per transformer layer [P*77][2C]
     dm::Arena arena; char* arena_base = nullptr; size_t arena_cap = 0;
+    std::map<std::vector<long long>, size_t> arena_need;    // exact peak per (schedule, shape) key: the dry run is done once
     bool prof = false;
     std::vector<Ev> evs; std::vector<hipEvent_t> ev_pool;
     double prof_ms[2] = {0, 0}, prof_flops[2] = {0, 0}; long long prof_n[2] = {0, 0};
@@ -472,10 +473,16 @@ int run_vae32(dm_f32_net* e, const VaeArgs32& A, hipStream_t s, bool dry) {
 }
 
 template <class RunDry>
-int ensure_arena_for32(dm_f32_net* e, hipStream_t s, RunDry run_dry) {
-    e->arena.reset((size_t)1 << 46, true);
-    F_TRY(run_dry());
-    const size_t need = e->arena.peak + (1 << 20);
+int ensure_arena_for32(dm_f32_net* e, hipStream_t s, const std::vector<long long>& key, RunDry run_dry) {
+    size_t need;
+    auto it = e->arena_need.find(key);
+    if (it != e->arena_need.end()) need = it->second;
+    else {
+        e->arena.reset((size_t)1 << 46, true);
+        F_TRY(run_dry());
+        need = e->arena.peak + (1 << 20);
+        e->arena_need[key] = need;
+    }
     if (need > e->arena_cap) {
         if (e->arena_base) { F_HIP(e, hipStreamSynchronize(s)); F_HIP(e, hipFree(e->arena_base)); e->arena_base = nullptr; e->arena_cap = 0; }
         F_HIP(e, hipMalloc((void**)&e->arena_base, need));
@@ -493,7 +500,7 @@ int chunk32(int h, int w) {
 }
 
 int ensure_arena32(dm_f32_net* e, const Args32& A, hipStream_t s) {
-    return ensure_arena_for32(e, s, [&]() { return run_forward32(e, A, s, true); });
+    return ensure_arena_for32(e, s, {0, A.B, A.H, A.W, A.up_ft_index}, [&]() { return run_forward32(e, A, s, true); });
 }
 
 int run_chunked32(dm_f32_net* e, Args32 A, void* stream) {
@@ -786,7 +793,7 @@ int dm_f32_vae_encode(dm_f32_net* e, const void* image_dev, const void* noise_de
         A.noise = noise_dev ? (const float*)noise_dev + (size_t)b0 * draws_per_image * 4 * h * w : nullptr;
         A.latent = latent_dev ? (float*)latent_dev + (size_t)b0 * draws_per_image * 4 * h * w : nullptr;
         A.moments = moments_dev ? (float*)moments_dev + (size_t)b0 * 8 * h * w : nullptr;
-        F_TRY(ensure_arena_for32(e, s, [&]() { return run_vae32(e, A, s, true); }));
+        F_TRY(ensure_arena_for32(e, s, {1, A.B, A.H, A.W, 0}, [&]() { return run_vae32(e, A, s, true); }));
         F_TRY(run_vae32(e, A, s, false));
     }
     return 0;

@@ -552,3 +552,39 @@ def test_rescale_and_get_path_match_the_reference_class():
         assert list(T.TypicalityScorer.rescale_size(r["which"], W, H)) == r["out"]
     for src, want in m["get_path"].items():
         assert T.TypicalityScorer.get_path("/data/out/typicality", src) == want
+
+
+def test_sdfeaturizer_runs_in_the_dtype_of_its_engine():
+    """r04: the reference's featuriser is fp32 (dift.py:197-199); `SDFeaturizer` over the fp32 net hands fp32 latents and prompt
+    embeddings to it, over the fp16 engine fp16 ones; image / string inputs of the fp32 featuriser go to its own VAE or to `aux`."""
+    from diff_mining_amd.dift import SDFeaturizer
+    from diff_mining_amd.engine import UNetEngineF32
+
+    seen = {}
+
+    class _F32(UNetEngineF32):
+        def __init__(self):                      # no library, no GPU: only the host logic is under test
+            self.device, self.prompt_generation, self.n_prompts = torch.device("cpu"), 0, 0
+
+        def set_prompts(self, ctx):
+            seen["ctx"] = ctx.dtype
+            self.prompt_generation += 1
+
+        def dift(self, noisy, t, slots, up_ft_index, ens):
+            seen["noisy"] = noisy.dtype
+            return None, torch.zeros(1, 4, 2, 2)
+
+        def close(self):
+            pass
+
+    f = SDFeaturizer(_F32())
+    assert f.dtype == torch.float32 and f.aux is None
+    p = torch.randn(1, 77, 768).half()
+    f.forward(torch.randn(1, 4, 8, 8), p, ensemble_size=2, noise=torch.zeros(2, 4, 8, 8))
+    assert seen["noisy"] == torch.float32
+    with pytest.raises(ValueError, match="VAE"):
+        f.forward(torch.zeros(1, 3, 64, 64), p, ensemble_size=2)
+    with pytest.raises(ValueError, match="tokenizer"):
+        f.forward(torch.randn(1, 4, 8, 8), "a string prompt", ensemble_size=2)
+    g = SDFeaturizer(_FakeEngine())
+    assert g.dtype == torch.float16 and g.aux is g.engine
