@@ -360,7 +360,7 @@ def side_workload(args, eng, dev, sd):
     line = {"metric": name, "value": round(val, 4), "unit": "images/s", "n_gpus": 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if f32 else "f16", "data": "synthetic", "config": cfg,
-            "roofline": {"bound": "mfma", "kernel": "gemm32_kernel (fp32 implicit GEMM, 128x160x16 tile, v_mfma_f32_16x16x4_f32)" if f32 else
+            "roofline": {"bound": "mfma", "kernel": "gemm32_kernel (fp32 implicit GEMM, 128x160x32 tile, v_mfma_f32_32x32x2_f32)" if f32 else
                          "igemm family (igemm_pers_kernel + igemm_kernel)", "achieved": round(ig_tf, 2),
                          "peak": peak, "unit": "TFLOP/s", "frac": round(ig_tf / peak, 4), "traffic": None,
                          "launches": prof["igemm_launches"], "kernel_ms_total": round(prof["igemm_ms"], 3),
