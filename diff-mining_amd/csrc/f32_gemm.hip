@@ -21,6 +21,7 @@
 // one pixel per register quad, so the epilogue stores 16 bytes per lane into the NHWC row.  LDS: two stages of (160 + 128) rows x
 // 32 floats (72 KiB, two blocks per CU), 16-byte chunks XOR-swizzled by row.
 #include "f32_kernels.h"
+#include <atomic>
 
 namespace dm32 {
 namespace {
@@ -212,9 +213,16 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.Cout + BN - 1) / BN;
     const long long tiles = (long long)tiles_m * tiles_n;
     const int per_xcd = (int)((tiles + 7) / 8);
-    float* zp = nullptr;
-    hipError_t e = hipGetSymbolAddress((void**)&zp, HIP_SYMBOL(g_zero_page32));
-    if (e != hipSuccess) return e;
+    // device address of the zero page: one symbol lookup per device ordinal
+    static std::atomic<float*> zero_pages[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    float* zp = zero_pages[dev & 63].load(std::memory_order_relaxed);
+    if (!zp) {
+        hipError_t e = hipGetSymbolAddress((void**)&zp, HIP_SYMBOL(g_zero_page32));
+        if (e != hipSuccess) return e;
+        zero_pages[dev & 63].store(zp, std::memory_order_relaxed);
+    }
     hipLaunchKernelGGL(gemm32_kernel, dim3((unsigned)(per_xcd * 8)), dim3(NT), 0, s, p, tiles_m, tiles_n, per_xcd, (const float*)zp);
     return hipGetLastError();
 }
