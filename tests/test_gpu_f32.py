@@ -342,3 +342,40 @@ def test_sdfeaturizer_from_pixels_in_fp32(net32, vae_sd, sd15_weights_torch):
     r = U.rel_l2(out.cpu(), mean_ref)
     print(f"SDFeaturizer from pixels, fp32 end to end: rel-L2 vs the fp32 oracles {r:.2e}")
     assert out.shape == mean_ref.shape and r < TOL_E2E
+
+
+def test_f32_net_error_behaviour(sd15_weights_f16):
+    """Failures are loud and named (no fallback): calls before finalize / set_prompts, a state dict with a tensor missing or of the
+    wrong shape, a prompt slot outside the registered prompts, a batch that is not whole ensembles."""
+    from diff_mining_amd.engine import EngineError, UNetEngineF32
+    e = UNetEngineF32(0)
+    x = torch.zeros(2, 4, 8, 8)
+    with pytest.raises(EngineError, match="finalized"):
+        e.n_prompts = 1
+        e.unet(x, torch.tensor(5), torch.zeros(2, dtype=torch.int32))
+    e.n_prompts = 0
+    partial = {k: v for k, v in sd15_weights_f16.items() if k != "mid_block.resnets.1.conv2.weight"}
+    with pytest.raises(EngineError, match="mid_block.resnets.1.conv2.weight"):
+        e.load_state_dict(partial)
+    e.close()
+    e = UNetEngineF32(0)
+    bad = dict(sd15_weights_f16)
+    bad["conv_in.weight"] = bad["conv_in.weight"][:, :3]
+    with pytest.raises(EngineError, match="conv_in.weight"):
+        e.load_state_dict(bad)
+    e.close()
+    e = UNetEngineF32(0)
+    e.load_state_dict(sd15_weights_f16)
+    with pytest.raises(EngineError, match="set_prompts"):
+        e.n_prompts = 1                      # get past the host-side slot check: the library itself must refuse
+        e.unet(x, torch.tensor(5), torch.zeros(2, dtype=torch.int32))
+    e.set_prompts(torch.zeros(2, 77, 768))
+    with pytest.raises(EngineError, match="slot"):
+        e.unet(x, torch.tensor(5), torch.tensor([0, 2], dtype=torch.int32))
+    with pytest.raises(EngineError, match="ensemble"):
+        e.dift(torch.zeros(3, 4, 8, 8), torch.tensor(5), torch.zeros(3, dtype=torch.int32), 1, 2)
+    with pytest.raises(EngineError, match="VAE"):
+        e.vae_encode(torch.zeros(1, 3, 64, 64))
+    out = e.unet(x, torch.tensor([5, 900]), torch.tensor([1, 0], dtype=torch.int32))          # and it still works afterwards
+    assert out.shape == (2, 4, 8, 8) and torch.isfinite(out).all()
+    e.close()
