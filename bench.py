@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the score-deviation leg (image 0 of the step re-scored in exact fp32 on the GPU by the fp32 net, after the timed region)")
     ap.add_argument("--images", type=int, default=N_IMG)
     ap.add_argument("--latent-dtype", choices=["f32", "f16"], default="f32",
                     help="dtype flow of add_noise / MSE: f32 = the reference's (compute.py:91-101), f16 = fp16 scheduler")
@@ -250,11 +252,40 @@ def main():
                                        "all": [round(v, 3) for v in rank_ms]}
         if STUB:
             out["data"] = "stub (DM_BENCH_STUB=1: launcher / gather path only, no engine)"
+        if not args.no_parity and world == 1 and not STUB:
+            out["score_deviation"] = score_deviation(sd, eng, x[:1], eps, t, c, last["loss"], n_img, dev)
         if not args.no_cpu_baseline and world == 1 and not STUB:
             out["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def score_deviation(sd, eng, x0, eps, t, c, loss, n_img, dev):
+    """north_star ends on "<= 1e-3 score deviation from reference": image 0 of the timed step (its 10 draws x 2 prompts, the very
+    losses the step produced) against the EXACT-fp32 evaluation of the same U-Net on the same inputs — the fp32 net (dm_f32_*,
+    product code, 2-4e-6 from the CPU oracle's autocast=False arithmetic: tests/test_gpu_f32.py) with the reference's fp32
+    add_noise / MSE around it (compute.py:99-101).  Outside the timed region; the CPU oracle cannot reach this size."""
+    from diff_mining_amd.dift import scheduler_alphas_cumprod
+    from diff_mining_amd.engine import UNetEngineF32
+    t0 = time.perf_counter()
+    net = UNetEngineF32(dev.index or 0)
+    net.load_state_dict(sd)
+    net.set_prompts(c.float())
+    a = scheduler_alphas_cumprod().to(dev)[t].view(N_DRAWS, 1, 1, 1)
+    e32 = eps.float()
+    noisy = (a ** 0.5) * x0.float() + ((1 - a) ** 0.5) * e32
+    ref = torch.stack([(net.unet(noisy, t, torch.full((N_DRAWS,), k, dtype=torch.int32)) - e32) ** 2 for k in range(N_COND)], dim=1)
+    net.close()
+    got = loss.view(N_COND, n_img, N_DRAWS, 4, LAT, LAT)[:, 0].transpose(0, 1).float()      # [N,2,4,h,w] of image 0 (cond 0 = c, 1 = null)
+    T = (got[:, 1] - got[:, 0]).double().mean().item()
+    T32 = (ref[:, 1] - ref[:, 0]).double().mean().item()
+    ml = ref.double().mean().item()
+    return {"reference": "exact-fp32 evaluation of the same U-Net on the same (x, t, eps, c) on the GPU (fp32 net), image 0 of the step: "
+                         "10 draws x 2 prompts @64x64",
+            "loss_grid_rel_l2": round(((got - ref).double().norm() / ref.double().norm()).item(), 7),
+            "T_engine": T, "T_fp32": T32, "abs_dT_over_abs_T": round(abs(T - T32) / abs(T32), 7),
+            "abs_dT_over_mean_loss": round(abs(T - T32) / ml, 9), "seconds": round(time.perf_counter() - t0, 1)}
 
 
 TRAFFIC_SOURCE = {}
