@@ -31,6 +31,7 @@ constexpr int CH = BK / 4;                               // 16-byte chunks per r
 constexpr int XI = BM * CH / NT, WI = BN * CH / NT;      // 4 activation + 5 weight chunks per lane and step
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __attribute__((aligned(256))) float g_zero_page32[BK] = {0};
 
@@ -196,6 +197,13 @@ __global__ __launch_bounds__(NT, 2) void gemm32_kernel(GemmParams p, int tiles_m
                 if (ch >= p.Cout) continue;
                 v4f v = acc[ct][q];
                 if (p.bias) v += *reinterpret_cast<const v4f*>(p.bias + ch);
+                if (p.epi == 1) {          // GEGLU: the quad is (h0, h1, g0, g1); erf GELU as F.gelu
+                    v2f y;
+                    y[0] = v[0] * (0.5f * v[2] * (1.0f + erff(v[2] * 0.70710678118654752440f)));
+                    y[1] = v[1] * (0.5f * v[3] * (1.0f + erff(v[3] * 0.70710678118654752440f)));
+                    *reinterpret_cast<v2f*>(p.Y + (size_t)m * p.ldy + (ch >> 1)) = y;
+                    continue;
+                }
                 if (tb) v += *reinterpret_cast<const v4f*>(tb + ch);
                 if (p.res) v += *reinterpret_cast<const v4f*>(p.res + (size_t)m * p.ldres + ch);
                 *reinterpret_cast<v4f*>(p.Y + (size_t)m * p.ldy + ch) = v;
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(NT, 2) void gemm32_kernel(GemmParams p, int tiles_m
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     const int taps = p.mode == 0 ? 1 : 9;
     if (p.M <= 0 || p.Cout <= 0 || p.Cin % BK != 0 || p.C1 % BK != 0 || p.C1 <= 0 || p.Cout % 4 != 0 || (p.C1 < p.Cin && !p.X2) ||
-        (long long)taps * p.Cin > (1LL << 30) || p.ldy % 4 != 0 || (p.res && p.ldres % 4 != 0) || (p.temb && p.temb_ld % 4 != 0))
+        (long long)taps * p.Cin > (1LL << 30) || p.ldy % (p.epi == 1 ? 2 : 4) != 0 || (p.epi == 1 && (p.temb || p.res)) || (p.res && p.ldres % 4 != 0) || (p.temb && p.temb_ld % 4 != 0))
         return hipErrorInvalidValue;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.Cout + BN - 1) / BN;
     const long long tiles = (long long)tiles_m * tiles_n;

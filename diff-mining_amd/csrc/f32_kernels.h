@@ -21,6 +21,9 @@ struct GemmParams {
     int H = 1, W = 1, OH = 1, OW = 1;
     int mode = 0;
     int ldy = 0, ldres = 0, temb_ld = 0;
+    // epi = 1: GEGLU — the weight rows are packed in quads (h0, h1, g0, g1) (value rows 2q, 2q + 1 and gate rows F + 2q, F + 2q + 1 of
+    // ff.net.0.proj [2F][C], F = Cout / 2), a lane's four channels are one quad, Y [M][F] gets (h0 gelu(g0), h1 gelu(g1)) at columns 2q, 2q + 1
+    int epi = 0;
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 
@@ -41,8 +44,6 @@ hipError_t launch_gn_apply(const float* X, const float* X2, int N, int HW, int C
                            const float* stats, int silu, float* Y, hipStream_t s);
 hipError_t launch_layernorm(const float* X, int rows, int C, const float* gamma, const float* beta, float eps, float* Y, hipStream_t s);
 hipError_t launch_silu(const float* in, float* out, long long n, hipStream_t s);
-// GEGLU: proj [M][2*F] -> out [M][F] = proj[:, :F] * gelu_erf(proj[:, F:])
-hipError_t launch_geglu(const float* proj, long long M, int F, float* out, hipStream_t s);
 // Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): out [B][dim] = [cos | sin]
 hipError_t launch_timestep_embed(const int64_t* t, int B, int dim, float* out, hipStream_t s);
 // conv_in: sample NCHW [B,Cin<=4,H,W] (x) 3x3 pad 1 -> NHWC [B,H,W,Cout]; w transposed [Cin*9][Cout] (k = (ci, dy, dx): consecutive

@@ -1,5 +1,5 @@
 // f32_ops.hip — the non-GEMM kernels of the fp32 U-Net path (reference: the DIFT featuriser's fp32 run, dift.py:191,197-199):
-// flash attention on the fp32 matrix cores, GroupNorm (+ SiLU), LayerNorm, GEGLU, the time-step embedding, conv_in / conv_out and the
+// flash attention on the fp32 matrix cores, GroupNorm (+ SiLU), LayerNorm, the time-step embedding, conv_in / conv_out and the
 // layout kernels at the NCHW boundary.  All tensors fp32, NHWC inside.
 #include "f32_kernels.h"
 #include <math.h>
@@ -249,21 +249,6 @@ __global__ void silu32_kernel(const float* in, float* out, long long n) {
     }
 }
 
-__global__ void geglu32_kernel(const float* proj, long long M, int F, float* out) {
-    const int f4 = F / 4;
-    const long long total = M * f4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long row = i / f4;
-        const int ch = 4 * (int)(i - row * f4);
-        const v4f a = *reinterpret_cast<const v4f*>(proj + row * 2 * F + ch);
-        const v4f gt = *reinterpret_cast<const v4f*>(proj + row * 2 * F + F + ch);
-        v4f y;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = a[j] * (0.5f * gt[j] * (1.0f + erff(gt[j] * 0.70710678118654752440f)));
-        *reinterpret_cast<v4f*>(out + row * F + ch) = y;
-    }
-}
-
 __global__ void temb32_kernel(const int64_t* t, int B, int dim, float* out) {
     const int half = dim / 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -410,11 +395,6 @@ hipError_t launch_layernorm(const float* X, int rows, int C, const float* gamma,
 }
 hipError_t launch_silu(const float* in, float* out, long long n, hipStream_t s) {
     hipLaunchKernelGGL(silu32_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
-    return hipGetLastError();
-}
-hipError_t launch_geglu(const float* proj, long long M, int F, float* out, hipStream_t s) {
-    if (F % 4 != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(geglu32_kernel, dim3(grid_for(M * (F / 4))), dim3(256), 0, s, proj, M, F, out);
     return hipGetLastError();
 }
 hipError_t launch_timestep_embed(const int64_t* t, int B, int dim, float* out, hipStream_t s) {

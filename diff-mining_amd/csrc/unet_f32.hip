@@ -157,6 +157,25 @@ int pack_stack(dm_f32_net* e, const std::vector<std::string>& names, int rows_ea
     o->cin = cin; o->cout = (int)names.size() * rows_each; o->k = 1; o->b = NONE;
     return 0;
 }
+// GEGLU projection [2F][C] (F = 4C): rows packed in quads (h 2q, h 2q+1, g 2q, g 2q+1) so that a lane of gemm32's epilogue holds a
+// value pair and its gate pair (GemmParams::epi = 1)
+int pack_geglu(dm_f32_net* e, const std::string& name, int c, Conv* o) {
+    const int F = 4 * c;
+    HostT* w = get(e, name + ".weight", {2 * F, c});
+    HostT* b = get(e, name + ".bias", {2 * F});
+    if (!w || !b) return 1;
+    std::vector<float> pk((size_t)2 * F * c), pb((size_t)2 * F);
+    for (int rho = 0; rho < 2 * F; ++rho) {
+        const int q = rho >> 2, r = rho & 3;
+        const int src = (r < 2) ? (2 * q + r) : (F + 2 * q + (r - 2));
+        memcpy(pk.data() + (size_t)rho * c, w->data.data() + (size_t)src * c, (size_t)c * sizeof(float));
+        pb[rho] = b->data[src];
+    }
+    o->w = put(e, pk.data(), pk.size());
+    o->b = put(e, pb.data(), pb.size());
+    o->cin = c; o->cout = 2 * F; o->k = 1;
+    return 0;
+}
 int pack_res(dm_f32_net* e, const std::string& name, int cin, int cout, Res* r) {
     F_TRY(pack_norm(e, name + ".norm1", cin, &r->n1));
     F_TRY(pack_conv3(e, name + ".conv1", cout, cin, &r->c1));
@@ -195,7 +214,7 @@ int pack_tfm(dm_f32_net* e, const std::string& name, int c, Tfm* t) {
     F_TRY(pack_stack(e, {b + ".attn2.to_k", b + ".attn2.to_v"}, c, CTX_DIM, &t->kv2));
     F_TRY(pack_dense(e, b + ".attn2.to_out.0", c, c, false, true, &t->o2));
     F_TRY(pack_norm(e, b + ".norm3", c, &t->ln3));
-    F_TRY(pack_dense(e, b + ".ff.net.0.proj", 8 * c, c, false, true, &t->ff1));
+    F_TRY(pack_geglu(e, b + ".ff.net.0.proj", c, &t->ff1));
     F_TRY(pack_dense(e, b + ".ff.net.2", c, 4 * c, false, true, &t->ff2));
     F_TRY(pack_dense(e, name + ".proj_out", c, c, true, true, &t->proj_out));
     return 0;
@@ -230,14 +249,16 @@ struct Fwd32 {
     }
     int prof_end() { if (e->prof && !dry) F_HIP(e, hipEventRecord(e->evs.back().b, s)); return 0; }
 
-    int gemm(const Conv& cv, int mode, const T32& x, const T32* x2, int OH, int OW, const float* temb, int temb_ld, const T32* res, T32* y) {
+    int gemm(const Conv& cv, int mode, const T32& x, const T32* x2, int OH, int OW, const float* temb, int temb_ld, const T32* res, T32* y, int epi = 0) {
         const int cin = x.C + (x2 ? x2->C : 0);
         if (cin != cv.cin) F_FAIL(e, "gemm32: channel mismatch %d vs %d", cin, cv.cin);
-        F_TRY(alloc(y, x.N, OH, OW, cv.cout));
+        const int cy = epi == 1 ? cv.cout / 2 : cv.cout;
+        F_TRY(alloc(y, x.N, OH, OW, cy));
         if (dry) return 0;
         GemmParams p;
+        p.epi = epi;
         p.X = x.p; p.X2 = x2 ? x2->p : nullptr; p.Wp = P(cv.w); p.bias = P(cv.b); p.temb = temb; p.res = res ? res->p : nullptr; p.Y = y->p;
-        p.Cout = cv.cout; p.Cin = cin; p.C1 = x.C; p.mode = mode; p.ldy = cv.cout; p.ldres = res ? res->C : 0; p.temb_ld = temb_ld;
+        p.Cout = cv.cout; p.Cin = cin; p.C1 = x.C; p.mode = mode; p.ldy = cy; p.ldres = res ? res->C : 0; p.temb_ld = temb_ld;
         if (mode == 0) { p.M = (int)x.rows(); p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M; }
         else { p.M = x.N * OH * OW; p.H = x.H; p.W = x.W; p.OH = OH; p.OW = OW; }
         F_TRY(prof_begin(0, 2.0 * (double)p.M * cv.cout * (double)((mode == 0 ? 1 : 9) * cin), p.M, cv.cout, (mode == 0 ? 1 : 9) * cin, mode));
@@ -291,7 +312,7 @@ struct Fwd32 {
     }
     int transformer(const Tfm& t, const T32& x, const int32_t* slots, T32* out) {       // Transformer2DModel + BasicTransformerBlock
         const int C = t.c, T = x.H * x.W, B = x.N;
-        T32 n, t0, ln, qkv, a, t1, q, t2, pr, ff, t3;
+        T32 n, t0, ln, qkv, a, t1, q, t2, ff, t3;
         F_TRY(groupnorm(t.gn, x, nullptr, ATTN_GN_EPS, false, &n));
         F_TRY(dense(t.proj_in, n, nullptr, nullptr, &t0));
         free(n);
@@ -315,11 +336,8 @@ struct Fwd32 {
         F_TRY(dense(t.o2, a, nullptr, &t1, &t2));
         free(a); free(t1);
         F_TRY(layernorm(t.ln3, t2, &ln));
-        F_TRY(dense(t.ff1, ln, nullptr, nullptr, &pr));
+        F_TRY(gemm(t.ff1, 0, ln, nullptr, x.H, x.W, nullptr, 0, nullptr, &ff, 1));        // GEGLU in the epilogue: [tokens][4C]
         free(ln);
-        F_TRY(alloc(&ff, B, x.H, x.W, 4 * C));
-        if (!dry) F_HIP(e, launch_geglu(pr.p, pr.rows(), 4 * C, ff.p, s));
-        free(pr);
         F_TRY(dense(t.ff2, ff, nullptr, &t2, &t3));
         free(ff); free(t2);
         F_TRY(dense(t.proj_out, t3, nullptr, &x, out));
