@@ -13,9 +13,16 @@ from collections import defaultdict
 
 root = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+what = sys.argv[3] if len(sys.argv) > 3 else "bench.py"          # e.g. "bench.py --workload dift" (the fp32 net)
 
 
 def family(name):
+    if "gemm32" in name:
+        return "gemm32"
+    if "attn32" in name:
+        return "attention32"
+    if "gn32" in name or "ln32" in name:
+        return "norms32"
     if "igemm" in name:
         return "igemm_family"
     if "attn_" in name:
@@ -32,16 +39,16 @@ counts = defaultdict(lambda: defaultdict(int))
 for f in glob.glob(root + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        if "dm::" not in name and "_ZN2dm" not in name:
+        if "dm::" not in name and "_ZN2dm" not in name and "dm32::" not in name and "_ZN4dm32" not in name:
             continue
         fam = family(name)
         sums[fam][r["Counter_Name"]] += float(r["Counter_Value"])
         counts[fam][r["Counter_Name"]] += 1
 
 out = {
-    "command": "rocprofv3 --pmc <set> --kernel-trace -f csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline "
+    "command": f"rocprofv3 --pmc <set> --kernel-trace -f csv -- python {what} --steps 1 --warmup 1 --no-cpu-baseline "
                "(separate process per counter set: FETCH_SIZE | WRITE_SIZE | SQ set A | SQ set B; each pass = "
-               f"{steps} steps: 1 warm-up + 1 timed + 2 of the grid-D2H leg)",
+               f"{steps} steps" + (": 1 warm-up + 1 timed + 2 of the grid-D2H leg)" if what == "bench.py" else ": 1 warm-up + 1 timed)"),
     "steps_in_pass": steps,
     "units": "FETCH_SIZE/WRITE_SIZE in KiB; FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads, "
              "MI355X_MICROARCH.md HBM section); WRITE_SIZE uncorrected; SQ_* as reported",

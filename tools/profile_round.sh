@@ -37,6 +37,16 @@ rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats32 -o stats -- python bench
     > $OUT/dift_f32_bench_under_rocprof.json 2>> $OUT/rocprof.err
 find $OUT/stats32 -name '*kernel_stats.csv' -exec cp {} $OUT/dift_f32_kernel_stats.csv \; ; rm -rf $OUT/stats32
 python tools/t_deviation_gpu.py 16 > $OUT/T_deviation_baseline_size_fp32.txt 2>> $OUT/bench.err
+# PMC passes of the fp32 DIFT run (gemm32 / attn32): the same four counter sets, folded per kernel family
+mkdir -p $OUT/d32
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+           "SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+    rocprofv3 --pmc $set --kernel-trace -f csv -d $OUT/d32/pmc_$i -o pmc -- python bench.py --workload dift --steps 1 --warmup 1 --no-cpu-baseline \
+        > /dev/null 2> $OUT/d32/pmc_$i.err
+    i=$((i+1))
+done
+python tools/pmc_to_json.py $OUT/d32 2 "bench.py --workload dift" > $OUT/dift_f32_pmc.json; rm -rf $OUT/d32
 for w in vae pixels; do python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline >> $OUT/side_workloads.jsonl 2>> $OUT/bench.err; done
 DM_BENCH_NOPROF=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_noprof.json 2>> $OUT/bench.err
 find $OUT/stats -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
