@@ -111,7 +111,8 @@ def main():
         noisy = sched.add_noise(x.expand(2, -1, -1, -1), eps, tt)
         unet(noisy, tt, c[:1].float().expand(2, -1, -1))
     hook.remove()
-    dift = dict(noisy=noisy.numpy(), t=np.int64(161), prompt=c[:1].numpy(), feat_fp32=grabbed["ft"].numpy().astype(np.float16))
+    dift = dict(noisy=noisy.numpy(), t=np.int64(161), prompt=c[:1].numpy(), feat_fp32=grabbed["ft"].numpy().astype(np.float16),
+                feat_f32_full=grabbed["ft"].numpy())           # unrounded: what the fp32 net (dm_f32_dift) is held to (r04)
     # the same tap on an odd latent (12 x 10 -> 6 x 5 -> 3 x 3 -> 2 x 2; up_blocks[1] ends at 6 x 5 through upsample_size)
     xo, eo, _, _ = (torch.from_numpy(a) for a in synth.synth_inputs(1, 2, 12, 10, latent_dtype=np.float32))
     hook = unet.up_blocks[1].register_forward_hook(lambda m, i, o: grabbed.__setitem__("ft_odd", o))
@@ -119,7 +120,8 @@ def main():
         noisy_o = sched.add_noise(xo.expand(2, -1, -1, -1), eo, tt)
         unet(noisy_o, tt, c[:1].float().expand(2, -1, -1))
     hook.remove()
-    dift.update(noisy_12x10=noisy_o.numpy(), feat_fp32_12x10=grabbed["ft_odd"].numpy().astype(np.float16))
+    dift.update(noisy_12x10=noisy_o.numpy(), feat_fp32_12x10=grabbed["ft_odd"].numpy().astype(np.float16),
+                feat_f32_full_12x10=grabbed["ft_odd"].numpy())
     np.savez_compressed(os.path.join(OUT, "dift_diffusers.npz"), diffusers_version=ver, **dift)
 
     # ---- VAE encoder moments (compute.py:91-93) ----------------------------------------------------------------

@@ -379,3 +379,41 @@ def test_f32_net_error_behaviour(sd15_weights_f16):
     out = e.unet(x, torch.tensor([5, 900]), torch.tensor([1, 0], dtype=torch.int32))          # and it still works afterwards
     assert out.shape == (2, 4, 8, 8) and torch.isfinite(out).all()
     e.close()
+
+
+def test_fp32_net_against_real_diffusers_fixture():
+    """The pin the image cannot provide: when tests/make_golden_with_diffusers.py has been run where diffusers==0.24.0 exists,
+    the fp32 net is compared with diffusers' OWN fp32 U-Net on the CPU — `unet(noisy, t, ctx).sample` at every size of the
+    fixture (incl. the odd latents) and the `up_blocks[1]` tap — at fp32 round-off, with the fixture's unrounded fp32 weights."""
+    import os
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    sp = os.path.join(golden, "score_diffusers.npz")
+    if not os.path.exists(sp):
+        pytest.skip("tests/golden/score_diffusers.npz absent: run tests/make_golden_with_diffusers.py where diffusers==0.24.0 is installed")
+    from diff_mining_amd.engine import UNetEngineF32
+    g = np.load(sp)
+    net = UNetEngineF32(0)
+    net.load_state_dict(synth.synth_state_dict(seed=0, dtype=np.float32))          # the weights the fixture was made with
+    for tag in ("8x8", "16x16", "12x10", "32x42", "32x48"):
+        if f"pred_fp32_cpu_{tag}" not in g:
+            continue
+        noisy, t, c = (torch.from_numpy(g[f"{k}_{tag}"]) for k in ("noisy_fp32_cpu", "t", "c"))
+        n = noisy.shape[0] // c.shape[0]
+        net.set_prompts(c.float())
+        pred = net.unet(noisy, torch.cat([t] * c.shape[0]), torch.arange(c.shape[0], dtype=torch.int32).repeat_interleave(n)).cpu()
+        r = U.rel_l2(pred, torch.from_numpy(g[f"pred_fp32_cpu_{tag}"]))
+        print(f"fp32 net vs diffusers {str(g['diffusers_version'])} [{tag}]: eps_hat rel-L2 {r:.2e}")
+        assert r < TOL_E2E, tag
+    dp = os.path.join(golden, "dift_diffusers.npz")
+    if os.path.exists(dp):
+        d = np.load(dp)
+        for sfx in ("", "_12x10"):
+            if f"feat_f32_full{sfx}" not in d:
+                continue
+            noisy = torch.from_numpy(d[f"noisy{sfx}"])
+            net.set_prompts(torch.from_numpy(d["prompt"]).float())
+            feat, _ = net.dift(noisy, torch.tensor(int(d["t"])), torch.zeros(noisy.shape[0], dtype=torch.int32), 1)
+            r = U.rel_l2(feat.cpu(), torch.from_numpy(d[f"feat_f32_full{sfx}"]))
+            print(f"fp32 net vs diffusers DIFT tap{sfx}: rel-L2 {r:.2e}")
+            assert r < TOL_E2E
+    net.close()
