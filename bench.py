@@ -264,18 +264,15 @@ def main():
 def score_deviation(sd, eng, x0, eps, t, c, loss, n_img, dev):
     """north_star ends on "<= 1e-3 score deviation from reference": image 0 of the timed step (its 10 draws x 2 prompts, the very
     losses the step produced) against the EXACT-fp32 evaluation of the same U-Net on the same inputs — the fp32 net (dm_f32_*,
-    product code, 2-4e-6 from the CPU oracle's autocast=False arithmetic: tests/test_gpu_f32.py) with the reference's fp32
-    add_noise / MSE around it (compute.py:99-101).  Outside the timed region; the CPU oracle cannot reach this size."""
-    from diff_mining_amd.dift import scheduler_alphas_cumprod
+    product code, 2-4e-6 from the CPU oracle's autocast=False arithmetic: tests/test_gpu_f32.py): dm_f32_score = compute.py:95-102 with no
+    autocast.  Outside the timed region; the CPU oracle cannot reach this size."""
     from diff_mining_amd.engine import UNetEngineF32
     t0 = time.perf_counter()
     net = UNetEngineF32(dev.index or 0)
     net.load_state_dict(sd)
     net.set_prompts(c.float())
-    a = scheduler_alphas_cumprod().to(dev)[t].view(N_DRAWS, 1, 1, 1)
-    e32 = eps.float()
-    noisy = (a ** 0.5) * x0.float() + ((1 - a) ** 0.5) * e32
-    ref = torch.stack([(net.unet(noisy, t, torch.full((N_DRAWS,), k, dtype=torch.int32)) - e32) ** 2 for k in range(N_COND)], dim=1)
+    ref = net.score_conds(x0, eps, t, N_COND)                     # dm_f32_score: fp32 add_noise -> U-Net -> squared error, cond-major rows
+    ref = ref.view(N_COND, N_DRAWS, 4, LAT, LAT).transpose(0, 1)
     net.close()
     got = loss.view(N_COND, n_img, N_DRAWS, 4, LAT, LAT)[:, 0].transpose(0, 1).float()      # [N,2,4,h,w] of image 0 (cond 0 = c, 1 = null)
     T = (got[:, 1] - got[:, 0]).double().mean().item()

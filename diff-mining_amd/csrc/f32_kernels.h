@@ -51,6 +51,10 @@ hipError_t launch_timestep_embed(const int64_t* t, int B, int dim, float* out, h
 hipError_t launch_conv_in(const float* x, const float* w, const float* bias, int B, int Cin, int H, int W, int Cout, float* y, hipStream_t s);
 // conv_out: NHWC [B,H,W,C] (x) 3x3 pad 1 -> NCHW [B,Cout<=8,H,W]; w packed [Cout][9*C] k = (tap, c)
 hipError_t launch_conv_out(const float* x, const float* w, const float* bias, int B, int H, int W, int C, int Cout, float* y, hipStream_t s);
+// scheduler.add_noise in fp32: out[b] = sa[t[b]] * x[x_index ? x_index[b] : b] + sb[t[b]] * eps[b]; `per` elements per sample
+hipError_t launch_add_noise(const float* x, const int32_t* x_index, const float* eps, const int64_t* t, const float* sa, const float* sb,
+                            int B, long long per, float* out, hipStream_t s);
+hipError_t launch_sqerr(const float* pred, const float* eps, long long n, float* out, hipStream_t s);      // (pred - eps)^2
 hipError_t launch_nhwc_to_nchw(const float* X, int N, int HW, int C, float* Y, hipStream_t s);
 // quant_conv (1x1, 8 -> 8) on Hm [B*HW][8] + `draws` posterior samples per image * scaling (NCHW outputs: latent [B*draws,4,HW], moments [B,8,HW])
 hipError_t launch_posterior(const float* Hm, const float* qw, const float* qb, const float* noise, int B, int draws, int HW, float scaling,

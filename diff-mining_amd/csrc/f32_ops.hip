@@ -359,6 +359,26 @@ __global__ void posterior32_kernel(const float* Hm, const float* qw, const float
     }
 }
 
+// scheduler.add_noise in fp32 (compute.py:99 / dift.py:190): noisy[b] = sqrt(acp[t[b]]) * x[xi[b]] + sqrt(1 - acp[t[b]]) * eps[b]
+__global__ void add_noise32_kernel(const float* x, const int32_t* x_index, const float* eps, const int64_t* t, const float* sa, const float* sb,
+                                   int B, long long per, float* out) {
+    const long long total = (long long)B * per;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per);
+        const long long r = i - (long long)b * per;
+        const int xi = x_index ? x_index[b] : b;
+        long long tt = t[b]; tt = tt < 0 ? 0 : (tt > 999 ? 999 : tt);
+        out[i] = sa[tt] * x[(long long)xi * per + r] + sb[tt] * eps[i];
+    }
+}
+// F.mse_loss(pred, eps, reduction='none') (compute.py:101)
+__global__ void sqerr32_kernel(const float* pred, const float* eps, long long n, float* out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float d = pred[i] - eps[i];
+        out[i] = d * d;
+    }
+}
+
 inline unsigned grid_for(long long n, int block = 256) {
     long long g = (n + block - 1) / block;
     return (unsigned)(g < 1 ? 1 : (g > 65536 * 16 ? 65536 * 16 : g));
@@ -415,6 +435,15 @@ hipError_t launch_posterior(const float* Hm, const float* qw, const float* qb, c
                             float* latent, float* moments, hipStream_t s) {
     const long long total = (long long)B * draws * HW;
     hipLaunchKernelGGL(posterior32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Hm, qw, qb, noise, B, draws, HW, scaling, latent, moments);
+    return hipGetLastError();
+}
+hipError_t launch_add_noise(const float* x, const int32_t* x_index, const float* eps, const int64_t* t, const float* sa, const float* sb,
+                            int B, long long per, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(add_noise32_kernel, dim3(grid_for((long long)B * per)), dim3(256), 0, s, x, x_index, eps, t, sa, sb, B, per, out);
+    return hipGetLastError();
+}
+hipError_t launch_sqerr(const float* pred, const float* eps, long long n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(sqerr32_kernel, dim3(grid_for(n)), dim3(256), 0, s, pred, eps, n, out);
     return hipGetLastError();
 }
 hipError_t launch_nhwc_to_nchw(const float* X, int N, int HW, int C, float* Y, hipStream_t s) {

@@ -30,7 +30,7 @@ SYMBOLS = [
     "dm_f32_create", "dm_f32_destroy", "dm_f32_last_error", "dm_f32_load_weight", "dm_f32_finalize", "dm_f32_set_prompts",
     "dm_f32_unet_forward", "dm_f32_dift", "dm_f32_prof_enable", "dm_f32_prof_read", "dm_f32_memory", "dm_f32_op_gemm",
     "dm_f32_op_attention", "dm_f32_op_groupnorm", "dm_f32_op_layernorm", "dm_f32_load_vae_weight", "dm_f32_finalize_vae",
-    "dm_f32_vae_encode",
+    "dm_f32_vae_encode", "dm_f32_score",
 ]
 
 
@@ -124,6 +124,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         lib.dm_f32_load_vae_weight.argtypes = [vp, C.c_char_p, vp, i32, C.POINTER(i64), i32]
         lib.dm_f32_finalize_vae.argtypes = [vp]
         lib.dm_f32_vae_encode.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.c_float, vp, vp, vp]
+        lib.dm_f32_score.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     if path is None:
         _lib = lib
     return lib
@@ -651,6 +652,38 @@ class UNetEngineF32:
         self._check(self.lib.dm_f32_unet_forward(self._h, C.c_void_p(sample.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(s.data_ptr()),
                                                  B, h, w, C.c_void_p(out.data_ptr()), self._stream()), "dm_f32_unet_forward")
         return out
+
+    def score(self, x, eps, t, slots, x_index=None):
+        """SD.compute_loss (compute.py:95-102) with no autocast: fp32 add_noise, fp32 U-Net, fp32 squared error -> [B,4,h,w] fp32.
+        The exact-arithmetic yardstick of `UNetEngine.score`."""
+        torch = self._torch
+        x = x.to(self.device, torch.float32).contiguous()
+        eps = eps.to(self.device, torch.float32).contiguous()
+        B, _, h, w = eps.shape
+        t, s = self._tsl(t, slots, B)
+        xi = None
+        if x_index is not None:
+            xi = torch.as_tensor(x_index, device=self.device).to(torch.int32).contiguous()
+            assert xi.shape == (B,)
+        elif x.shape[0] != B:
+            assert x.shape[0] == 1, "x must have 1 or B rows when x_index is not given"
+            xi = torch.zeros(B, dtype=torch.int32, device=self.device)
+        out = torch.empty(B, 4, h, w, dtype=torch.float32, device=self.device)
+        self._check(self.lib.dm_f32_score(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(xi.data_ptr()) if xi is not None else None,
+                                          C.c_void_p(eps.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(s.data_ptr()), B, x.shape[0], h, w,
+                                          C.c_void_p(out.data_ptr()), self._stream()), "dm_f32_score")
+        return out
+
+    def score_conds(self, x, eps, t, n_cond: int, x_index=None):
+        """Each of the U draws (x, eps, t) under prompts 0..n_cond-1 -> loss [n_cond*U,4,h,w] fp32, cond-major (row k*U+i), like
+        `UNetEngine.score_conds`."""
+        torch = self._torch
+        U = eps.shape[0]
+        t = torch.as_tensor(t).reshape(-1)
+        xi = None if x_index is None else torch.as_tensor(x_index).reshape(-1).repeat(n_cond)
+        xx = x if (x.shape[0] == 1 or x_index is not None) else x.repeat(n_cond, 1, 1, 1)
+        slots = torch.arange(n_cond, dtype=torch.int32).repeat_interleave(U)
+        return self.score(xx, eps.repeat(n_cond, 1, 1, 1), t.repeat(n_cond), slots, x_index=xi)
 
     def dift(self, noisy, t, slots, up_ft_index: int = 1, ensemble: Optional[int] = None):
         """MyUNet2DConditionModel.forward tap (dift.py:24-169) in the reference's fp32.  Returns (features fp32 [B,C,h',w'],

@@ -333,6 +333,11 @@ int dm_f32_unet_forward(dm_f32_net* e, const void* sample_dev, const int64_t* t_
                         int h, int w, void* out_dev, void* stream);
 int dm_f32_dift(dm_f32_net* e, const void* noisy_dev, const int64_t* t_dev, const int32_t* slot_dev, int batch, int h, int w,
                 int up_ft_index, void* feat_out_dev, void* mean_out_dev, int ensemble, void* stream);
+/* SD.compute_loss (compute.py:95-102) with NO autocast: fp32 add_noise (x_dev [n_x,4,h,w], x_index_dev [batch] or NULL for identity,
+ * eps_dev [batch,4,h,w], t_dev [batch]), fp32 U-Net, fp32 squared error -> loss_out_dev [batch,4,h,w] fp32: the exact-arithmetic
+ * yardstick of dm_score (bench.py's `score_deviation`, tools/t_deviation_gpu.py). */
+int dm_f32_score(dm_f32_net* e, const void* x_dev, const int32_t* x_index_dev, const void* eps_dev, const int64_t* t_dev,
+                 const int32_t* slot_dev, int batch, int n_x, int h, int w, void* loss_out_dev, void* stream);
 /* optional AutoencoderKL encoder in fp32: `pipe.vae.encode(img_tensor).latent_dist.sample() * scaling_factor` of the featuriser
  * (dift.py:187) — image_dev [batch,3,H,W] fp32 in [-1,1]; noise_dev [batch*draws_per_image,4,H/8,W/8] fp32 N(0,1) draws or NULL
  * (posterior mode); latent_dev [batch*draws_per_image,4,H/8,W/8] fp32 and / or moments_dev [batch,8,H/8,W/8] fp32 (either may be

@@ -230,20 +230,12 @@ def test_sdfeaturizer_fp32_is_the_default_arithmetic(net32, sd15_weights_f16, sd
 
 
 def _grid32(net32, x, c, noises, ts):
-    """D.compute_losses (compute.py:134-160) in exact fp32 on the GPU: the reference's add_noise / MSE in torch fp32 around the
-    fp32 U-Net -> [N,2,4,h,w] fp32 (cond 0 = c, 1 = null) — what the CPU oracle computes with autocast=False, at any size."""
-    dev = net32.device
+    """D.compute_losses (compute.py:134-160) in exact fp32 on the GPU: dm_f32_score = the reference's add_noise -> U-Net -> squared error
+    with no autocast -> [N,2,4,h,w] fp32 (cond 0 = c, 1 = null) — what the CPU oracle computes with autocast=False, at any size."""
     N = noises.shape[0]
-    acp = R.alphas_cumprod().to(dev)
-    xs, eps, t = x.to(dev).float().expand(N, -1, -1, -1), noises.to(dev).float(), ts.to(dev)
-    a = acp[t].view(N, 1, 1, 1)
-    noisy = (a ** 0.5) * xs + ((1 - a) ** 0.5) * eps
     net32.set_prompts(c.float())
-    out = []
-    for k in range(2):
-        eh = net32.unet(noisy, t, torch.full((N,), k, dtype=torch.int32))
-        out.append((eh - eps) ** 2)
-    return torch.stack(out, dim=1)
+    loss = net32.score_conds(x, noises, ts, 2)                     # [2N,4,h,w], cond-major
+    return loss.view(2, N, *loss.shape[1:]).transpose(0, 1)
 
 
 def test_gpu_fp32_ground_truth_agrees_with_the_cpu_oracle(net32, sd15_weights_torch):

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """T(x|c) of the fp16 engine against the EXACT-fp32 evaluation of the same U-Net at the BASELINE configuration itself
 (configs[1]: 64 x 64 latent, N = 10 draws x 2 prompts per image), both on the GPU: the fp32 side is the fp32 net (dm_f32_*,
-checked against the CPU oracle's autocast=False arithmetic by tests/test_gpu_f32.py) with the reference's fp32 add_noise / MSE
-around it (compute.py:99-101).  tools/t_deviation.py is the same table against the CPU oracle, which reaches 32 x 32 only.
+checked against the CPU oracle's autocast=False arithmetic by tests/test_gpu_f32.py): dm_f32_score = compute.py:95-102
+with no autocast.  tools/t_deviation.py is the same table against the CPU oracle, which reaches 32 x 32 only.
 
     python tools/t_deviation_gpu.py [n_images] > profiles/r04_T_deviation_baseline_size_fp32.txt
 """
@@ -17,7 +17,6 @@ import torch  # noqa: E402
 
 from diff_mining_amd import synth  # noqa: E402
 from diff_mining_amd.engine import UNetEngine, UNetEngineF32  # noqa: E402
-from diff_mining_amd.dift import scheduler_alphas_cumprod  # noqa: E402
 from diff_mining_amd.typicality import TypicalityScorer  # noqa: E402
 
 
@@ -32,17 +31,14 @@ def main():
     sc = TypicalityScorer(e16, seed=42, N=N, t_min=0.1, t_max=0.7)
     xs, _, _, c = synth.synth_inputs(n_img, 1, hw, hw, latent_dtype=np.float32)
     xs, c = torch.from_numpy(xs), torch.from_numpy(c)
-    acp = scheduler_alphas_cumprod().to(dev)
     e32.set_prompts(c.float())
     rows = []
     for i in range(n_img):
         x = xs[i:i + 1]
         noises, ts = sc.draw(x.shape)
         grid = sc.compute_losses(x, c, noises=noises, timesteps=ts, to_host=False).float()       # [N,2,4,h,w] (fp16 values)
-        eps, t = noises.to(dev).float(), ts.to(dev)
-        a = acp[t].view(N, 1, 1, 1)
-        noisy = (a ** 0.5) * x.to(dev).float() + ((1 - a) ** 0.5) * eps
-        ref = torch.stack([(e32.unet(noisy, t, torch.full((N,), k, dtype=torch.int32)) - eps) ** 2 for k in range(2)], dim=1)
+        ref = e32.score_conds(x, noises, ts, 2)                                          # dm_f32_score, cond-major rows
+        ref = ref.view(2, N, 4, hw, hw).transpose(0, 1)
         T = (grid[:, 1] - grid[:, 0]).mean().item()
         T32 = (ref[:, 1] - ref[:, 0]).double().mean().item()
         ml = ref.mean().item()
