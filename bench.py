@@ -91,6 +91,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
     if world > 1:
+        # librccl prints a banner ("Librccl path : ...") on the C-level stdout (seen in tests/test_gpu_rccl.py on the GPU box; with a
+        # pipe it is flushed at exit, i.e. AFTER the JSON line).  The contract is ONE JSON line on stdout: file descriptor 1 goes to
+        # stderr for every native library, Python's sys.stdout keeps a private duplicate of the real stdout.
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
+        sys.stdout = os.fdopen(real_stdout, "w", buffering=1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if not STUB:
