@@ -60,12 +60,12 @@ inline void launch_timed(F kernel, const dim3& grid, const dim3& block, size_t l
 
 // Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of
 // the same name in upper case with a DM_ prefix (DM_IGEMM_PERSIST=0 ...), changeable through dm_set_option().
-enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_TAP_REUSE, OPT_COUNT };
+enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_TAP_REUSE, OPT_UP_FOLD, OPT_COUNT };
 int option(Option o);                       // engine.hip
 int set_option(const char* name, int value);   // 0 on success
 
 // ---- K1/K2/K3: implicit-GEMM on MFMA (conv3x3 s1/s2/upsampled, 1x1 conv, linear) -------------
-enum IGemmMode { IG_DENSE = 0, IG_CONV3 = 1, IG_CONV3_S2 = 2, IG_CONV3_UP = 3, IG_CONV3_S2P0 = 4 };
+enum IGemmMode { IG_DENSE = 0, IG_CONV3 = 1, IG_CONV3_S2 = 2, IG_CONV3_UP = 3, IG_CONV3_S2P0 = 4, IG_CONV2_UP4 = 5 };
 enum IGemmEpi { EPI_PLAIN = 0, EPI_GEGLU = 1 };
 
 struct IGemmParams {
@@ -124,6 +124,17 @@ constexpr int IGEMM_TILE_CTR_INTS = 8 * 32 + 32;
 // igemm_pers_tile.h and igemm_tile.h, so the two tiles stay bit-identical.
 constexpr float LN_REDO_RATIO2 = 256.0f;       // |mean| / std > 16
 hipError_t launch_igemm(const IGemmParams& p, hipStream_t s);
+// Upsample2D (nearest, exact 2x) + conv3x3 as four 2x2 convolutions on the source grid (igemm_pers_up.hip): X [N][H][W][Cin],
+// Wp = fold_upconv_weights() [4][Cout][4 Cin], Y [N][2H][2W][Cout]; p.mode = IG_CONV2_UP4, p.H = p.OH = H, p.W = p.OW = W, p.M = N H W.
+// hipErrorInvalidValue for shapes it does not take (Cout % 320, Cin % 64, 32-bit offsets): the caller keeps the unfolded layer.
+hipError_t launch_igemm_pers_up4(const IGemmParams& p, hipStream_t s);
+inline bool igemm_up4_ok(int N, int H, int W, int Cin, int Cout) {
+    return Cout % 320 == 0 && Cin % 64 == 0 && H >= 1 && W >= 1 && H <= 511 && W <= 511 && N <= 8191 && (long long)N * H * W >= 2 &&
+           (long long)N * H * W * Cin < (1LL << 31) && 16LL * Cout * Cin < (1LL << 32);
+}
+// host: conv weight [Cout][Cin][3][3] fp16 -> [4 = py * 2 + px][Cout][(a * 2 + b) * Cin + ci] fp16, each entry the fp32 sum of the 1, 2 or 4
+// taps (dy, dx) of the 3x3 kernel that read source pixel (y - 1 + py + a, x - 1 + px + b), rounded to fp16 once
+void fold_upconv_weights(const f16* w_oihw, int cout, int cin, f16* out);
 // number of k parts for a layer with `spatial` output positions per sample (1 = no split); batch independent;
 // the caller provides the workspace
 int igemm_splitk_parts(const IGemmParams& p, int spatial);

@@ -64,7 +64,8 @@ struct TfmW {
     LnFold qkv_ln, q2_ln, ff1_ln;       // LN1 -> to_q/k/v, LN2 -> to_q (cross), LN3 -> GEGLU projection
     int c = 0; int layer = 0;
 };
-struct UpBlockW { ResW res[3]; TfmW tf[3]; bool attn = false; ConvW up; bool has_up = false; };
+struct UpBlockW { ResW res[3]; TfmW tf[3]; bool attn = false; ConvW up; bool has_up = false;
+                  ConvW up4; };   // up4: the up-sampler's convolution folded onto the source grid (fold_upconv_weights), w == nullptr if not built
 struct DownBlockW { ResW res[2]; TfmW tf[2]; bool attn = false; ConvW down; bool has_down = false; };
 
 // SDv1.5 VAE encoder (block_out_channels 128/256/512/512, two resnets per block, no time embedding)
@@ -98,7 +99,7 @@ struct Tensor {            // NHWC activation in the arena
     long long rows() const { return (long long)N * H * W; }
 };
 
-struct ProfEv { std::vector<hipEvent_t> pairs; double flops; int kind; int M = 0, N = 0, K = 0, mode = 0; };      // (start, stop) per dispatch
+struct ProfEv { std::vector<hipEvent_t> pairs; double flops; int kind; int M = 0, N = 0, K = 0, mode = 0; double folded = 0; };   // folded: MACs x 2 of the layer's definition that the launch does not execute      // (start, stop) per dispatch
 
 }  // namespace
 
@@ -161,6 +162,7 @@ struct dm_engine {
     std::vector<ProfEv> prof_ev;
     std::vector<hipEvent_t> ev_pool;
     double prof_ms[2] = {0, 0}, prof_flops[2] = {0, 0};
+    double prof_folded = 0, prof_folded_last = 0;          // nominal-minus-executed FLOPs of the folded up-samplers (dm_prof_read_folded)
     long long prof_n[2] = {0, 0};
 
     hipStream_t stream = nullptr;
@@ -269,6 +271,17 @@ int pack_conv3(Packer& P, const std::string& name, int cout, int cin, ConvW* o) 
     o->w = as_ptr(P.put(pk.data(), pk.size() * 2));
     o->cin = cin; o->cout = cout; o->k = 3;
     return pack_bias(P, name, cout, &o->b);
+}
+
+// Upsample2D.conv folded onto the source grid: four 2x2 kernels (dm_kernels.h); shares the bias of the packed 3x3 layer `full`
+int pack_upconv4(Packer& P, const std::string& name, int cout, int cin, const ConvW& full, ConvW* o) {
+    HostTensor* w = P.get(name + ".weight", {cout, cin, 3, 3});
+    if (!w) return 1;
+    std::vector<f16> pk((size_t)16 * cout * cin);
+    fold_upconv_weights(w->data.data(), cout, cin, pk.data());
+    o->w = as_ptr(P.put(pk.data(), pk.size() * 2));
+    o->cin = cin; o->cout = cout; o->k = 2; o->b = full.b;
+    return 0;
 }
 
 int pack_dense(Packer& P, const std::string& name, int cout, int cin, bool conv1x1, bool bias, ConvW* o) {
@@ -559,6 +572,24 @@ struct Fwd {
             DM_TRY(prof_end());
         }
         if (parts > 1) free_raw(poff);
+        return 0;
+    }
+    // Upsample2D (nearest 2x) + conv3x3 as four 2x2 convolutions on x's own grid (igemm_pers_up.hip): y [N][2H][2W][cout].
+    // The FLOPs booked are the EXECUTED ones (4 taps): 4/9 of the layer's nominal count.
+    int upconv4(const ConvW& cv, const Tensor& x, Tensor* y) {
+        if (x.C != cv.cin) DM_FAIL(e, "upconv4: channel mismatch %d vs %d", x.C, cv.cin);
+        DM_TRY(alloc(y, x.N, 2 * x.H, 2 * x.W, cv.cout));
+        IGemmParams p;
+        p.X = x.p; p.X2 = nullptr; p.Wp = cv.w; p.bias = cv.b; p.temb = nullptr; p.res = nullptr; p.Y = y->p;
+        p.Cout = cv.cout; p.Cin = x.C; p.C1 = x.C; p.mode = IG_CONV2_UP4; p.epi = EPI_PLAIN; p.ldy = cv.cout; p.ldres = 0; p.temb_ld = 0;
+        p.M = x.N * x.H * x.W; p.H = x.H; p.W = x.W; p.OH = x.H; p.OW = x.W;
+        p.tile_ctr = e->tile_ctr;
+        if (!dry) {
+            DM_TRY(prof_begin(0, 2.0 * 4.0 * (double)p.M * cv.cout * 4.0 * (double)x.C, 4 * p.M, cv.cout, 4 * x.C, IG_CONV2_UP4));
+            if (e->prof) e->prof_ev.back().folded = 2.0 * 4.0 * (double)p.M * cv.cout * 5.0 * (double)x.C;     // 9 - 4 taps
+            DM_HIP(e, launch_igemm_pers_up4(p, s));
+            DM_TRY(prof_end());
+        }
         return 0;
     }
     int dense(const ConvW& cv, const Tensor& x, const Tensor* x2, const Tensor* res, int epi, Tensor* y) {
@@ -914,7 +945,12 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
             int OH = cur.H * 2, OW = cur.W * 2;
             if (fwd_up_size && !skips.empty()) { OH = skips.back().H; OW = skips.back().W; }
             Tensor upc;
-            DM_TRY(F.igemm(u.up, IG_CONV3_UP, cur, nullptr, OH, OW, nullptr, 0, nullptr, EPI_PLAIN, &upc));
+            // exact 2x (every latent whose side is a multiple of 8): four 2x2 convolutions on the source grid, 4/9 of the MACs
+            // (option up_fold; a property of the layer and the sample geometry, never of the batch)
+            if (option(OPT_UP_FOLD) != 0 && u.up4.w && OH == 2 * cur.H && OW == 2 * cur.W && igemm_up4_ok(cur.N, cur.H, cur.W, cur.C, u.up4.cout))
+                DM_TRY(F.upconv4(u.up4, cur, &upc));
+            else
+                DM_TRY(F.igemm(u.up, IG_CONV3_UP, cur, nullptr, OH, OW, nullptr, 0, nullptr, EPI_PLAIN, &upc));
             F.free(cur);
             cur = upc;
         }
@@ -1081,7 +1117,7 @@ int ensure_arena_for(dm_engine* e, hipStream_t s, const std::vector<long long>& 
 
 std::vector<long long> fwd_key(const FwdArgs& A) {
     return {0, A.B, A.H, A.W, A.n_cond, A.up_ft_index, A.add_noise ? 1 : 0, A.loss ? 1 : 0, A.pred ? 1 : 0, A.feat ? 1 : 0,
-            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD), option(OPT_FF_FOLD)};
+            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD), option(OPT_FF_FOLD), option(OPT_UP_FOLD)};
 }
 
 int ensure_arena(dm_engine* e, const FwdArgs& A, hipStream_t s) {
@@ -1167,7 +1203,7 @@ namespace {
 struct OptDef { const char* name; const char* env; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
-    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1}, {"tap_reuse", "DM_TAP_REUSE", 1},
+    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1}, {"tap_reuse", "DM_TAP_REUSE", 1}, {"up_fold", "DM_UP_FOLD", 1},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<int> g_opt_init{0};
@@ -1182,6 +1218,26 @@ void opts_init() {
 }  // namespace
 
 int option(Option o) { opts_init(); return g_opt[o].load(std::memory_order_relaxed); }
+
+void fold_upconv_weights(const f16* w, int cout, int cin, f16* out) {
+    // parity class p (0 / 1) of an output coordinate, 2x2 tap a (0 / 1): the 3x3 taps d whose up-sampled coordinate 2 y + p + d - 1
+    // falls on source coordinate y - 1 + p + a.   p = 0: a = 0 <- {0}, a = 1 <- {1, 2};   p = 1: a = 0 <- {0, 1}, a = 1 <- {2}
+    static const int lo[2][2] = {{0, 1}, {0, 2}}, hi[2][2] = {{0, 2}, {1, 2}};
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            f16* o = out + (size_t)(py * 2 + px) * cout * 4 * cin;
+            for (int co = 0; co < cout; ++co)
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b)
+                        for (int ci = 0; ci < cin; ++ci) {
+                            const f16* k9 = w + ((size_t)co * cin + ci) * 9;
+                            float acc = 0.f;                  // <= 4 fp16 terms: exact in fp32
+                            for (int dy = lo[py][a]; dy <= hi[py][a]; ++dy)
+                                for (int dx = lo[px][b]; dx <= hi[px][b]; ++dx) acc += (float)k9[dy * 3 + dx];
+                            o[(size_t)co * 4 * cin + (size_t)(a * 2 + b) * cin + ci] = (f16)acc;
+                        }
+        }
+}
 int set_option(const char* name, int value) {
     opts_init();
     for (int i = 0; i < OPT_COUNT; ++i)
@@ -1315,7 +1371,10 @@ int dm_engine_finalize(dm_engine* e) {
                 if (u.attn) DM_TRY(pack_tfm(P, "up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), o, &u.tf[j], e));
             }
             u.has_up = (i != NB - 1);
-            if (u.has_up) DM_TRY(pack_conv3(P, "up_blocks." + std::to_string(i) + ".upsamplers.0.conv", o, o, &u.up));
+            if (u.has_up) {
+                DM_TRY(pack_conv3(P, "up_blocks." + std::to_string(i) + ".upsamplers.0.conv", o, o, &u.up));
+                if (o % 320 == 0) DM_TRY(pack_upconv4(P, "up_blocks." + std::to_string(i) + ".upsamplers.0.conv", o, o, u.up, &u.up4));
+            }
             prev = o;
         }
     }
@@ -1355,7 +1414,7 @@ int dm_engine_finalize(dm_engine* e) {
         for (int j = 0; j < LAYERS; ++j) { rebase_res(e->down[i].res[j], base); if (e->down[i].attn) rebase_tfm(e->down[i].tf[j], base); }
         rebase_conv(e->down[i].down, base);
         for (int j = 0; j < LAYERS + 1; ++j) { rebase_res(e->up[i].res[j], base); if (e->up[i].attn) rebase_tfm(e->up[i].tf[j], base); }
-        rebase_conv(e->up[i].up, base);
+        rebase_conv(e->up[i].up, base); rebase_conv(e->up[i].up4, base);
     }
     rebase_res(e->mid_res[0], base); rebase_res(e->mid_res[1], base); rebase_tfm(e->mid_tf, base);
     // (Wp W2) of every transformer block into the first 4C columns of its fused rows: Y[o][j] = sum_c Wp[o][c] W2^T[j][c];
@@ -1867,6 +1926,12 @@ int dm_normalize_map(dm_engine* e, const void* map_dev, int64_t n, int mode, voi
     return 0;
 }
 
+int dm_prof_read_folded(dm_engine* e, double* igemm_flops_folded) {
+    if (!e || !igemm_flops_folded) return 1;
+    *igemm_flops_folded = e->prof_folded_last;
+    return 0;
+}
+
 int dm_prof_enable(dm_engine* e, int on) {
     if (!e) return 1;
     e->prof = on != 0;
@@ -1889,7 +1954,7 @@ int dm_prof_read(dm_engine* e, double* igemm_ms, double* igemm_flops, int64_t* i
             ms += d;
         }
         if (dump) fprintf(dump, "%d %d %d %d %d %.0f %.6f\n", ev.kind, ev.M, ev.N, ev.K, ev.mode, ev.flops, ms);
-        e->prof_ms[ev.kind] += ms; e->prof_flops[ev.kind] += ev.flops; e->prof_n[ev.kind] += 1;
+        e->prof_ms[ev.kind] += ms; e->prof_flops[ev.kind] += ev.flops; e->prof_n[ev.kind] += 1; e->prof_folded += ev.folded;
         for (hipEvent_t h : ev.pairs) e->ev_pool.push_back(h);
     }
     if (dump) fclose(dump);
@@ -1901,6 +1966,7 @@ int dm_prof_read(dm_engine* e, double* igemm_ms, double* igemm_flops, int64_t* i
     if (attn_flops) *attn_flops = e->prof_flops[1];
     if (attn_launches) *attn_launches = e->prof_n[1];
     e->prof_ms[0] = e->prof_ms[1] = 0; e->prof_flops[0] = e->prof_flops[1] = 0; e->prof_n[0] = e->prof_n[1] = 0;
+    e->prof_folded_last = e->prof_folded; e->prof_folded = 0;
     return 0;
 }
 
@@ -2007,6 +2073,21 @@ int dm_op_igemm_shortcut(void* stream, const void* X, const void* X3, const void
     if (mode == IG_DENSE) { p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M; } else { p.H = H; p.W = W; p.OH = H; p.OW = W; }
     p.X3 = (const f16*)X3; p.X4 = (const f16*)X4; p.C3 = C3; p.Csc = C3 + C4;
     return launch_igemm(p, (hipStream_t)stream) == hipSuccess ? 0 : 1;
+}
+
+int dm_op_fold_upconv_weights(const void* w_oihw_f16_host, int Cout, int Cin, void* out_f16_host) {
+    if (!w_oihw_f16_host || !out_f16_host || Cout <= 0 || Cin <= 0) return 1;
+    fold_upconv_weights((const f16*)w_oihw_f16_host, Cout, Cin, (f16*)out_f16_host);
+    return 0;
+}
+
+int dm_op_upconv_folded(void* stream, const void* X, const void* W4, const void* bias, void* Y, int N, int H, int W, int Cin, int Cout) {
+    if (!igemm_up4_ok(N, H, W, Cin, Cout)) return 1;
+    IGemmParams p;
+    p.X = (const f16*)X; p.X2 = nullptr; p.Wp = (const f16*)W4; p.bias = (const f16*)bias; p.temb = nullptr; p.res = nullptr; p.Y = (f16*)Y;
+    p.Cout = Cout; p.Cin = Cin; p.C1 = Cin; p.mode = IG_CONV2_UP4; p.epi = EPI_PLAIN; p.ldy = Cout; p.ldres = 0; p.temb_ld = 0;
+    p.M = N * H * W; p.H = H; p.W = W; p.OH = H; p.OW = W;
+    return launch_igemm_pers_up4(p, (hipStream_t)stream) == hipSuccess ? 0 : 1;
 }
 
 int dm_op_groupnorm_conv1x1(void* stream, const void* X, int N, int HW, int C, int G, float eps, const float* gamma,

@@ -152,7 +152,13 @@ constexpr int EPI_PARTIAL = 2;
 // tensor is never written or read back as a residual, its MACs run at the convolution's rate, the sum is rounded once), and the
 // transformer blocks' `ff.net.2` + residual + `proj_out` chain as one GEMM (dense mode: (Wp W2) ff + Wp t2 + x).  Template variant in a
 // translation unit of its own (igemm_pers_sc.hip).
-template <int EPI, bool LN, int EXTRA, bool WS = false, bool SC = false>
+// UP4 (r04): Upsample2D (nearest 2x) + its 3x3 convolution as FOUR 2x2 convolutions on the low-resolution source, one per output
+// parity class (py, px): output pixel (2 y + py, 2 x + px) sees source rows y - 1 + py + {0, 1} and columns x - 1 + px + {0, 1}, and
+// the taps of the 3x3 kernel that land on one source pixel are pre-summed (engine.hip fold_upconv_weights): 4 instead of 9 k taps.
+// mode IG_CONV2_UP4, H x W = OH x OW = the SOURCE grid, M = N H W rows PER PHASE; the tile stream walks phase-major
+// (4 x tiles-per-phase tiles), weights Wp [4][Cout][4 Cin], the epilogue scatters a row to its pixel of the [N][2H][2W] output.
+// Template variant in a translation unit of its own (igemm_pers_up.hip).
+template <int EPI, bool LN, int EXTRA, bool WS = false, bool SC = false, bool UP4 = false>
 __global__ __launch_bounds__(512, 2)
 void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
     constexpr int WC = 2, CH = 2, NW = 8;
@@ -199,8 +205,9 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
 
     const int C1 = p.C1;
     const int C2 = p.Cin - C1;
-    const int ntaps = (p.mode == IG_DENSE) ? 1 : 9;
+    const int ntaps = UP4 ? 4 : (p.mode == IG_DENSE) ? 1 : 9;
     const int cpt = p.Cin / BK;
+    const int tpp = UP4 ? ntiles >> 2 : 0;                      // UP4: tiles per output parity class (the launch has 4 x tpp)
     const int KSP = PART ? p.ksplit : 1;                         // k parts (each ntaps / KSP taps); `ntiles` counts units = tiles * KSP
     const int cpt_sc = SC ? p.Csc / BK : 0;                      // SC: k steps of the folded shortcut ("tap 9")
     const int nk = ntaps * cpt / KSP + cpt_sc;                   // k steps of one unit, >= 4 (igemm_pers_ok)
@@ -218,6 +225,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
     const unsigned wstride = (unsigned)(NW * 8) * (unsigned)Ktot;
     const f16* xbase = p.X;
     int ld_tap = 0, ld_cc = 0;
+    int ld_ph = 0;                    // UP4: output parity class (py << 1 | px) of the tile being fetched
 
     auto pack_row = [&](int m) __attribute__((always_inline)) -> int {
         if (m >= p.M) return -1;
@@ -228,8 +236,9 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
         return (n << 18) | (oh << 9) | (rem - oh * p.OW);
     };
     auto set_tile = [&](int unit) __attribute__((always_inline)) {
-        const int tl = PART ? unit / KSP : unit;
+        int tl = PART ? unit / KSP : unit;
         const int tap0 = PART ? (unit - tl * KSP) * (ntaps / KSP) : 0;
+        if constexpr (UP4) { ld_ph = tl / tpp; tl -= ld_ph * tpp; }
         const int pt = tl / tiles_c;
         lp0 = pt * TP;
         lc0 = (tl - pt * tiles_c) * TC;
@@ -237,6 +246,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
         const int lrow = ln >> 3, lchunk = ((ln & 7) ^ lrow) * 8;
         woff = (unsigned)((size_t)(lc0 + wid * 8 + lrow) * Ktot + lchunk) + (unsigned)(tap0 * p.Cin);
         if constexpr (WS) woff += (unsigned)((long long)(lp0 / p.rows_per_sample) * p.w_sample_stride);
+        if constexpr (UP4) woff += (unsigned)ld_ph * (unsigned)p.Cout * (unsigned)Ktot;
         ld_tap = tap0; ld_cc = 0;
 #pragma unroll
         for (int k = 0; k < XI; ++k) xpk[k] = pack_row(lp0 + (wid + k * NW) * 8 + lrow);
@@ -247,6 +257,10 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
         if (p.mode == IG_DENSE) return pk;
         const int oh = (pk >> 9) & 511, ow = pk & 511;
         const int xnb = (pk >> 18) * (p.H * p.W);
+        if constexpr (UP4) {                                       // (dy, dx) = the 2x2 tap (a, b); rows are pixels of the source grid
+            const int ih = oh + dy - 1 + (ld_ph >> 1), iw = ow + dx - 1 + (ld_ph & 1);
+            return (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) ? xnb + ih * p.W + iw : -1;
+        }
         if (p.mode == IG_CONV3 || p.mode == IG_CONV3_S2) {
             const int st = (p.mode == IG_CONV3_S2) ? 2 : 1;
             const int ih = oh * st + dy - 1, iw = ow * st + dx - 1;
@@ -264,7 +278,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
         return xnb + ih * p.W + iw;
     };
     auto set_src = [&](int tap, int cs) __attribute__((always_inline)) {
-        const int dy = tap / 3, dx = tap - dy * 3;
+        const int dy = UP4 ? tap >> 1 : tap / 3, dx = UP4 ? tap & 1 : tap - dy * 3;
         const int ln = hw_lane();
         const int lrow = ln >> 3, lchunk = ((ln & 7) ^ lrow) * 8;
 #pragma unroll
@@ -417,7 +431,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
     };
 
     // ---- epilogue: straight from the accumulators ---------------------------------------------------------------
-    auto epilogue = [&](int p0, int c0out, int slot) __attribute__((always_inline)) {
+    auto epilogue = [&](int p0, int c0out, int slot, int ph) __attribute__((always_inline)) {
         const char* ax = aux0 + slot * AUX_BYTES;
         constexpr int OCH = (EPI == EPI_GEGLU) ? 40 : 80;          // output channels of one (wave, h) sub-tile
         constexpr bool RES = (EXTRA == PX_RES);
@@ -499,7 +513,13 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
                     else { R4[0] = w0; if (NWD == 2) R4[NWD - 1] = w1; }
                 }
                 transpose4<NWD>(R);            // lane group eg now holds quarters 0..3 of channel block eg
-                f16* yp = (m < p.M) ? p.Y + (size_t)m * p.ldy + c0o + wc * (OCH * CH) + h * OCH : nullptr;
+                size_t orow = (size_t)m;
+                if constexpr (UP4) {                               // source-grid row -> its pixel of parity class ph in the [N][2H][2W] output
+                    const int n = m / OHW, rem = m - n * OHW;
+                    const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                    orow = ((size_t)n * (2 * p.OH) + (2 * oh + (ph >> 1))) * (size_t)(2 * p.OW) + (2 * ow + (ph & 1));
+                }
+                f16* yp = (m < p.M) ? p.Y + orow * p.ldy + c0o + wc * (OCH * CH) + h * OCH : nullptr;
                 if (EPI == EPI_GEGLU) {
                     const uintx4 o8 = uintx4{R[0][0], R[1][0], R[2][0], R[3][0]};           // 8 output channels of block eg
                     *reinterpret_cast<uintx4*>(yp ? yp + 8 * eg : sink) = o8;
@@ -559,7 +579,9 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
     int slot = 0;
     bool first = true;
     while (true) {
-        const int rtile = PART ? tile / KSP : tile;
+        int rtile = PART ? tile / KSP : tile;
+        int cur_ph = 0;
+        if constexpr (UP4) { cur_ph = rtile / tpp; rtile -= cur_ph * tpp; }
         const int pt = rtile / tiles_c;
         const int p0 = pt * TP, c0out = (rtile - pt * tiles_c) * TC;
 #pragma unroll
@@ -629,7 +651,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
             }
         }
         if constexpr (PART) epilogue_partial(p0, c0out, tile - rtile * KSP);
-        else epilogue(p0, c0out, slot);
+        else epilogue(p0, c0out, slot, cur_ph);
         PTICK(2);
 #ifdef DM_IGEMM_TIMING
         dbg[4] += 1;
@@ -714,6 +736,31 @@ static hipError_t launch_igemm_pers_ws_t(const IGemmParams& p, hipStream_t s) {
     static std::atomic<unsigned> launch_no{0};
     const int cset = (int)(launch_no.fetch_add(1) % CSETS);
     launch_timed((igemm_pers_kernel<EPI_PLAIN, true, PX_NONE, true>), dim3(grid), dim3(512), lds, s, with_zero_page(p), ntiles, cset);
+    return hipGetLastError();
+}
+#endif
+
+// Upsample2D + conv as four 2x2 convolutions on the source grid (template parameter UP4); only igemm_pers_up.hip defines DM_IGEMM_PERS_UP.
+// Always this kernel, for every batch size (no 128-row partner, no head / tail cut): a sample's bits cannot depend on its batch.
+#ifdef DM_IGEMM_PERS_UP
+static hipError_t launch_igemm_pers_up4_t(const IGemmParams& p, hipStream_t s) {
+    constexpr int TP = 256, TC = 320;
+    constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 2 * AUX_BYTES;
+    if (p.mode != IG_CONV2_UP4 || p.epi != EPI_PLAIN || p.ln_s || p.temb || p.res || p.X2 || p.X3 || p.ksplit > 1 || p.w_sample_stride ||
+        p.Cout % TC != 0 || p.Cin % BK != 0 || p.C1 != p.Cin || p.OH != p.H || p.OW != p.W || p.H < 1 || p.W < 1 || p.H > 511 || p.W > 511 ||
+        p.M < 2 || p.M != (p.M / (p.H * p.W)) * p.H * p.W || p.M / (p.H * p.W) > 8191) return hipErrorInvalidValue;
+    // 32-bit element offsets: activations (row * channels + chunk), the four weight matrices, and 4 x tiles in an int
+    if ((long long)p.M * p.Cin >= (1LL << 31) || 16LL * p.Cout * p.Cin >= (1LL << 32)) return hipErrorInvalidValue;
+    const int tpp = ((p.M + TP - 1) / TP) * (p.Cout / TC);
+    const int ntiles = 4 * tpp;
+    const int n_cu = device_cu_count();
+    const int grid = ntiles < n_cu ? ntiles : n_cu;
+    static std::atomic<uint64_t> attr_seen{0};
+    if (first_use_on_device(attr_seen))
+        (void)hipFuncSetAttribute((const void*)igemm_pers_kernel<EPI_PLAIN, false, PX_NONE, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static std::atomic<unsigned> launch_no{0};
+    const int cset = (int)(launch_no.fetch_add(1) % CSETS);
+    launch_timed((igemm_pers_kernel<EPI_PLAIN, false, PX_NONE, false, false, true>), dim3(grid), dim3(512), lds, s, with_zero_page(p), ntiles, cset);
     return hipGetLastError();
 }
 #endif

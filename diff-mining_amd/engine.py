@@ -27,6 +27,7 @@ SYMBOLS = [
     "dm_engine_load_clip_weight", "dm_engine_finalize_clip", "dm_clip_encode", "dm_op_igemm_splitk",
     "dm_op_ln_stats", "dm_op_igemm_ln", "dm_reduce_typicality_batched", "dm_op_igemm_tile", "dm_op_igemm_head_rows", "dm_set_option",
     "dm_engine_reserve", "dm_engine_stats", "dm_op_groupnorm_conv1x1", "dm_op_igemm_shortcut", "dm_normalize_map",
+    "dm_op_fold_upconv_weights", "dm_op_upconv_folded", "dm_prof_read_folded",
     "dm_f32_create", "dm_f32_destroy", "dm_f32_last_error", "dm_f32_load_weight", "dm_f32_finalize", "dm_f32_set_prompts",
     "dm_f32_unet_forward", "dm_f32_dift", "dm_f32_prof_enable", "dm_f32_prof_read", "dm_f32_memory", "dm_f32_op_gemm",
     "dm_f32_op_attention", "dm_f32_op_groupnorm", "dm_f32_op_layernorm", "dm_f32_load_vae_weight", "dm_f32_finalize_vae",
@@ -73,6 +74,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_reduce_typicality.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.dm_typicality_image.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.dm_prof_enable.argtypes = [vp, i32]
+    if hasattr(lib, "dm_prof_read_folded"):
+        lib.dm_prof_read_folded.argtypes = [vp, C.POINTER(C.c_double)]
     lib.dm_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64),
                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
     lib.dm_engine_memory.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
@@ -95,6 +98,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_op_attention512.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float]
     if hasattr(lib, "dm_op_igemm_shortcut"):
         lib.dm_op_igemm_shortcut.argtypes = [vp] * 8 + [i32] * 8
+    if hasattr(lib, "dm_op_upconv_folded"):
+        lib.dm_op_fold_upconv_weights.argtypes = [vp, i32, i32, vp]
+        lib.dm_op_upconv_folded.argtypes = [vp] * 5 + [i32] * 5
     if hasattr(lib, "dm_op_groupnorm_conv1x1"):
         lib.dm_op_groupnorm_conv1x1.argtypes = [vp, vp, i32, i32, i32, i32, C.c_float, vp, vp, vp, vp, i32, vp]
     if hasattr(lib, "dm_engine_reserve"):        # absent only from older A/B libraries loaded through DM_ENGINE_LIB
@@ -525,8 +531,13 @@ class UNetEngine:
         d, e, f = C.c_double(), C.c_double(), C.c_int64()
         self._check(self.lib.dm_prof_read(self._h, C.byref(a), C.byref(b), C.byref(c2), C.byref(d), C.byref(e),
                                           C.byref(f)), "prof_read")
-        return {"igemm_ms": a.value, "igemm_flops": b.value, "igemm_launches": c2.value,
-                "attn_ms": d.value, "attn_flops": e.value, "attn_launches": f.value}
+        out = {"igemm_ms": a.value, "igemm_flops": b.value, "igemm_launches": c2.value,
+               "attn_ms": d.value, "attn_flops": e.value, "attn_launches": f.value, "igemm_flops_folded": 0.0}
+        if hasattr(self.lib, "dm_prof_read_folded"):       # (absent only from older A/B libraries loaded through DM_ENGINE_LIB)
+            g = C.c_double()
+            self._check(self.lib.dm_prof_read_folded(self._h, C.byref(g)), "prof_read_folded")
+            out["igemm_flops_folded"] = g.value
+        return out
 
     def reserve(self, max_batch: int = 0, h: int = 0, w: int = 0, n_cond: int = 1, max_prompts: int = 0):
         """Pre-size the workspace arena for U-Net batches of up to `max_batch` samples of h x w latents (n_cond > 1: the

@@ -155,6 +155,10 @@ int dm_normalize_map(dm_engine* e, const void* map_dev, int64_t n, int mode, voi
 int dm_prof_enable(dm_engine* e, int on);
 int dm_prof_read(dm_engine* e, double* igemm_ms, double* igemm_flops, int64_t* igemm_launches,
                  double* attn_ms, double* attn_flops, int64_t* attn_launches);
+/* igemm_flops above counts the multiply-adds the launches EXECUTE.  With "up_fold" an Upsample2D + conv launch executes 4 / 9 of the
+ * layer's definition (interpolate, then 9 taps: the count SURVEY 8d's 803.27 GFLOP per forward uses); this returns the difference
+ * (definition minus executed) accumulated over the interval the last dm_prof_read closed, so a caller can quote either figure. */
+int dm_prof_read_folded(dm_engine* e, double* igemm_flops_folded);
 
 /* ---- VAE encoder -------------------------------------------------------------
  * Replaces `self.vae.encode(x).latent_dist.sample() * self.vae.config.scaling_factor`
@@ -263,6 +267,10 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
  *     of 32-pixel-wide images (2: every eligible layer down to 16 pixels) run their k steps in the order
  *     (dy, 64-channel slab, dx) and fetch ONE activation stage per three horizontal taps (igemm_pers_tr.hip; the 128-row tile
  *     follows the same order, so the two tile kernels stay bit-identical) — numerically equivalent, not bit-identical to 0;
+ *   "up_fold" (1 / 0): Upsample2D (nearest, exact 2x) + its 3x3 convolution as four 2x2 convolutions on the low-resolution source, one per
+ *     output parity class, with the 3x3 taps that read the same source pixel pre-summed in fp32 and rounded to fp16 once (4 / 9 of the
+ *     layer's MACs; the up-sampled tensor is never formed) — numerically equivalent, not bit-identical to 0; other sizes
+ *     (F.interpolate(size=...) of odd latents) always run the unfolded layer;
  *   "graph" (0 / 1): replay whole U-Net runs as captured hipGraphs (bit-identical: the same kernels with the same arguments);
  *   "igemm_exp": experimental kernel paths of the current round (0 = shipped). */
 int dm_set_option(const char* name, int value);
@@ -301,6 +309,12 @@ int dm_op_layernorm(void* stream, const void* X, int rows, int C, const float* g
  * ((Wp W2) f + Wp t2 + x).  Cout % 160 == 0; Cin, C3, C4 multiples of 64. */
 int dm_op_igemm_shortcut(void* stream, const void* X, const void* X3, const void* X4, const void* Wp, const void* bias, const void* res,
                          void* Y, int N, int H, int W, int Cin, int C3, int C4, int Cout, int mode);
+/* Upsample2D + conv (diffusers Upsample2D.forward: F.interpolate(scale_factor=2, mode="nearest") then Conv2d(3x3, padding 1)) folded onto
+ * the source grid.  dm_op_fold_upconv_weights (host): w [Cout][Cin][3][3] fp16 -> W4 [4 = py*2+px][Cout][(a*2+b)*Cin + ci] fp16, entry =
+ * fp16(fp32 sum of the 3x3 taps that read source pixel (y-1+py+a, x-1+px+b) for output pixel (2y+py, 2x+px)).
+ * dm_op_upconv_folded (device): X [N][H][W][Cin], W4, bias [Cout] -> Y [N][2H][2W][Cout].  Cout % 320 == 0, Cin % 64 == 0. */
+int dm_op_fold_upconv_weights(const void* w_oihw_f16_host, int Cout, int Cin, void* out_f16_host);
+int dm_op_upconv_folded(void* stream, const void* X, const void* W4, const void* bias, void* Y, int N, int H, int W, int Cin, int Cout);
 /* GroupNorm(G, eps) (no activation) folded into the following 1x1 convolution W [Cout][C] + bias (Transformer2DModel.norm ->
  * proj_in): statistics of X [N][HW][C], per-sample weights fp16(W diag(a_n)) and fp32 bias rows W b_n + bias, then the GEMM on
  * the raw X — Y [N][HW][Cout] fp16.  HW must be a multiple of 128, C of 64, Cout of 160. */

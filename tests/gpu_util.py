@@ -116,3 +116,31 @@ def assert_close_fp16(got, ref, what, rel=2e-3, abs_frac=2e-3):
     assert not torch.isnan(got.float()).any().item(), f"{what}: NaN in output"
     assert r < rel and m < abs_frac, f"{what}: rel_l2={r:.3e} (<{rel}) max_abs/max_ref={m:.3e} (<{abs_frac})"
     return r, m
+
+
+def fold_upconv_torch(w):
+    """Upsample2D (nearest 2x) + conv3x3 folded onto the source grid, built with torch: w [Cout,Cin,3,3] ->
+    [4 = py*2+px][Cout][(a*2+b)*Cin + ci] fp16; the 3x3 taps that read the same source pixel are summed in fp32, rounded once."""
+    sel = {0: ([0], [1, 2]), 1: ([0, 1], [2])}          # parity -> 3x3 taps feeding 2x2 tap a = 0 / 1
+    wf = w.float()
+    out = []
+    for py in (0, 1):
+        for px in (0, 1):
+            taps = []
+            for a in (0, 1):
+                for b in (0, 1):
+                    taps.append(wf[:, :, sel[py][a], :][:, :, :, sel[px][b]].sum(dim=(2, 3)))     # [Cout, Cin]
+            out.append(torch.cat(taps, dim=1))
+    return torch.stack(out, 0).half().contiguous()
+
+
+def op_upconv_folded(X, W4, bias):
+    """X [N,H,W,Cin] fp16 cuda, W4 [4][Cout][4*Cin] fp16 cuda -> Y [N,2H,2W,Cout]"""
+    lib = E.load_library()
+    N, H, Wd, Cin = X.shape
+    Cout = W4.shape[1]
+    Y = torch.empty(N, 2 * H, 2 * Wd, Cout, dtype=torch.float16, device=X.device)
+    rc = lib.dm_op_upconv_folded(stream(), ptr(X), ptr(W4), ptr(bias), ptr(Y), N, H, Wd, Cin, Cout)
+    assert rc == 0, "dm_op_upconv_folded failed"
+    torch.cuda.synchronize()
+    return Y

@@ -103,3 +103,13 @@ def test_tap_reuse_kernels_do_not_spill():
     assert len(found) == 13, found
     spilled = [(n, int(c)) for n, c in found if int(c) != 0]
     assert not spilled, f"tap-reuse kernels with spilled registers (move them to the run-time-dx loop: TrUnroll): {spilled}"
+    # the folded up-sampler (igemm_pers_up.hip, template parameter UP4 of the persistent tile) carries a parity class and a scattering
+    # epilogue on top of the plain kernel's state: same check
+    src = os.path.join(os.path.dirname(b.__file__), "csrc", "igemm_pers_up.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "up.s")
+        subprocess.run([b._hipcc()] + b.FLAGS + ["-S", "--cuda-device-only", "-o", out, src], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    found = re.findall(r"\.name:\s+(\S*igemm_pers_kernelILi0ELb0ELi0ELb0ELb0ELb1E\S*).*?\.vgpr_spill_count:\s+(\d+)", text, re.S)
+    assert len(found) == 1 and int(found[0][1]) == 0, found

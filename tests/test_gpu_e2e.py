@@ -866,3 +866,37 @@ def test_tap_reuse_option_end_to_end(engine):
         print(f"tap_reuse {v} vs 1: rel-L2 {rel:.2e}")
         assert rel < 2.5e-3, rel          # a pure reordering of fp32 partial sums: the oracle's own noise floor is 1.1-1.2e-3 (tests/test_oracle.py)
     assert not torch.equal(out[0], out[1])          # (the k order differs: equal bits would mean the option does nothing)
+
+
+@pytest.mark.parametrize("h,w", [(64, 64), (16, 24)])
+def test_up_fold_option_end_to_end(engine, sd15_weights_torch, h, w):
+    """Option "up_fold" (Upsample2D + conv as four 2x2 convolutions on the source grid, igemm_pers_up.hip) end to end: the loss
+    grids with the option on / off agree to the fp16 noise floor, a sample's bits do not depend on the batch it rides in with the
+    option on, and — at the size the oracle reaches — the folded engine is no further from the fp32 oracle than the unfolded one."""
+    lib = engine.lib
+    x, eps, t, c = _inputs(h, w, 3, flow="f32")
+    dev = engine.device
+    xd, ed, td = x.to(dev), eps.to(dev), t.to(dev)
+    engine.set_prompts(c)
+    out = {}
+    try:
+        for v in (1, 0):
+            assert lib.dm_set_option(b"up_fold", v) == 0
+            out[v] = engine.score_conds(xd, ed, td, 2, latent_dtype=torch.float32).clone()
+        assert lib.dm_set_option(b"up_fold", 1) == 0
+        one = engine.score_conds(xd, ed[:1], td[:1], 2, latent_dtype=torch.float32).clone()
+    finally:
+        lib.dm_set_option(b"up_fold", 1)
+    n = eps.shape[0]
+    assert torch.equal(one[0], out[1][0]) and torch.equal(one[1], out[1][n]), "a draw's loss depends on the batch with up_fold on"
+    rel = ((out[0] - out[1]).norm() / out[1].norm()).item()
+    print(f"up_fold 0 vs 1 @{h}x{w}: loss rel-L2 {rel:.2e}")
+    assert rel < 2.5e-3, rel                         # same bound as the pure re-orderings (the oracle's own noise floor is 1.1-1.2e-3)
+    assert not torch.equal(out[0], out[1])           # (equal bits would mean the option does nothing)
+    if h * w <= 16 * 24:
+        nb, tb, cc, slots = _tile(eps, t, c)
+        ref = R.compute_loss(sd15_weights_torch, x, nb, tb, cc, autocast=False, latent_dtype=torch.float32)
+        e1 = ((out[1].cpu() - ref).norm() / ref.norm()).item()
+        e0 = ((out[0].cpu() - ref).norm() / ref.norm()).item()
+        print(f"vs the fp32 oracle: up_fold on {e1:.2e}, off {e0:.2e}")
+        assert e1 <= 1.2 * e0, (e1, e0)

@@ -2,7 +2,8 @@
 
 r03 added four rewrites that move rounding points — LayerNorm folded into the following GEMM (`ln_fold`: rstd (acc - mean sum W')),
 GroupNorm folded into per-sample weights (`gn_fold`: fp16(W diag(a_n)), 64x64 level), `ff.net.2` + `proj_out` pre-multiplied
-(`ff_fold`), `conv_shortcut` folded into `conv2` (`sc_fold`) — each validated only on weights that give zero-mean O(1)
+(`ff_fold`), `conv_shortcut` folded into `conv2` (`sc_fold`); r04: `Upsample2D` + conv as four 2x2 convolutions with pre-summed
+taps (`up_fold`) — each validated only on weights that give zero-mean O(1)
 activations.  Here the same U-Net runs on `tests/stress_weights.py`: output-channel scales over two decades, x50 outlier channels,
 |mean| / std of 5-20 at the LayerNorm inputs and the ResNets' inner GroupNorm, 9 (median) / 18 (max) at the first transformer's
 GroupNorm — the place where a folded form cancels a large common mode against a rounded operand.
@@ -22,7 +23,7 @@ from diff_mining_amd import synth  # noqa: E402
 from oracle import unet_ref as R  # noqa: E402
 from tests import stress_weights as S  # noqa: E402
 
-FOLDS = ("ln_fold", "gn_fold", "ff_fold", "sc_fold")
+FOLDS = ("ln_fold", "gn_fold", "ff_fold", "sc_fold", "up_fold")
 
 
 @pytest.fixture(scope="module")

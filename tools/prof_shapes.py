@@ -25,7 +25,7 @@ for (kind, M, N, K, mode), (n, ms, fl) in acc.items():
     tf = fl / ms / 1e9
     if kind == 0:
         epi = mode // 10
-        taps = 1 if mode % 10 == 0 else 9
+        taps = 1 if mode % 10 == 0 else 4 if mode % 10 == 5 else 9      # mode 5: Upsample2D + conv as four 2x2 convolutions (M = 4 parity classes x source rows)
         nout = N // 2 if epi else N
         byts = EB * (M * (K // taps) + N * K + M * nout)
         hbm_ms = byts / 5e12 * 1e3
