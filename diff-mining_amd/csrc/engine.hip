@@ -1247,6 +1247,8 @@ int set_option(const char* name, int value) {
 
 }  // namespace dm
 
+int dm_get_option_up_fold() { return dm::option(dm::OPT_UP_FOLD); }      // for unet_f32.hip (internal, not exported through the header)
+
 // ================================================================================================
 // C ABI
 // ================================================================================================

@@ -35,6 +35,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __attribute__((aligned(256))) float g_zero_page32[BK] = {0};
 
+template <bool UP4>
 __global__ __launch_bounds__(NT, 2) void gemm32_kernel(GemmParams p, int tiles_m, int tiles_n, int per_xcd, const float* zero_page) {
     __shared__ __attribute__((aligned(16))) float Ws[2][BN][BK];
     __shared__ __attribute__((aligned(16))) float Xs[2][BM][BK];
@@ -42,11 +43,17 @@ __global__ __launch_bounds__(NT, 2) void gemm32_kernel(GemmParams p, int tiles_m
     // blocks of one XCD share their activation rows in its L2)
     const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (tile >= tiles_m * tiles_n) return;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    int tm = tile / tiles_n;
+    const int tn = tile - tm * tiles_n;
+    // mode 5 (r04): Upsample2D (nearest, exact 2x) + conv3x3 as four 2x2 convolutions on the SOURCE grid, one per output parity class
+    // ph = py * 2 + px (igemm_pers_tile.h, UP4): H x W = OH x OW = the source grid, M = rows per class, tiles_m = 4 x tiles per class,
+    // Wp [4][Cout][4 Cin] with the 3x3 taps that read the same source pixel pre-summed; the epilogue scatters rows into [N][2H][2W].
+    int ph = 0;
+    if constexpr (UP4) { const int tmp = tiles_m >> 2; ph = tm / tmp; tm -= ph * tmp; }
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c32 = lane & 31, h32 = lane >> 5;
-    const int K = (p.mode == 0 ? 1 : 9) * p.Cin;
+    const int K = (UP4 ? 4 : p.mode == 0 ? 1 : 9) * p.Cin;
     const int OHW = p.OH * p.OW;
     const int lrow = tid / CH, lchunk = tid % CH;         // loader: rows lrow + 32 i, chunk lchunk
     const float* zero = zero_page + 4 * lchunk;
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(NT, 2) void gemm32_kernel(GemmParams p, int tiles_m
     for (int i = 0; i < WI; ++i) {
         const int ch = n0 + lrow + (NT / CH) * i;
         const bool ok = ch < p.Cout;
-        wsrc[i] = ok ? p.Wp + (size_t)ch * K + 4 * lchunk : zero;
+        wsrc[i] = ok ? p.Wp + (UP4 ? (size_t)ph * p.Cout + ch : (size_t)ch) * K + 4 * lchunk : zero;
         winc[i] = ok ? BK : 0;
     }
     int ld_tap = 0, ld_c = 0;                              // loader position: tap and channel offset of the NEXT step to load
@@ -78,12 +85,16 @@ __global__ __launch_bounds__(NT, 2) void gemm32_kernel(GemmParams p, int tiles_m
         const float* base = second ? p.X2 : p.X;
         const int cs = second ? p.Cin - p.C1 : p.C1;
         const int cc = (second ? ld_c - p.C1 : ld_c) + 4 * lchunk;
-        const int dy = ld_tap / 3, dx = ld_tap - dy * 3;
+        const int dy = UP4 ? ld_tap >> 1 : ld_tap / 3, dx = UP4 ? ld_tap & 1 : ld_tap - dy * 3;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             long long off = -1;
             if (xn[i] >= 0) {
-                if (p.mode == 0) off = xox[i];
+                if (UP4) {                           // 2x2 tap (dy, dx) of parity class ph reads source pixel (y - 1 + py + dy, x - 1 + px + dx)
+                    const int ih = xoy[i] + dy - 1 + (ph >> 1), iw = xox[i] + dx - 1 + (ph & 1);
+                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) off = ((long long)xn[i] * p.H + ih) * p.W + iw;
+                }
+                else if (p.mode == 0) off = xox[i];
                 else if (p.mode == 3) {              // F.interpolate(mode="nearest") to (OH, OW), then the 3x3 convolution (pad 1)
                     const int uh = xoy[i] + dy - 1, uw = xox[i] + dx - 1;
                     if (uh >= 0 && uh < p.OH && uw >= 0 && uw < p.OW) {
@@ -189,6 +200,11 @@ __global__ __launch_bounds__(NT, 2) void gemm32_kernel(GemmParams p, int tiles_m
     const int m = m0 + wid * 32 + c32;
     if (m < p.M) {
         const float* tb = p.temb ? p.temb + (size_t)(m / OHW) * p.temb_ld : nullptr;
+        size_t orow = (size_t)m;
+        if constexpr (UP4) {
+            const int n = m / OHW, rem = m - n * OHW, oy = rem / p.OW, ox = rem - oy * p.OW;
+            orow = ((size_t)n * (2 * p.OH) + (2 * oy + (ph >> 1))) * (size_t)(2 * p.OW) + (2 * ox + (ph & 1));
+        }
 #pragma unroll
         for (int ct = 0; ct < 5; ++ct)
 #pragma unroll
@@ -201,12 +217,12 @@ __global__ __launch_bounds__(NT, 2) void gemm32_kernel(GemmParams p, int tiles_m
                     v2f y;
                     y[0] = v[0] * (0.5f * v[2] * (1.0f + erff(v[2] * 0.70710678118654752440f)));
                     y[1] = v[1] * (0.5f * v[3] * (1.0f + erff(v[3] * 0.70710678118654752440f)));
-                    *reinterpret_cast<v2f*>(p.Y + (size_t)m * p.ldy + (ch >> 1)) = y;
+                    *reinterpret_cast<v2f*>(p.Y + orow * p.ldy + (ch >> 1)) = y;
                     continue;
                 }
                 if (tb) v += *reinterpret_cast<const v4f*>(tb + ch);
                 if (p.res) v += *reinterpret_cast<const v4f*>(p.res + (size_t)m * p.ldres + ch);
-                *reinterpret_cast<v4f*>(p.Y + (size_t)m * p.ldy + ch) = v;
+                *reinterpret_cast<v4f*>(p.Y + orow * p.ldy + ch) = v;
             }
     }
 }
@@ -214,11 +230,13 @@ __global__ __launch_bounds__(NT, 2) void gemm32_kernel(GemmParams p, int tiles_m
 }  // namespace
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
-    const int taps = p.mode == 0 ? 1 : 9;
+    const int taps = p.mode == 0 ? 1 : p.mode == 5 ? 4 : 9;
+    if (p.mode == 5 && (p.X2 || p.C1 != p.Cin || p.temb || p.res || p.epi || p.OH != p.H || p.OW != p.W || p.M != (p.M / (p.H * p.W)) * p.H * p.W))
+        return hipErrorInvalidValue;
     if (p.M <= 0 || p.Cout <= 0 || p.Cin % BK != 0 || p.C1 % BK != 0 || p.C1 <= 0 || p.Cout % 4 != 0 || (p.C1 < p.Cin && !p.X2) ||
         (long long)taps * p.Cin > (1LL << 30) || p.ldy % (p.epi == 1 ? 2 : 4) != 0 || (p.epi == 1 && (p.temb || p.res)) || (p.res && p.ldres % 4 != 0) || (p.temb && p.temb_ld % 4 != 0))
         return hipErrorInvalidValue;
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.Cout + BN - 1) / BN;
+    const int tiles_m = (p.mode == 5 ? 4 : 1) * ((p.M + BM - 1) / BM), tiles_n = (p.Cout + BN - 1) / BN;
     const long long tiles = (long long)tiles_m * tiles_n;
     const int per_xcd = (int)((tiles + 7) / 8);
     // device address of the zero page: one symbol lookup per device ordinal
@@ -231,7 +249,8 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
         if (e != hipSuccess) return e;
         zero_pages[dev & 63].store(zp, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL(gemm32_kernel, dim3((unsigned)(per_xcd * 8)), dim3(NT), 0, s, p, tiles_m, tiles_n, per_xcd, (const float*)zp);
+    if (p.mode == 5) hipLaunchKernelGGL(gemm32_kernel<true>, dim3((unsigned)(per_xcd * 8)), dim3(NT), 0, s, p, tiles_m, tiles_n, per_xcd, (const float*)zp);
+    else hipLaunchKernelGGL(gemm32_kernel<false>, dim3((unsigned)(per_xcd * 8)), dim3(NT), 0, s, p, tiles_m, tiles_n, per_xcd, (const float*)zp);
     return hipGetLastError();
 }
 

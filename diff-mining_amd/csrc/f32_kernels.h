@@ -8,7 +8,8 @@
 namespace dm32 {
 
 // modes as dm::IGemmMode: 0 dense, 1 conv3x3 stride 1, 2 conv3x3 stride 2 (pad 1), 3 nearest-upsample to (OH, OW) then conv3x3,
-// 4 conv3x3 stride 2 with pad (0,1,0,1) (VAE downsampler)
+// 4 conv3x3 stride 2 with pad (0,1,0,1) (VAE downsampler), 5 Upsample2D (nearest, exact 2x) + conv3x3 as four 2x2 convolutions on the source
+// grid (H = OH, W = OW = the source, M = N H W rows per parity class, Wp [4][Cout][4 Cin] pre-summed taps, Y [N][2H][2W][Cout])
 struct GemmParams {
     const float* X = nullptr;     // source 1, NHWC [N,H,W,C1] (dense: [M,C1])
     const float* X2 = nullptr;    // source 2 (channel concat), NHWC [N,H,W,Cin-C1], or nullptr

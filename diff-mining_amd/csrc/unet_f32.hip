@@ -14,6 +14,8 @@
 #include "arena.h"
 #include "../../include/dm_engine.h"
 
+int dm_get_option_up_fold();      // engine.hip: the process-wide switch "up_fold" (dm_set_option)
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -44,7 +46,7 @@ struct Norm { size_t g = NONE, b = NONE; int c = 0; };
 struct Res { Norm n1, n2; Conv c1, c2, sc; bool has_sc = false; int temb_off = 0; };
 struct Tfm { Norm gn, ln1, ln2, ln3; Conv proj_in, proj_out, qkv, o1, q2, kv2, o2, ff1, ff2; int c = 0, layer = 0; };
 struct DownB { Res res[2]; Tfm tf[2]; bool attn = false; Conv down; bool has_down = false; };
-struct UpB { Res res[3]; Tfm tf[3]; bool attn = false; Conv up; bool has_up = false; };
+struct UpB { Res res[3]; Tfm tf[3]; bool attn = false; Conv up; bool has_up = false; Conv up4; bool has_up4 = false; };   // up4: the up-sampler folded onto the source grid (mode 5)
 
 // SDv1.5 AutoencoderKL encoder (block_out_channels 128/256/512/512, two resnets per block, no time embedding)
 constexpr int VNB = 4;
@@ -135,6 +137,30 @@ int pack_conv3(dm_f32_net* e, const std::string& name, int cout, int cin, Conv* 
     o->w = put(e, pk.data(), pk.size());
     o->cin = cin; o->cout = cout; o->k = 3;
     return pack_vec(e, name + ".bias", cout, &o->b);
+}
+// Upsample2D.conv folded onto the source grid (f32_gemm.hip mode 5): [4 = py*2+px][cout][(a*2+b)*cin + ci], an entry = the sum (in double,
+// rounded to fp32 once: <= 2^-24 relative, a thirtieth of the fp32 summation-order noise of the layer) of the 3x3 taps that read source
+// pixel (y - 1 + py + a, x - 1 + px + b) for output pixel (2y + py, 2x + px); shares the bias of the packed 3x3 layer
+int pack_upconv4(dm_f32_net* e, const std::string& name, int cout, int cin, const Conv& full, Conv* o) {
+    HostT* w = get(e, name + ".weight", {cout, cin, 3, 3});
+    if (!w) return 1;
+    static const int lo[2][2] = {{0, 1}, {0, 2}}, hi[2][2] = {{0, 2}, {1, 2}};
+    std::vector<float> pk((size_t)16 * cout * cin);
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px)
+            for (int co = 0; co < cout; ++co)
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b)
+                        for (int ci = 0; ci < cin; ++ci) {
+                            const float* k9 = w->data.data() + ((size_t)co * cin + ci) * 9;
+                            double acc = 0.0;
+                            for (int dy = lo[py][a]; dy <= hi[py][a]; ++dy)
+                                for (int dx = lo[px][b]; dx <= hi[px][b]; ++dx) acc += (double)k9[dy * 3 + dx];
+                            pk[(((size_t)(py * 2 + px) * cout + co) * 4 + (a * 2 + b)) * cin + ci] = (float)acc;
+                        }
+    o->w = put(e, pk.data(), pk.size());
+    o->cin = cin; o->cout = cout; o->k = 2; o->b = full.b;
+    return 0;
 }
 int pack_dense(dm_f32_net* e, const std::string& name, int cout, int cin, bool conv1x1, bool bias, Conv* o) {
     HostT* w = conv1x1 ? get(e, name + ".weight", {cout, cin, 1, 1}) : get(e, name + ".weight", {cout, cin});
@@ -264,6 +290,18 @@ struct Fwd32 {
         if (mode == 0) { p.M = (int)x.rows(); p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M; }
         else { p.M = x.N * OH * OW; p.H = x.H; p.W = x.W; p.OH = OH; p.OW = OW; }
         F_TRY(prof_begin(0, 2.0 * (double)p.M * cv.cout * (double)((mode == 0 ? 1 : 9) * cin), p.M, cv.cout, (mode == 0 ? 1 : 9) * cin, mode));
+        F_HIP(e, launch_gemm(p, s));
+        return prof_end();
+    }
+    int upconv4(const Conv& cv, const T32& x, T32* y) {      // FLOPs booked = executed (4 taps)
+        if (x.C != cv.cin) F_FAIL(e, "upconv4 (fp32): channel mismatch %d vs %d", x.C, cv.cin);
+        F_TRY(alloc(y, x.N, 2 * x.H, 2 * x.W, cv.cout));
+        if (dry) return 0;
+        GemmParams p;
+        p.X = x.p; p.Wp = P(cv.w); p.bias = P(cv.b); p.Y = y->p;
+        p.Cout = cv.cout; p.Cin = x.C; p.C1 = x.C; p.mode = 5; p.ldy = cv.cout;
+        p.M = x.N * x.H * x.W; p.H = x.H; p.W = x.W; p.OH = x.H; p.OW = x.W;
+        F_TRY(prof_begin(0, 2.0 * 4.0 * (double)p.M * cv.cout * 4.0 * (double)x.C, 4 * p.M, cv.cout, 4 * x.C, 5));
         F_HIP(e, launch_gemm(p, s));
         return prof_end();
     }
@@ -417,7 +455,9 @@ int run_forward32(dm_f32_net* e, const Args32& A, hipStream_t s, bool dry) {
             int OH = cur.H * 2, OW = cur.W * 2;
             if (fwd_up_size && !skips.empty()) { OH = skips.back().H; OW = skips.back().W; }
             T32 upc;
-            F_TRY(F.gemm(u.up, 3, cur, nullptr, OH, OW, nullptr, 0, nullptr, &upc));
+            // exact 2x: four 2x2 convolutions on the source grid (4/9 of the MACs; option up_fold, as the fp16 engine)
+            if (dm_get_option_up_fold() && u.has_up4 && OH == 2 * cur.H && OW == 2 * cur.W) F_TRY(F.upconv4(u.up4, cur, &upc));
+            else F_TRY(F.gemm(u.up, 3, cur, nullptr, OH, OW, nullptr, 0, nullptr, &upc));
             F.free(cur);
             cur = upc;
         }
@@ -645,7 +685,11 @@ int dm_f32_finalize(dm_f32_net* e) {
             if (u.attn) F_TRY(pack_tfm(e, b + ".attentions." + std::to_string(j), out_c, &u.tf[j]));
         }
         u.has_up = i != NB - 1;
-        if (u.has_up) F_TRY(pack_conv3(e, "up_blocks." + std::to_string(i) + ".upsamplers.0.conv", out_c, out_c, &u.up));
+        if (u.has_up) {
+            F_TRY(pack_conv3(e, "up_blocks." + std::to_string(i) + ".upsamplers.0.conv", out_c, out_c, &u.up));
+            F_TRY(pack_upconv4(e, "up_blocks." + std::to_string(i) + ".upsamplers.0.conv", out_c, out_c, u.up, &u.up4));
+            u.has_up4 = true;
+        }
         prev = out_c;
     }
     F_TRY(pack_norm(e, "conv_norm_out", BOC[0], &e->norm_out));

@@ -86,6 +86,31 @@ def test_gemm32_conv_modes(mode, N, H, W, C1, C2, Cout, OH, OW):
     assert r < TOL_OP
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 8, 8, 640, 640), (3, 5, 7, 64, 320), (1, 1, 2, 32, 128), (2, 16, 16, 1280, 1280)])
+def test_gemm32_upconv_folded(N, H, W, Cin, Cout):
+    """gemm32 mode 5 (option up_fold in the fp32 net): Upsample2D — nearest 2x, then conv3x3 pad 1 — as four 2x2 convolutions on the
+    source grid with the 3x3 taps that read the same source pixel pre-summed (double sum, one fp32 rounding), against
+    F.conv2d(F.interpolate(x)) in fp32 at the operator tolerance; ragged rows, a one-row image, Cout below the channel tile."""
+    lib = E.load_library()
+    x = _randn(N, Cin, H, W, seed=1)
+    w = _randn(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    b = _randn(Cout, seed=3)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+    sel = {0: ([0], [1, 2]), 1: ([0, 1], [2])}
+    wd = w.double()
+    w4 = torch.stack([torch.cat([wd[:, :, sel[py][a], :][:, :, :, sel[px][bb]].sum(dim=(2, 3)) for a in (0, 1) for bb in (0, 1)], dim=1)
+                      for py in (0, 1) for px in (0, 1)], 0).float().contiguous()        # [4][Cout][(a*2+b)*Cin + ci]
+    X = U.to_nhwc(x).cuda()
+    Y = torch.empty(N, 2 * H, 2 * W, Cout, dtype=torch.float32, device=X.device)
+    W4, B = w4.cuda(), b.cuda()
+    rc = lib.dm_f32_op_gemm(U.stream(), U.ptr(X), None, U.ptr(W4), U.ptr(B), None, None, U.ptr(Y), N, H, W, H, W, Cin, Cin, Cout, 5, 0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    r = U.rel_l2(U.to_nchw(Y).cpu(), ref)
+    print(f"gemm32 mode 5 (folded up-sampler) {N}x{H}x{W} {Cin}->{Cout}: rel-L2 {r:.2e}")
+    assert r < TOL_OP
+
+
 @pytest.mark.parametrize("M,K,Nn", [(77 * 3, 768, 640), (5, 320, 1280), (1000, 1280, 20160), (4096, 320, 2560)])
 def test_gemm32_dense(M, K, Nn):
     x = _randn(M, K, seed=1)
