@@ -257,6 +257,9 @@ def main():
         }
         if eng is not None:
             out["engine_stats"] = eng.stats()
+            from diff_mining_amd.engine import get_options
+            # the algebraic rewrites / schedules the line was measured with (all numerically equivalent to the layer-by-layer order)
+            out["config"]["engine_options"] = get_options()
         out["roofline"]["traffic_recorded_from"] = TRAFFIC_SOURCE.get("file")
         if world > 1:
             out["ranks_seen"] = dist.get_world_size()

@@ -63,6 +63,7 @@ inline void launch_timed(F kernel, const dim3& grid, const dim3& block, size_t l
 enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_TAP_REUSE, OPT_UP_FOLD, OPT_COUNT };
 int option(Option o);                       // engine.hip
 int set_option(const char* name, int value);   // 0 on success
+int get_option(const char* name, int* value);  // 0 on success
 
 // ---- K1/K2/K3: implicit-GEMM on MFMA (conv3x3 s1/s2/upsampled, 1x1 conv, linear) -------------
 enum IGemmMode { IG_DENSE = 0, IG_CONV3 = 1, IG_CONV3_S2 = 2, IG_CONV3_UP = 3, IG_CONV3_S2P0 = 4, IG_CONV2_UP4 = 5 };

@@ -1238,6 +1238,12 @@ void fold_upconv_weights(const f16* w, int cout, int cin, f16* out) {
                         }
         }
 }
+int get_option(const char* name, int* value) {
+    opts_init();
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (name && value && !strcmp(name, kOpts[i].name)) { *value = g_opt[i].load(); return 0; }
+    return 1;
+}
 int set_option(const char* name, int value) {
     opts_init();
     for (int i = 0; i < OPT_COUNT; ++i)
@@ -2026,6 +2032,7 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
 }
 
 int dm_set_option(const char* name, int value) { return dm::set_option(name, value); }
+int dm_get_option(const char* name, int* value) { return dm::get_option(name, value); }
 
 int dm_op_igemm_tile(int M, int Cin, int Cout, int mode) {
     IGemmParams p{};

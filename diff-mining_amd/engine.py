@@ -27,12 +27,25 @@ SYMBOLS = [
     "dm_engine_load_clip_weight", "dm_engine_finalize_clip", "dm_clip_encode", "dm_op_igemm_splitk",
     "dm_op_ln_stats", "dm_op_igemm_ln", "dm_reduce_typicality_batched", "dm_op_igemm_tile", "dm_op_igemm_head_rows", "dm_set_option",
     "dm_engine_reserve", "dm_engine_stats", "dm_op_groupnorm_conv1x1", "dm_op_igemm_shortcut", "dm_normalize_map",
-    "dm_op_fold_upconv_weights", "dm_op_upconv_folded", "dm_prof_read_folded",
+    "dm_op_fold_upconv_weights", "dm_op_upconv_folded", "dm_prof_read_folded", "dm_get_option",
     "dm_f32_create", "dm_f32_destroy", "dm_f32_last_error", "dm_f32_load_weight", "dm_f32_finalize", "dm_f32_set_prompts",
     "dm_f32_unet_forward", "dm_f32_dift", "dm_f32_prof_enable", "dm_f32_prof_read", "dm_f32_memory", "dm_f32_op_gemm",
     "dm_f32_op_attention", "dm_f32_op_groupnorm", "dm_f32_op_layernorm", "dm_f32_load_vae_weight", "dm_f32_finalize_vae",
     "dm_f32_vae_encode", "dm_f32_score",
 ]
+
+
+def get_options(names=("ln_fold", "gn_fold", "ff_fold", "sc_fold", "up_fold", "tap_reuse", "ln_inkernel", "igemm_splitk", "graph")) -> dict:
+    """Current values of the library's runtime switches (dm_get_option); {} with a library that predates the getter."""
+    lib = load_library()
+    out = {}
+    if not hasattr(lib, "dm_get_option"):
+        return out
+    for n in names:
+        v = C.c_int32()
+        if lib.dm_get_option(n.encode(), C.byref(v)) == 0:
+            out[n] = v.value
+    return out
 
 
 class EngineError(RuntimeError):
@@ -95,6 +108,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_clip_encode.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     lib.dm_op_igemm_tile.argtypes = [i32, i32, i32, i32]
     lib.dm_set_option.argtypes = [C.c_char_p, i32]
+    if hasattr(lib, "dm_get_option"):
+        lib.dm_get_option.argtypes = [C.c_char_p, C.POINTER(i32)]
     lib.dm_op_attention512.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float]
     if hasattr(lib, "dm_op_igemm_shortcut"):
         lib.dm_op_igemm_shortcut.argtypes = [vp] * 8 + [i32] * 8

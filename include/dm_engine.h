@@ -274,6 +274,8 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
  *   "graph" (0 / 1): replay whole U-Net runs as captured hipGraphs (bit-identical: the same kernels with the same arguments);
  *   "igemm_exp": experimental kernel paths of the current round (0 = shipped). */
 int dm_set_option(const char* name, int value);
+/* current value of a switch (bench.py prints the arithmetic rewrites a line was measured with); nonzero for an unknown name */
+int dm_get_option(const char* name, int* value);
 
 /* which tile geometry dm_op_igemm runs a shape on: 0 = 128-row tile (128x320 / 128x160), 1 = persistent 256x320 tile */
 int dm_op_igemm_tile(int M, int Cin, int Cout, int mode);
