@@ -201,6 +201,27 @@ def test_unet32_vs_fp32_oracle(net32, sd15_weights_torch, h, w, B):
     assert out.shape == ref.shape and torch.isfinite(out).all() and r < TOL_E2E
 
 
+def test_unet32_up_fold_option(net32, sd15_weights_torch):
+    """Option "up_fold" in the fp32 net (gemm32 mode 5): on and off agree at the fp32 summation-order level and are equally far from
+    the fp32 oracle (the summed taps are rounded at 2^-24)."""
+    lib = net32.lib
+    noisy, t, c = _inputs(16, 16, 2)
+    slots = torch.tensor([0, 1], dtype=torch.int32)
+    net32.set_prompts(c)
+    out = {}
+    try:
+        for v in (1, 0):
+            assert lib.dm_set_option(b"up_fold", v) == 0
+            out[v] = net32.unet(noisy, t, slots).cpu()
+    finally:
+        lib.dm_set_option(b"up_fold", 1)
+    ref = R.unet_forward(sd15_weights_torch, noisy, t, c[slots.long()], autocast=False)
+    d, r1, r0 = U.rel_l2(out[1], out[0]), U.rel_l2(out[1], ref), U.rel_l2(out[0], ref)
+    print(f"unet32 up_fold on vs off {d:.2e}; vs the fp32 oracle on {r1:.2e} off {r0:.2e}")
+    # on vs off: a different k walk of three layers = a re-ordering of fp32 partial sums (the oracle against itself under re-orderings: 2.8-3.1e-6)
+    assert not torch.equal(out[1], out[0]) and d < 4e-6 and r1 < TOL_E2E and r0 < TOL_E2E and r1 <= 1.2 * r0
+
+
 @pytest.mark.parametrize("idx", [0, 1, 2, 3])
 def test_dift32_vs_fp32_oracle(net32, sd15_weights_torch, idx):
     """MyUNet2DConditionModel.forward's tap at every up_ft_index + the ensemble mean of SDFeaturizer.forward (dift.py:231)."""

@@ -1139,3 +1139,23 @@ def test_upconv_folded(N, H, W, Cin, Cout):
     # end to end the distance to the fp32 oracle moves 8.99e-4 -> 9.11e-4: tests/test_gpu_e2e.py::test_up_fold_option_end_to_end)
     assert r <= 1.6 * r0 + 1e-5 and r < 4e-4, (r, r0)
     assert d_fold < 6e-4
+
+
+def test_upconv_folded_refuses_what_it_does_not_take():
+    """The folded up-sampler exists on the 320-channel persistent tile only: other shapes must fail loudly (nonzero return, nothing
+    written), never fall back silently — the engine keeps the unfolded layer for them (igemm_up4_ok)."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    x = torch.zeros(1, 4, 4, 64, dtype=torch.float16, device=d)
+    y = torch.full((1, 8, 8, 320), 7.0, dtype=torch.float16, device=d)
+    w4 = torch.zeros(4, 320, 4 * 64, dtype=torch.float16, device=d)
+    b = torch.zeros(320, dtype=torch.float16, device=d)
+    args = (U.stream(), U.ptr(x), U.ptr(w4), U.ptr(b), U.ptr(y))
+    assert lib.dm_op_upconv_folded(*args, 1, 4, 4, 64, 160) != 0          # Cout not a multiple of 320
+    assert lib.dm_op_upconv_folded(*args, 1, 4, 4, 48, 320) != 0          # Cin not a multiple of 64
+    assert lib.dm_op_upconv_folded(*args, 1, 600, 4, 64, 320) != 0        # packed row coordinates: side <= 511
+    assert lib.dm_op_upconv_folded(*args, 1, 1, 1, 64, 320) != 0          # a single source row per class
+    torch.cuda.synchronize()
+    assert (y == 7.0).all()
+    assert lib.dm_op_fold_upconv_weights(None, 320, 64, None) != 0
