@@ -5,7 +5,7 @@ switch off).  A rewrite that perturbs the weights (up_fold: summed taps rounded 
 effect on T does not average out over the draws the way rounding noise does — so the signed, paired statistics matter, not only the
 medians of tools/t_deviation_gpu.py.
 
-    python tools/t_deviation_fold.py [n_images] [option=up_fold] > profiles/r04_T_deviation_up_fold_paired.txt
+    python tools/t_deviation_fold.py [n_images] [option[,option...]=up_fold] > profiles/r04_T_deviation_up_fold_paired.txt
 """
 import os
 import sys
@@ -23,7 +23,8 @@ from diff_mining_amd.typicality import TypicalityScorer  # noqa: E402
 
 def main():
     n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-    opt = (sys.argv[2] if len(sys.argv) > 2 else "up_fold").encode()
+    opts = [o.encode() for o in (sys.argv[2] if len(sys.argv) > 2 else "up_fold").split(",")]      # several switches: toggled together
+    opt = b"+".join(opts)
     N, hw = 10, 64
     sdn = synth.synth_state_dict(seed=0, dtype=np.float16)
     e16, e32 = UNetEngine(0), UNetEngineF32(0)
@@ -40,10 +41,12 @@ def main():
         noises, ts = sc.draw(x.shape)
         g = {}
         for v in (1, 0):
-            assert lib.dm_set_option(opt, v) == 0
+            for o in opts:
+                assert lib.dm_set_option(o, v) == 0
             g[v] = sc.compute_losses(x, c, noises=noises, timesteps=ts, to_host=False).float()
         ref = e32.score_conds(x, noises, ts, 2).view(2, N, 4, hw, hw).transpose(0, 1)        # fp32 net, switch off
-        lib.dm_set_option(opt, 1)
+        for o in opts:
+            lib.dm_set_option(o, 1)
         T32 = (ref[:, 1] - ref[:, 0]).double().mean().item()
         ml = ref.mean().item()
         T = {v: (g[v][:, 1] - g[v][:, 0]).double().mean().item() for v in (1, 0)}
