@@ -355,14 +355,21 @@ hipError_t launch_attention_pipe80(const AttnParams& p, hipStream_t s);  // atte
 bool attention_pipe80_supports(const AttnParams& p);
 hipError_t launch_attention_cross(const AttnParams& p, hipStream_t s);   // attention_cross.hip
 bool attention_cross_supports(const AttnParams& p);
+hipError_t launch_attention_pp(const AttnParams& p, int variant, hipStream_t s);   // attention_pp.hip
+bool attention_pp_supports(const AttnParams& p);
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.Tq <= 0 || p.Tk <= 0 || p.B <= 0) return hipErrorInvalidValue;
     // long head_dim-40 / 80 self-attention: software-pipelined variants (DM_ATTN_PIPE=0 disables)
     if (option(OPT_ATTN_CROSS) && attention_cross_supports(p)) return launch_attention_cross(p, s);   // 77-key cross-attention
     const int pipe = option(OPT_ATTN_PIPE);
+    if (pipe >= 4 && attention_pp_supports(p)) return launch_attention_pp(p, pipe, s);        // anti-phase wave sets (r05)
+    // default: the three-set anti-phase kernel where it measured faster (>= 8192 keys: the 128x128 level of a 1024-pixel image, -4...6 %
+    // per launch; bit-identical to attn_pipe_kernel) and its 384-query blocks waste < 2 % of their rows; attn_pipe = 2 / 3 keep the r04 kernels
+    if (pipe == 1 && p.Tk >= 8192 && attention_pp_supports(p) && (long long)((p.Tq + 383) / 384) * 384 * 50 <= 51LL * p.Tq)
+        return launch_attention_pp(p, 12, s);
     if (pipe && attention_pipe_supports(p)) return launch_attention_pipe(p, s);
-    if ((pipe == 1 || pipe == 3) && attention_pipe80_supports(p)) return launch_attention_pipe80(p, s);     // attn_pipe = 2: head_dim 40 only (A/B)
+    if ((pipe == 1 || pipe >= 3) && attention_pipe80_supports(p)) return launch_attention_pipe80(p, s);     // attn_pipe = 2: head_dim 40 only (A/B)
     switch (p.D) {
         case 40: return launch_t<40, 2>(p, s);
         case 80: return launch_t<80, 2>(p, s);

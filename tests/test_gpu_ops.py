@@ -264,6 +264,43 @@ def test_attention_pipelined_kernels_ragged_queries_and_rescale(D, Tq, Tk, spike
     U.assert_close_fp16(o, o_plain.float().cpu(), f"pipelined vs plain D={D}", rel=3e-3, abs_frac=4e-3)
 
 
+@pytest.mark.parametrize("variant", [4, 10, 12])
+@pytest.mark.parametrize("Tq,Tk,spike", [(4096, 4096, 3000), (300, 384, 300), (256, 320, None), (1000, 256, 100), (512, 1024, -1)])
+def test_attention_antiphase_kernel(variant, Tq, Tk, spike):
+    """attention_pp.hip (head_dim 40; two wave sets per SIMD half an iteration apart): ragged query counts, key counts that are
+    odd multiples of the 64-key tile, the minimum of four tiles, a late dominating key (lazy rescale), and all-negative logits
+    (spike = -1: the first tile must set the running max whatever its sign); against fp32 SDPA and the generic kernel."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    heads, B, D = 8, 2, 40
+    Cc = heads * D
+    q = U.f16_randn(B, Tq, Cc, seed=33)
+    k = U.f16_randn(B, Tk, Cc, seed=34)
+    v = U.f16_randn(B, Tk, Cc, seed=35)
+    if spike == -1:
+        q = (q.float().abs() * 3.0).half()
+        k = (-k.float().abs() * 3.0).half()               # every logit strongly negative: sc * q.k ~ -500
+    elif spike is not None:
+        k[:, spike] = q[:, 7] * 4.0
+
+    def split(t, T):
+        return t.float().view(B, T, heads, D).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(split(q, Tq), split(k, Tk), split(v, Tk)).transpose(1, 2).reshape(B, Tq, Cc)
+    d = U.dev()
+    qd, kd, vd = q.to(d), k.to(d), v.to(d)
+    try:
+        assert lib.dm_set_option(b"attn_pipe", variant) == 0
+        o = U.op_attention(qd, kd, vd, heads)
+        o2 = U.op_attention(qd, kd, vd, heads)
+        assert lib.dm_set_option(b"attn_pipe", 0) == 0
+        o_plain = U.op_attention(qd, kd, vd, heads)
+    finally:
+        lib.dm_set_option(b"attn_pipe", 1)
+    assert torch.equal(o, o2), "not deterministic"
+    U.assert_close_fp16(o, ref, f"anti-phase attn v{variant} Tq={Tq} Tk={Tk}", rel=3e-3, abs_frac=4e-3)
+    U.assert_close_fp16(o, o_plain.float().cpu(), f"anti-phase vs plain v{variant}", rel=3e-3, abs_frac=4e-3)
+
+
 @pytest.mark.parametrize("C1,C2,silu,eps", [(320, 0, True, 1e-5), (640, 0, False, 1e-6), (1280, 640, True, 1e-5),
                                             (640, 320, True, 1e-5), (1280, 1280, True, 1e-5)])
 def test_groupnorm(C1, C2, silu, eps):

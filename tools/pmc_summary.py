@@ -11,7 +11,9 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
         name = r["Kernel_Name"]
         if "dm::" not in name and "_ZN2dm" not in name:
             continue
-        name = name.split("(")[0][-60:]
+        import re
+        m = re.search(r"(\w+_kernel\w*(?:<[^>]*>)?)", name)          # keep template arguments: they tell the variants apart
+        name = m.group(1) if m else name.split("(")[0][-60:]
         acc[(name, r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
     print(k)
