@@ -2,9 +2,11 @@
 """bench.py — typicality-scored images/sec/node (BASELINE.json metric) on N MI355X of one node.
 
 One "step" = one pass of the hot path over one batch of synthetic input PER GPU:
-    8 images of 512x512 (latent 4x64x64), each scored with 10 (t, eps) draws x 2 prompts
-    = 160 SDv1.5 U-Net forwards of the fused add_noise -> U-Net -> eps-MSE path (dm_score_conds: the
-    reference's draw-tiled-over-prompts batch, prompt-independent head computed once per draw), then ONE
+    8 images of 512x512 (latent 4x64x64), each under ITS OWN category prompt and the shared null prompt (the reference's work
+    list: one `path,category` line per image, compute.py:284-290), each scored with 10 (t, eps) draws x 2 prompts
+    = 160 SDv1.5 U-Net forwards of the fused add_noise -> U-Net -> eps-MSE path, through the PRODUCT SURFACE
+    `TypicalityScorer.compute_losses_batch` -> [8, 10, 2, 4, 64, 64] fp16 grids (dm_score_conds_slots: the reference's
+    draw-tiled-over-prompts batch with a per-image prompt-slot table, prompt-independent head computed once per draw), then ONE
     on-device typicality reduction over all images (dm_reduce_typicality_batched); N > 1: plus ONE all-gather
     of the per-image T(x|c) scalars (RCCL over xGMI).  This is BASELINE.json configs[1] (and [2] for N>1).
 Inputs (fp32 latents and draws like the reference's, fp16 prompt embeddings) and the synthetic fp16 weights are
@@ -17,8 +19,12 @@ sharding `r::N` as the reference's `subs[i::sub_split]` (diffmining/typicality/c
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     — dominant kernel = the implicit-GEMM MFMA kernel family (84 % of the FLOPs; igemm_pers_kernel + igemm_kernel):
-                 achieved = its algorithmic FLOPs / its summed launch time, measured with HIP events
-                 on the launch stream over the timed steps (dm_prof_*); peak = 2.5 PFLOP/s dense fp16.
+                 achieved = the multiply-adds its launches ISSUED / their summed kernel time, measured with HIP events
+                 on the launch stream over the timed steps (dm_prof_*); peak = 2.5 PFLOP/s dense fp16.  `achieved_nominal` books
+                 SURVEY 8d's algorithmic count instead (Upsample2D.conv = interpolate + nine taps; `up_fold` issues 4/9 of that).
+  single_image_call — images/s of `TypicalityScorer.compute_losses` on ONE image (the reference's own call, compute.py:134-160) at
+                 N = 10 draws (20 U-Net samples per engine call) and at the reference default N = 100 (compute.py:106).
+  side_workloads — BASELINE configs[3] (DIFT-161 in the reference's fp32) and configs[4] (X-ray 1024 px heat-map), 3 steps each.
   cpu_baseline — the oracle (fp32 PyTorch-CPU restatement; kind "port") timed on this host's cores on
                  one full image of the workload (20 U-Net forwards @64x64, ~45 s).
 `--workload dift|xray` print the same keys for BASELINE configs[3] / [4].
@@ -40,6 +46,7 @@ import torch  # noqa: E402
 FLOP_PER_FORWARD_64 = 803.27e9          # SURVEY.md §8d (2 FLOP/MAC, attention included), nominal
 N_IMG, N_DRAWS, N_COND, LAT = 8, 10, 2, 64
 PEAK_TFLOPS = 2500.0                    # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
+SCORE_DEVIATION_MAX = 1.0e-3            # north_star: "<= 1e-3 score deviation from reference" on the loss grid (vs exact fp32, same inputs)
 PEAK_TFLOPS_F32 = 157.3                 # MI355X fp32 matrix (v_mfma_f32_*_f32: 256 FLOP/clk/CU; MI355X_MICROARCH.md "Peak FP32 (matrix)")
 STUB = os.environ.get("DM_BENCH_STUB", "0") not in ("", "0")     # CPU test of the launcher / gather path (gloo, no engine)
 
@@ -65,6 +72,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the single-image and side-workload legs (configs[3], [4]) behind the timed region")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the score-deviation leg (image 0 of the step re-scored in exact fp32 on the GPU by the fp32 net, after the timed region)")
     ap.add_argument("--images", type=int, default=N_IMG)
@@ -122,7 +130,8 @@ def main():
         eng = UNetEngineF32(local_rank) if (args.workload == "dift" and args.dift_dtype == "f32") else UNetEngine(local_rank)
         eng.load_state_dict(sd)
         if args.workload != "typicality":
-            return side_workload(args, eng, dev, sd)
+            print(json.dumps(side_workload(args, eng, dev, sd)), flush=True)
+            return
         ldt = torch.float32 if args.latent_dtype == "f32" else torch.float16
         x, eps, t, c = synth.synth_inputs(n_img * world, N_DRAWS, LAT, LAT,
                                           latent_dtype=np.float32 if args.latent_dtype == "f32" else np.float16)
@@ -132,18 +141,21 @@ def main():
         eps = torch.from_numpy(eps).to(dev)
         t = torch.from_numpy(t).to(dev)
         c = torch.from_numpy(c).to(dev)
-        eng.set_prompts(c)
-        # the 80 distinct (image, draw) pairs of the step, image-major; each is scored under the N_COND prompts
-        # (D.compute_losses tiles exactly this, compute.py:150-152: same draws for every image, seed 42)
-        eps_u = eps.repeat(n_img, 1, 1, 1).contiguous()
-        t_u = t.repeat(n_img).contiguous()
-        x_index = torch.arange(n_img, dtype=torch.int32, device=dev).repeat_interleave(N_DRAWS).contiguous()
+        # the work list: image j under ITS OWN category prompt and the shared null prompt (compute.py:284-290, 182-192): 8 categories
+        # (c[0] and seven more, same distribution) + c[1] = 9 distinct prompts, registered once
+        gcat = torch.Generator().manual_seed(77)
+        cats = torch.cat([c[:1].cpu(), torch.randn(n_img - 1, 77, 768, generator=gcat).to(torch.float16)]).to(dev)
+        emb = torch.stack([torch.stack([cats[j], c[1]]) for j in range(n_img)]).contiguous()       # [n_img, 2, 77, 768]
+        from diff_mining_amd.typicality import TypicalityScorer
+        scorer = TypicalityScorer(eng, seed=42, N=N_DRAWS, t_min=0.1, t_max=0.7, latent_dtype=ldt)
         last = {}
 
         def step():
-            loss = eng.score_conds(x, eps_u, t_u, N_COND, x_index=x_index, latent_dtype=ldt)   # [2*n_img*10,4,64,64] fp32, cond-major
-            _, scores = eng.reduce_typicality_batched(loss, n_img, N_DRAWS, N_COND, cond_major=True)   # one launch, no torch glue
-            last["loss"] = loss
+            # the product surface: D.compute_losses for the 8 images of the work-list slice in ONE engine call; the same N draws for
+            # every image (manual_seed(42) precedes each image's draws, compute.py:139-141)
+            grids = scorer.compute_losses_batch(x, emb, noises=eps, timesteps=t, to_host=False)    # [n_img, 10, 2, 4, 64, 64] fp16
+            _, scores = eng.reduce_typicality_batched(grids, n_img, N_DRAWS, N_COND)               # one launch, no torch glue
+            last["grids"], last["loss"] = grids, scorer.last_loss32
             return gather_scores(scores, n_img * world, rank, world)     # world 1: the tensor itself (no kernel)
 
     if eng is not None and os.environ.get("DM_GRAPH", "0") not in ("", "0"):
@@ -204,19 +216,20 @@ def main():
         t1 = time.perf_counter()
         for _ in range(2):
             step()
-            host.copy_(last["loss"].view(N_COND, n_img, N_DRAWS, 4, LAT, LAT).permute(1, 2, 0, 3, 4, 5).to(torch.float16))
+            host.copy_(last["grids"])
         sync()
         d2h = (time.perf_counter() - t1) / 2
 
     if rank == 0:
         total_images = n_img * world * args.steps
         value = total_images / dt
-        # ALGORITHMIC FLOPs per launch (SURVEY 8d's count: interpolate + 9 taps for Upsample2D.conv) over the launches' kernel time is
-        # `achieved`; with option up_fold those three layers EXECUTE 4/9 of that (four 2x2 convolutions with pre-summed taps,
-        # igemm_pers_up.hip), so the multiply-adds actually issued are reported beside it (`achieved_executed`, `frac_executed`)
+        # `achieved` / `frac` = the multiply-adds the launches ISSUED over their kernel time: a hardware roofline (the same
+        # convention as the side workloads).  SURVEY 8d's ALGORITHMIC count (interpolate + 9 taps for Upsample2D.conv, of which
+        # option up_fold executes 4/9: four 2x2 convolutions with pre-summed taps, igemm_pers_up.hip) is booked beside it as
+        # `achieved_nominal` / `frac_nominal`
         folded = prof.get("igemm_flops_folded", 0.0)
-        ig_tf = (prof["igemm_flops"] + folded) / (prof["igemm_ms"] * 1e-3) / 1e12 if prof["igemm_ms"] > 0 else 0.0
-        ig_tf_x = prof["igemm_flops"] / (prof["igemm_ms"] * 1e-3) / 1e12 if prof["igemm_ms"] > 0 else 0.0
+        ig_tf_n = (prof["igemm_flops"] + folded) / (prof["igemm_ms"] * 1e-3) / 1e12 if prof["igemm_ms"] > 0 else 0.0
+        ig_tf = prof["igemm_flops"] / (prof["igemm_ms"] * 1e-3) / 1e12 if prof["igemm_ms"] > 0 else 0.0
         at_tf = prof["attn_flops"] / (prof["attn_ms"] * 1e-3) / 1e12 if prof["attn_ms"] > 0 else 0.0
         # executed work = what the engine's launches actually computed on this rank (shared-draw prefix and the cached
         # cross-attention K/V are NOT re-done per prompt); nominal = 803.27 GFLOP x forwards, as SURVEY §8d counts
@@ -230,15 +243,17 @@ def main():
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "configs[1]: SDv1.5 U-Net fp16, 512x512 (latent 64x64), 10 t-samples x 2 prompts, "
                                    f"batch {n_img} images/GPU = {n_img * per_img} U-Net forwards/step/GPU, synthetic weights",
+                       "entry": "TypicalityScorer.compute_losses_batch (dm_score_conds_slots): each image under its own category + the shared null prompt",
                        "images_per_gpu_per_step": n_img, "unet_forwards_per_image": per_img,
                        "latent_dtype_flow": args.latent_dtype,
                        "parallelism": f"image-sharded x{world}, one all-gather of T(x|c)"},
             "roofline": {"bound": "mfma", "kernel": "igemm family: igemm_pers_kernel / igemm_pers_tr_kernel (persistent 256x320 tile; tr = 3x3 convolutions with horizontal tap reuse) + igemm_kernel (128x320 / 128x160 tile) incl. their LayerNorm-folded and split-K instantiations (implicit-GEMM conv3x3/1x1/linear)",
                          "achieved": round(ig_tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ig_tf / PEAK_TFLOPS, 4),
-                         "achieved_executed": round(ig_tf_x, 2), "frac_executed": round(ig_tf_x / PEAK_TFLOPS, 4),
-                         "flops_convention": "achieved = algorithmic FLOPs of the launches (SURVEY 8d: Upsample2D.conv = interpolate + 9 taps) / their kernel time; "
-                                             "achieved_executed = multiply-adds issued (up_fold runs those layers as four 2x2 convolutions: 4/9)",
+                         "achieved_executed": round(ig_tf, 2), "frac_executed": round(ig_tf / PEAK_TFLOPS, 4),
+                         "achieved_nominal": round(ig_tf_n, 2), "frac_nominal": round(ig_tf_n / PEAK_TFLOPS, 4),
+                         "flops_convention": "achieved (= achieved_executed) = multiply-adds issued by the launches / their kernel time; achieved_nominal = "
+                                             "SURVEY 8d's algorithmic count (Upsample2D.conv = interpolate + 9 taps; up_fold issues 4/9 of it)",
                          "folded_tflop_per_step": round(folded / max(args.steps, 1) / 1e12, 3),
                          "traffic": hbm_traffic_per_launch(prof["igemm_launches"] / max(args.steps, 1)),
                          "launches": prof["igemm_launches"], "kernel_ms_total": round(prof["igemm_ms"], 3),
@@ -272,28 +287,76 @@ def main():
                                        "all": [round(v, 3) for v in rank_ms]}
         if STUB:
             out["data"] = "stub (DM_BENCH_STUB=1: launcher / gather path only, no engine)"
+        net32 = None
+        if world == 1 and not STUB and (not args.no_parity or not args.no_side):
+            from diff_mining_amd.engine import UNetEngineF32
+            net32 = UNetEngineF32(dev.index or 0)          # the fp32 net: exact-fp32 reference of the deviation leg and the DIFT side workload
+            net32.load_state_dict(sd)
         if not args.no_parity and world == 1 and not STUB:
-            out["score_deviation"] = score_deviation(sd, eng, x[:1], eps, t, c, last["loss"], n_img, dev)
+            out["score_deviation"] = score_deviation(net32, x[:1], eps, t, emb[0], last["loss"], n_img)
+        if not args.no_side and world == 1 and not STUB:
+            out["single_image_call"] = single_image_call(eng, x[:1], emb[0], ldt)
+            out["side_workloads"] = {}
+            for w, e_ in (("dift", net32), ("xray", eng)):
+                a2 = argparse.Namespace(**vars(args))
+                a2.workload, a2.dift_dtype, a2.steps, a2.warmup, a2.no_cpu_baseline = w, "f32", 3, 1, True
+                ln = side_workload(a2, e_, dev, sd)
+                out["side_workloads"][w] = {"metric": ln["metric"], "value": ln["value"], "unit": ln["unit"], "ms_per_step": ln["ms_per_step"],
+                                            "steps": 3, "dtype": ln["dtype"], "config": ln["config"]["workload"],
+                                            "roofline": {k: ln["roofline"][k] for k in ("kernel", "achieved", "peak", "frac", "attention_tflops",
+                                                                                       "whole_path_frac_nominal")}}
+        if net32 is not None:
+            net32.close()
         if not args.no_cpu_baseline and world == 1 and not STUB:
             out["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(out), flush=True)
+        # north_star: "<= 1e-3 score deviation from reference" — a line whose own deviation leg exceeds it is printed and FAILS
+        dev_bad = "score_deviation" in out and out["score_deviation"]["loss_grid_rel_l2"] > SCORE_DEVIATION_MAX
+    else:
+        dev_bad = False
+    if world > 1:
+        dist.destroy_process_group()
+    if dev_bad:
+        sys.exit(f"bench.py: score_deviation.loss_grid_rel_l2 exceeds {SCORE_DEVIATION_MAX:g}")
+
+
+def single_image_call(eng, x0, embeds, ldt):
+    """The reference's own call shape: `D.compute_losses` on ONE image (compute.py:134-160) = `TypicalityScorer.compute_losses`, at
+    N = 10 draws (one engine call of 20 U-Net samples: the 8x8 / 16x16 / 32x32 levels give the 256x320 tile 20 / 80 / 160 tiles for
+    256 CUs) and at the reference default N = 100 (compute.py:106: 200 samples, engine chunks of 160 + 40)."""
+    from diff_mining_amd.typicality import TypicalityScorer
+    res = {}
+    for N, reps in ((10, 5), (100, 2)):
+        sc = TypicalityScorer(eng, seed=42, N=N, t_min=0.1, t_max=0.7, latent_dtype=ldt)
+        noises, ts = sc.draw(x0.shape)
+        noises, ts = noises.to(eng.device), ts.to(eng.device)
+        sc.compute_losses(x0, embeds, noises=noises, timesteps=ts, to_host=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g = sc.compute_losses(x0, embeds, noises=noises, timesteps=ts, to_host=False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        res[f"N{N}"] = {"images_per_s": round(1.0 / dt, 3), "ms_per_image": round(dt * 1e3, 2), "unet_samples_per_image": 2 * N,
+                        "images_per_s_at_10_draws_equivalent": round(N / 10.0 / dt, 3), "grid": list(g.shape)}
+    res["note"] = ("one image per engine call, scores left on the device; the batched entry (`value`) rides 8 images per call. "
+                   "N100 per 10 draws compares with `value`: the same engine batch (160 samples), one image's prompts")
+    return res
+
+
     if world > 1:
         dist.destroy_process_group()
 
 
-def score_deviation(sd, eng, x0, eps, t, c, loss, n_img, dev):
+def score_deviation(net, x0, eps, t, c, loss, n_img):
     """north_star ends on "<= 1e-3 score deviation from reference": image 0 of the timed step (its 10 draws x 2 prompts, the very
     losses the step produced) against the EXACT-fp32 evaluation of the same U-Net on the same inputs — the fp32 net (dm_f32_*,
     product code, 2-4e-6 from the CPU oracle's autocast=False arithmetic: tests/test_gpu_f32.py): dm_f32_score = compute.py:95-102 with no
     autocast.  Outside the timed region; the CPU oracle cannot reach this size."""
-    from diff_mining_amd.engine import UNetEngineF32
     t0 = time.perf_counter()
-    net = UNetEngineF32(dev.index or 0)
-    net.load_state_dict(sd)
-    net.set_prompts(c.float())
+    net.set_prompts(c.float())                                    # image 0's own (category, null) pair
     ref = net.score_conds(x0, eps, t, N_COND)                     # dm_f32_score: fp32 add_noise -> U-Net -> squared error, cond-major rows
     ref = ref.view(N_COND, N_DRAWS, 4, LAT, LAT).transpose(0, 1)
-    net.close()
     got = loss.view(N_COND, n_img, N_DRAWS, 4, LAT, LAT)[:, 0].transpose(0, 1).float()      # [N,2,4,h,w] of image 0 (cond 0 = c, 1 = null)
     T = (got[:, 1] - got[:, 0]).double().mean().item()
     T32 = (ref[:, 1] - ref[:, 0]).double().mean().item()
@@ -422,7 +485,7 @@ def side_workload(args, eng, dev, sd):
         line["dtype_note"] = dtype_note
     if not args.no_cpu_baseline and args.workload in ("dift", "xray"):
         line["cpu_baseline"] = cpu_baseline_side(sd, args.workload)
-    print(json.dumps(line), flush=True)
+    return line
 
 
 def _oracle_threads():

@@ -148,6 +148,7 @@ struct dm_engine {
     long long n_dry_runs = 0;
     int kv_capacity = 0;                                   // prompts the K/V cache buffers hold
     int* tile_ctr = nullptr;                               // tile hand-out counters of the persistent igemm (this engine's own)
+    void* slot_scratch = nullptr; size_t slot_scratch_cap = 0;   // chunk-local prompt-slot tables of dm_score_conds_slots
     // hipGraph replay of a whole U-Net run (option "graph"): one executable graph per (schedule key, every pointer argument),
     // captured on the second call with that key (the first one sets function attributes and sizes the arena, which a capture
     // cannot contain); dropped when the arena or the K/V cache move
@@ -822,7 +823,7 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
     const int B = A.B;
     const int NC = A.n_cond > 1 ? A.n_cond : 1;
     const int U = B / NC;                 // distinct (x, t, eps) draws; every draw is scored under NC prompts
-    F.slot_div = (NC > 1) ? U : 0;
+    F.slot_div = (NC > 1 && !A.slots) ? U : 0;       // shared-draw mode without a slot table: prompt k for every draw of block k
     // the persistent igemm kernel leaves its tile hand-out counters at zero — unless a launch faulted or was aborted; a run
     // starts from a known state either way (1 KB, stream-ordered)
     if (!dry && e->tile_ctr) DM_HIP(e, hipMemsetAsync(e->tile_ctr, 0, IGEMM_TILE_CTR_INTS * sizeof(int), s));
@@ -1299,6 +1300,7 @@ void dm_engine_destroy(dm_engine* e) {
     if (e->cslab) (void)hipFree(e->cslab);
     if (e->arena_base) (void)hipFree(e->arena_base);
     if (e->tile_ctr) (void)hipFree(e->tile_ctr);
+    if (e->slot_scratch) (void)hipFree(e->slot_scratch);
     if (e->sin_table) (void)hipFree(e->sin_table);
     if (e->sa_tab) (void)hipFree(e->sa_tab);
     if (e->sb_tab) (void)hipFree(e->sb_tab);
@@ -1818,14 +1820,17 @@ int dm_score(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, const 
     return run_chunked(e, A, n_x, stream);
 }
 
-int dm_score_conds(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, const void* eps_dev, const int64_t* t_dev,
-                   int n_cond, int n_draws, int n_x, int h, int w, int latent_dtype, void* loss_out_dev, void* stream) {
+int dm_score_conds_slots(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, const void* eps_dev, const int64_t* t_dev,
+                         const int32_t* slot_table_dev, int n_cond, int n_draws, int n_x, int h, int w, int latent_dtype,
+                         void* loss_out_dev, void* stream) {
     if (!e) return 1;
     if (!x_dev || !eps_dev || !t_dev || !loss_out_dev) DM_FAIL(e, "dm_score_conds: null argument");
     if (latent_dtype != DM_F16 && latent_dtype != DM_F32) DM_FAIL(e, "dm_score_conds: latent_dtype must be DM_F16 or DM_F32");
     const size_t esz = latent_dtype == DM_F32 ? 4 : 2;
     if (n_cond < 1 || n_draws < 1) DM_FAIL(e, "dm_score_conds: bad n_cond / n_draws");
-    if (n_cond > e->n_prompts) DM_FAIL(e, "dm_score_conds: n_cond %d exceeds the %d registered prompts", n_cond, e->n_prompts);
+    if (n_cond == 1) DM_FAIL(e, "dm_score_conds: use dm_score for n_cond == 1");
+    if (!slot_table_dev && n_cond > e->n_prompts) DM_FAIL(e, "dm_score_conds: n_cond %d exceeds the %d registered prompts", n_cond, e->n_prompts);
+    if (slot_table_dev && e->n_prompts < 1) DM_FAIL(e, "dm_score_conds_slots: no prompts registered");
     if (!x_index_dev && n_x != n_draws) DM_FAIL(e, "dm_score_conds: x_index is NULL but n_x (%d) != n_draws (%d)", n_x, n_draws);
     if (!e->finalized) DM_FAIL(e, "engine not finalized");
     DM_HIP(e, hipSetDevice(e->device));
@@ -1833,6 +1838,18 @@ int dm_score_conds(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, 
     const size_t hw = (size_t)h * w;
     int uc = max_chunk(h, w) / n_cond;
     if (uc < 1) uc = 1;
+    const bool one_chunk = n_draws <= uc;
+    if (slot_table_dev && !one_chunk) {       // chunk-local [n_cond][nu] tables are gathered into an engine-owned buffer
+        const size_t need = (size_t)n_cond * uc * sizeof(int32_t);
+        if (need > e->slot_scratch_cap) {
+            DM_HIP(e, hipStreamSynchronize(s));
+            drop_graphs(e);
+            if (e->slot_scratch) DM_HIP(e, hipFree(e->slot_scratch));
+            e->slot_scratch = nullptr; e->slot_scratch_cap = 0;
+            DM_MALLOC(e, &e->slot_scratch, need);
+            e->slot_scratch_cap = need;
+        }
+    }
     for (int u0 = 0; u0 < n_draws; u0 += uc) {
         const int nu = (n_draws - u0 < uc) ? (n_draws - u0) : uc;
         FwdArgs A{};
@@ -1840,15 +1857,25 @@ int dm_score_conds(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, 
         A.latent_f32 = latent_dtype == DM_F32;
         if (!x_index_dev) A.x = (const char*)x_dev + (size_t)u0 * 4 * hw * esz;
         A.eps = (const char*)eps_dev + (size_t)u0 * 4 * hw * esz; A.t = t_dev + u0; A.slots = nullptr;
+        if (slot_table_dev) {
+            if (one_chunk) A.slots = slot_table_dev;
+            else {
+                DM_HIP(e, hipMemcpy2DAsync(e->slot_scratch, (size_t)nu * sizeof(int32_t), slot_table_dev + u0, (size_t)n_draws * sizeof(int32_t),
+                                           (size_t)nu * sizeof(int32_t), n_cond, hipMemcpyDeviceToDevice, s));
+                A.slots = (const int32_t*)e->slot_scratch;
+            }
+        }
         A.B = nu * n_cond; A.H = h; A.W = w; A.n_cond = n_cond; A.out_stride = n_draws; A.out_off = u0;
         A.add_noise = true; A.up_ft_index = -1; A.loss = (float*)loss_out_dev;
-        if (n_cond == 1) {          // degenerate: plain scoring of nu samples against prompt slot 0 .. handled by slot_div = 0
-            DM_FAIL(e, "dm_score_conds: use dm_score for n_cond == 1");
-        }
         DM_TRY(ensure_arena(e, A, s));
         DM_TRY(run_forward_graphed(e, A, s));
     }
     return 0;
+}
+
+int dm_score_conds(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, const void* eps_dev, const int64_t* t_dev,
+                   int n_cond, int n_draws, int n_x, int h, int w, int latent_dtype, void* loss_out_dev, void* stream) {
+    return dm_score_conds_slots(e, x_dev, x_index_dev, eps_dev, t_dev, nullptr, n_cond, n_draws, n_x, h, w, latent_dtype, loss_out_dev, stream);
 }
 
 int dm_unet_forward(dm_engine* e, const void* sample_dev, const int64_t* t_dev, const int32_t* slot_dev, int batch,

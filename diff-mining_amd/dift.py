@@ -60,6 +60,15 @@ class SDFeaturizer:
         self._registered = None             # (engine.prompt_generation, embeds fp16 [1,77,768]) of the last set_prompts made here
         self.prompt_registrations = 0
 
+    @staticmethod
+    def _version_of(t):
+        """`t._version`, or None for tensors without a version counter (created under `torch.inference_mode()`):
+        the identity fast path is skipped for them and the value comparison decides."""
+        try:
+            return None if t.is_inference() else t._version
+        except RuntimeError:
+            return None
+
     def _register_prompt(self, prompt_embeds):
         """`set_prompts` (the 16 blocks' cross-attention K/V projections of the prompt) only when the engine does not hold
         this prompt already: the reference featurises up to five patches per image under ONE category prompt (cluster.py:224-
@@ -68,16 +77,16 @@ class SDFeaturizer:
         eng = self.engine
         r = self._registered
         if r is not None and r[0] == eng.prompt_generation:
-            if r[1] is prompt_embeds and r[2] == prompt_embeds._version:          # the cached tensor of a string prompt
+            if r[1] is prompt_embeds and r[2] is not None and r[2] == self._version_of(prompt_embeds):   # the cached tensor of a string prompt
                 return
             pe16 = prompt_embeds.reshape(1, 77, -1).to(self.device, self.dtype)
             if r[3].shape == pe16.shape and torch.equal(r[3], pe16):             # a caller's fresh tensor with the same values
-                self._registered = (r[0], prompt_embeds, prompt_embeds._version, r[3])
+                self._registered = (r[0], prompt_embeds, self._version_of(prompt_embeds), r[3])
                 return
         pe = prompt_embeds.reshape(1, 77, -1)
         eng.set_prompts(pe)
         self.prompt_registrations += 1
-        self._registered = (eng.prompt_generation, prompt_embeds, prompt_embeds._version, pe.to(self.device, self.dtype).clone())
+        self._registered = (eng.prompt_generation, prompt_embeds, self._version_of(prompt_embeds), pe.to(self.device, self.dtype).clone())
 
     def add_noise(self, latents, noise, t):
         """DDIMScheduler.add_noise in the latents' dtype (dift.py:190; fp32 in the reference)."""
@@ -102,6 +111,9 @@ class SDFeaturizer:
                              "(engine.load_clip_state_dict; `aux=` when `engine` is the fp32 net); pass the [1,77,768] hidden states otherwise")
         tok = self.tokenizer
         ids = tok([prompt], max_length=tok.model_max_length, padding="max_length", truncation=True, return_tensors="pt").input_ids
+        # NOTE: the text tower runs on the fp16 engine also when `engine` is the fp32 net — the one fp16 stage of an
+        # otherwise fp32 featuriser (the reference's `pipe.encode_prompt` is fp32, dift.py:222-226); hidden states passed as a
+        # tensor are used as they are.  The engine's tower is 1.1e-3 (rel-L2) from transformers' fp32 output.
         emb = self.aux.clip_encode(ids)
         self._prompt_cache[prompt] = emb
         while len(self._prompt_cache) > 256:

@@ -20,7 +20,7 @@ _CHECK_DEVICE_SLOTS = os.environ.get("DM_CHECK_SLOTS", "0") not in ("", "0")    
 SYMBOLS = [
     "dm_version", "dm_scheduler_alphas_cumprod", "dm_timestep_sinusoid", "dm_engine_create",
     "dm_engine_destroy", "dm_last_error", "dm_engine_load_weight", "dm_engine_finalize",
-    "dm_engine_set_prompts", "dm_score", "dm_score_conds", "dm_unet_forward", "dm_dift", "dm_dift_shape",
+    "dm_engine_set_prompts", "dm_score", "dm_score_conds", "dm_score_conds_slots", "dm_unet_forward", "dm_dift", "dm_dift_shape",
     "dm_reduce_typicality", "dm_typicality_image", "dm_prof_enable", "dm_prof_read", "dm_engine_memory",
     "dm_op_igemm", "dm_op_attention", "dm_op_groupnorm", "dm_op_layernorm",
     "dm_engine_load_vae_weight", "dm_engine_finalize_vae", "dm_vae_encode", "dm_op_attention512", "dm_patch_embed",
@@ -80,6 +80,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_engine_set_prompts.argtypes = [vp, vp, i32, vp]
     lib.dm_score.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.dm_score_conds.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.dm_score_conds_slots.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.dm_reduce_typicality_batched.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.dm_unet_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.dm_dift.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
@@ -391,15 +392,22 @@ class UNetEngine:
                                       B, x.shape[0], h, w, ld, C.c_void_p(out.data_ptr()), self._stream()), "dm_score")
         return out
 
-    def score_conds(self, x, eps, t, n_cond: int, x_index=None, latent_dtype=None):
-        """D.compute_losses' inner call pattern: each of the U draws (x, eps, t) under prompts 0..n_cond-1.
+    def score_conds(self, x, eps, t, n_cond: int, x_index=None, latent_dtype=None, slot_table=None):
+        """D.compute_losses' inner call pattern: each of the U draws (x, eps, t) under n_cond prompts.
         Returns loss [n_cond*U,4,h,w] fp32, cond-major (row k*U+i).  Bit-identical to `score` on the tiled
-        batch; the prompt-independent head of the U-Net runs once per draw.  latent_dtype as in `score`."""
+        batch; the prompt-independent head of the U-Net runs once per draw.  latent_dtype as in `score`.
+        slot_table [n_cond, U] int32 (optional): the registered prompt of draw i in its k-th condition — draws of images
+        with different categories in one call (the reference's work list, compute.py:284-290); default: prompt k for every draw."""
         torch = self._torch
         x, eps, ld = self._latents(x, eps, latent_dtype)
         U, _, h, w = eps.shape
         t = t.to(self.device, torch.int64).contiguous()
-        assert t.shape == (U,) and 2 <= n_cond <= self.n_prompts
+        assert t.shape == (U,) and n_cond >= 2
+        st = None
+        if slot_table is not None:
+            st = self._slots(torch.as_tensor(slot_table).reshape(-1), n_cond * U)
+        else:
+            assert n_cond <= self.n_prompts
         xi = None
         if x_index is not None:
             xi = torch.as_tensor(x_index, device=self.device).to(torch.int32).contiguous()
@@ -408,10 +416,11 @@ class UNetEngine:
             assert x.shape[0] == 1
             xi = torch.zeros(U, dtype=torch.int32, device=self.device)
         out = torch.empty(n_cond * U, 4, h, w, dtype=torch.float32, device=self.device)
-        self._check(self.lib.dm_score_conds(self._h, C.c_void_p(x.data_ptr()),
-                                            C.c_void_p(xi.data_ptr()) if xi is not None else None,
-                                            C.c_void_p(eps.data_ptr()), C.c_void_p(t.data_ptr()), n_cond, U,
-                                            x.shape[0], h, w, ld, C.c_void_p(out.data_ptr()), self._stream()),
+        self._check(self.lib.dm_score_conds_slots(self._h, C.c_void_p(x.data_ptr()),
+                                                  C.c_void_p(xi.data_ptr()) if xi is not None else None,
+                                                  C.c_void_p(eps.data_ptr()), C.c_void_p(t.data_ptr()),
+                                                  C.c_void_p(st.data_ptr()) if st is not None else None, n_cond, U,
+                                                  x.shape[0], h, w, ld, C.c_void_p(out.data_ptr()), self._stream()),
                     "dm_score_conds")
         return out
 

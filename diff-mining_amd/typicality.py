@@ -8,6 +8,7 @@
     SD.compute_loss          compute.py:95-102        TypicalityScorer.compute_loss
     D.noising                compute.py:115-124       TypicalityScorer.noising / draw
     D.compute_losses         compute.py:134-160       TypicalityScorer.compute_losses
+    compute_submission loop  compute.py:284-290       TypicalityScorer.compute_losses_batch (n images, each under its own category, one engine call)
     D.get_path / np.save     compute.py:162-163,192   TypicalityScorer.save_grid (same .npy layout)
     D.rescale                compute.py:165-180       TypicalityScorer.rescale
     D.compute / __call__ / exists  compute.py:182-202 TypicalityScorer.compute / __call__ / exists
@@ -34,6 +35,7 @@ Same names, argument meaning and output layout ([N, n_cond, 4, h, w] float16, co
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Optional, Sequence
 
 import numpy as np
@@ -105,8 +107,19 @@ class UNetCallable:
             self._hash_w = (torch.randint(-(1 << 40), 1 << 40, (words.shape[1],), generator=g, dtype=torch.int64) | 1).to(flat.device)
         return (words * self._hash_w).sum(1)
 
-    def _slots_for(self, c: torch.Tensor):
-        """Prompt slot of every row of c [n, 77, 768] (fp16, on the device).  Three paths, cheapest first:
+    @staticmethod
+    def _version_of(c):
+        """`c._version`, or None where tensors carry no version counter (created under `torch.inference_mode()`): the identity
+        fast path is then skipped and the row-hash path decides."""
+        try:
+            return None if c.is_inference() else c._version
+        except RuntimeError:
+            return None
+
+    def _slots_for(self, c, ident=None):
+        """Prompt slot of every row of c [n, 77, 768] (fp16, on the device; or a callable that builds it — only called when the
+        identity path misses).  `ident`: the caller's own tensor object when `c` is a derived view / cast of it (default: c).
+        Three paths, cheapest first:
           1. the same tensor object, unmodified, as the previous call (a caller that keeps its `c`): nothing runs;
           2. every row equals one of the prompts already registered (the reference builds a fresh `torch.cat` of the same
              n_cond embeddings for every chunk of every image, compute.py:152): a row hash finds the candidate slot, ONE exact
@@ -116,9 +129,12 @@ class UNetCallable:
         # the engine's K/V cache is shared: anyone else's set_prompts (SDFeaturizer, compute_losses, a direct
         # call) bumps `prompt_generation`, which invalidates every cache here
         valid = self._ctx_key is not None and self._ctx_generation == eng.prompt_generation
-        if valid and self._last is not None and self._last[0] is c and self._last[1] == c._version:
+        ident = c if ident is None else ident
+        if valid and self._last is not None and self._last[0]() is ident and self._last[1] == self._version_of(ident):
             self.stats["identity_hits"] += 1
             return self._last[2]
+        if callable(c):
+            c = c()
         flat = c.reshape(c.shape[0], -1)
         inv = None
         if valid and flat.shape[1] == self._ctx_key.shape[1] and flat.shape[1] % 2 == 0 and flat.dtype == torch.float16:
@@ -136,7 +152,8 @@ class UNetCallable:
             inv = inv.to(torch.int32)
             if self._key_hash is None:
                 self._ctx_key = None
-        self._last = (c, c._version, inv)
+        v = self._version_of(ident)
+        self._last = (weakref.ref(ident), v, inv) if v is not None else None   # a weak reference: the cache must not keep the caller's tensor alive
         return inv
 
     def __call__(self, sample, timestep, encoder_hidden_states, **_):
@@ -166,6 +183,7 @@ class TypicalityScorer:
         self.latent_dtype = latent_dtype
         self.typicality_path, self.which, self.country_embeds = typicality_path, which, country_embeds
         self.unet = UNetCallable(engine)
+        self.last_loss32 = None
 
     # -- D.load_image / SD.encode_vae (compute.py:126-132, 91-93) --------------------------------
     @staticmethod
@@ -235,6 +253,53 @@ class TypicalityScorer:
             slots = torch.zeros(N, dtype=torch.int32)
             loss = eng.score(x, noises, timesteps, slots, latent_dtype=self.latent_dtype)
         grid = loss.view(n_cond, N, *loss.shape[1:]).transpose(0, 1).to(torch.float16)   # compute.py:155,160
+        return grid.cpu() if to_host else grid.contiguous()
+
+    # -- D.compute_losses over a slice of the work list (compute.py:284-290, 182-192) ------------
+    @torch.no_grad()
+    def compute_losses_batch(self, xs, country_embeds, B: int = 10, noises=None, timesteps=None, to_host: bool = True):
+        """`D.compute_losses` for n images of one latent size in ONE engine call — what `compute_submission`'s loop over the
+        `path,category` lines of a work list (compute.py:284-290) does image by image, each image under ITS OWN category and the
+        shared null prompt (`D.compute`, compute.py:182-192).
+          xs [n,4,h,w] latents;  country_embeds [n_cond,77,768] (one prompt set for every image) or [n,n_cond,77,768] (per image;
+          repeated prompts — the null prompt, images of one category — are registered once);
+          noises / timesteps: None = D's own draws: `manual_seed(seed)` precedes every image's N draws (compute.py:139-141), so
+          images of one size see the SAME N (eps, t); or [N,4,h,w] / [N] shared, or [n,N,4,h,w] / [n,N] per image.
+        Returns [n, N, n_cond, 4, h, w] float16 — image j's slice is bit-equal to `compute_losses(xs[j:j+1], embeds_j)`: the engine
+        guarantees that a sample's bits do not depend on the batch it rides in; the prompt-independent head of the U-Net still
+        runs once per (image, draw)."""
+        eng = self.engine
+        n = xs.shape[0]
+        if noises is None or timesteps is None:
+            noises, timesteps = self.draw(xs[0:1].shape)
+        per_image_draws = noises.dim() == 5
+        N = noises.shape[1] if per_image_draws else noises.shape[0]
+        if per_image_draws:
+            assert noises.shape[0] == n and tuple(timesteps.shape) == (n, N), (noises.shape, timesteps.shape)
+            eps_all, t_all = noises.reshape((n * N,) + tuple(noises.shape[2:])), timesteps.reshape(n * N)
+        else:
+            eps_all, t_all = noises.repeat(n, 1, 1, 1), timesteps.repeat(n)          # image-major: row j*N + i = draw i of image j
+        x_index = torch.arange(n, dtype=torch.int32, device=self.device).repeat_interleave(N)       # built on the device: no H2D copy in the loop
+        per_image_prompts = country_embeds.dim() == 4
+        n_cond = country_embeds.shape[1] if per_image_prompts else country_embeds.shape[0]
+        table = None
+        if per_image_prompts:
+            assert country_embeds.shape[0] == n, (country_embeds.shape, n)
+            def flat_c():
+                return country_embeds.reshape((n * n_cond,) + tuple(country_embeds.shape[2:])).to(self.device, torch.float16)
+            # registers the distinct prompts; a caller that passes the same tensor again (a work list walked in batches of one
+            # category set, bench.py) takes the identity path: no hashing, no read-back
+            inv = self.unet._slots_for(flat_c, ident=country_embeds).reshape(n, n_cond)
+            table = inv.t().repeat_interleave(N, dim=1).contiguous()                 # [n_cond, n*N]: slot of draw (j, i) under condition k
+        else:
+            eng.set_prompts(country_embeds)
+        if n_cond >= 2:
+            loss = eng.score_conds(xs, eps_all, t_all, n_cond, x_index=x_index, latent_dtype=self.latent_dtype, slot_table=table)
+        else:
+            slots = table.reshape(-1) if table is not None else torch.zeros(n * N, dtype=torch.int32)
+            loss = eng.score(xs, eps_all, t_all, slots, x_index=x_index, latent_dtype=self.latent_dtype)
+        self.last_loss32 = loss             # diagnostics (bench.py's score_deviation): the call's fp32 losses, rows k*n*N + j*N + i
+        grid = loss.view(n_cond, n, N, *loss.shape[1:]).permute(1, 2, 0, 3, 4, 5).to(torch.float16)     # compute.py:155,160 per image
         return grid.cpu() if to_host else grid.contiguous()
 
     # -- D.get_path / np.save (compute.py:162-163,192) -------------------------------------------
@@ -405,26 +470,36 @@ def compute_losses_draw_split(scorer: "TypicalityScorer", x, country_embeds, ran
 
 @torch.no_grad()
 def score_images_sharded(scorer: "TypicalityScorer", latents, country_embeds, rank: int, world: int, B: int = 10,
-                         mode: str = "scalars"):
+                         mode: str = "scalars", images_per_call: int = 8):
     """The multi-GPU scoring step: `latents` = the whole work list [n_img, 4, h, w] (every rank sees the
-    list, as every reference process sees the submission files, compute.py:337-341).
-      n_img >= world: rank r scores images `r::world`; ONE all-gather of the per-image T(x|c) fp32 scalars
-                      (mode "scalars") or of the fp16 grids (mode "grids");
+    list, as every reference process sees the submission files, compute.py:337-341); `country_embeds` [n_cond,77,768] (one
+    prompt set) or [n_img,n_cond,77,768] (image j under its own category, compute.py:284-290).
+      n_img >= world: rank r scores images `r::world`, `images_per_call` at a time through `compute_losses_batch` (one engine
+                      call each); ONE all-gather of the per-image T(x|c) fp32 scalars (mode "scalars") or of the fp16 grids
+                      (mode "grids");
       n_img <  world: every image's N draws are split over the ranks and the grids gathered (`compute_losses_draw_split`);
                       the scalars are then reduced from the full grids on every rank.
     Returns T(x|c) [n_img] fp32 (mode "scalars") or the grids [n_img, N, n_cond, 4, h, w] fp16 (mode "grids")."""
     assert mode in ("scalars", "grids")
     n_img = latents.shape[0]
+    per_image = country_embeds.dim() == 4
     if n_img >= world:
         mine = shard_indices(n_img, rank, world)
-        grids = [scorer.compute_losses(latents[i:i + 1], country_embeds, B, to_host=False) for i in mine]
+        grids = []
+        for c0 in range(0, len(mine), max(1, images_per_call)):
+            idx = torch.as_tensor(mine[c0:c0 + max(1, images_per_call)], dtype=torch.long)
+            emb = country_embeds[idx] if per_image else country_embeds
+            grids.append(scorer.compute_losses_batch(latents[idx], emb, B, to_host=False))
+        local = torch.cat(grids) if grids else None
         if mode == "grids":
-            local = torch.stack(grids) if grids else torch.zeros((0,), dtype=torch.float16, device=scorer.device)
+            if local is None:
+                local = torch.zeros((0,), dtype=torch.float16, device=scorer.device)
             return gather_grids(local, n_img, rank, world)
-        local = torch.cat([scorer.typicality_scalar(g).reshape(1) for g in grids]) if grids else \
+        local = torch.cat([scorer.typicality_scalar(g).reshape(1) for g in local]) if local is not None else \
             torch.zeros(0, dtype=torch.float32, device=scorer.device)
         return gather_scores(local, n_img, rank, world)
-    grids = torch.stack([compute_losses_draw_split(scorer, latents[i:i + 1], country_embeds, rank, world, B) for i in range(n_img)])
+    grids = torch.stack([compute_losses_draw_split(scorer, latents[i:i + 1], country_embeds[i] if per_image else country_embeds,
+                                                   rank, world, B) for i in range(n_img)])
     if mode == "grids":
         return grids
     return torch.cat([scorer.typicality_scalar(g).reshape(1) for g in grids])

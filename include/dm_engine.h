@@ -98,6 +98,16 @@ int dm_score_conds(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, 
                    const int64_t* t_dev, int n_cond, int n_draws, int n_x, int h, int w, int latent_dtype,
                    void* loss_out_dev, void* stream);
 
+/* dm_score_conds with a prompt-slot TABLE: slot_table_dev [n_cond][n_draws] int32, entry (k, i) = the registered prompt that
+ * draw i is scored under in its k-th condition.  This is the batched form of the reference's work list (compute.py:284-290: one
+ * `path,category` line per image, D.compute(country, path) scores each image under ITS OWN category and the shared null prompt,
+ * :182-192): the draws of several images ride in one call, image j's draws carry (slot of category_j, slot of "") — the
+ * prompt-independent prefix still runs once per draw, and every draw's bits equal those of a per-image dm_score_conds call.
+ * slot_table_dev == NULL is dm_score_conds (prompt k for every draw).  Entries are clamped to the registered prompts on the device. */
+int dm_score_conds_slots(dm_engine* e, const void* x_dev, const int32_t* x_index_dev, const void* eps_dev,
+                         const int64_t* t_dev, const int32_t* slot_table_dev, int n_cond, int n_draws, int n_x, int h, int w,
+                         int latent_dtype, void* loss_out_dev, void* stream);
+
 /* `unet(sample, t, encoder_hidden_states).sample` (compute.py:100) without the fused
  * add_noise / loss: sample_dev [batch,4,h,w] fp16 -> out_dev [batch,4,h,w] fp16 (NCHW). */
 int dm_unet_forward(dm_engine* e, const void* sample_dev, const int64_t* t_dev, const int32_t* slot_dev,

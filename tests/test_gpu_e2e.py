@@ -524,6 +524,37 @@ def test_shared_draw_scoring_is_bit_identical(engine, h, w, U, n_img):
     assert torch.equal(engine.score_conds(x, eps, t, 3, x_index=xi), ref3)
 
 
+@pytest.mark.parametrize("h,w,n,N", [(16, 16, 5, 3), (64, 64, 9, 10)])
+def test_compute_losses_batch_is_bit_equal_to_the_per_image_calls(engine, h, w, n, N):
+    """the benchmarked path is the product surface.  `TypicalityScorer.compute_losses_batch` scores n images,
+    each under ITS OWN category prompt and the shared null prompt (the reference's work list, compute.py:284-290 -> D.compute
+    :182-192), in one engine call (dm_score_conds_slots) -> [n, N, 2, 4, h, w] fp16; every image's slice must be BIT-equal to
+    its own `compute_losses` call (a sample's bits do not depend on the batch it rides in, nor on the slot its prompt sits in).
+    (64, 64, 9, 10): 90 draws x 2 prompts = two engine chunks (80 + 10 draws): the chunk-local slot tables."""
+    from diff_mining_amd.typicality import TypicalityScorer
+    x, _, _, c = _inputs(h, w, 1, n_img=n, flow="f32")
+    g = torch.Generator().manual_seed(123)
+    cats = torch.randn(n, 77, 768, generator=g).half()
+    cats[3] = cats[1]                                               # two images of one category
+    emb = torch.stack([torch.stack([cats[j], c[1]]) for j in range(n)])       # [n, 2, 77, 768]
+    sc = TypicalityScorer(engine, seed=42, N=N, t_min=0.1, t_max=0.7)
+    d = U.dev()
+    grids = sc.compute_losses_batch(x.to(d), emb.to(d), to_host=False)
+    assert grids.shape == (n, N, 2, 4, h, w) and grids.dtype == torch.float16
+    assert engine.n_prompts == n                                    # n - 1 distinct categories + the null prompt
+    again = sc.compute_losses_batch(x.to(d), emb.to(d), to_host=False)
+    assert torch.equal(grids, again)
+    for j in range(n):
+        want = sc.compute_losses(x[j:j + 1].to(d), emb[j].to(d), to_host=False)
+        assert torch.equal(grids[j], want), f"image {j}: batched grid differs from its own compute_losses call"
+    # the same images under ONE prompt set (no slot table) and the scalars of the batched reduction
+    g1 = sc.compute_losses_batch(x.to(d), emb[0].to(d), to_host=False)
+    assert torch.equal(g1[0], grids[0]) and torch.equal(g1[2], sc.compute_losses(x[2:3].to(d), emb[0].to(d), to_host=False))
+    _, sc_b = engine.reduce_typicality_batched(grids, n, N, 2)
+    for j in range(n):
+        assert abs(sc_b[j].item() - sc.typicality_scalar(grids[j]).item()) <= 1e-6 * max(1.0, abs(sc_b[j].item()))
+
+
 def test_full_size_properties(engine):
     """BASELINE config 2 shape (64x64 latent, 10 t x 2 prompts): size-independent properties."""
     x, eps, t, c = _inputs(64, 64, 10)

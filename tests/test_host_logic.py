@@ -413,11 +413,17 @@ class _FakeScoreEngine(_FakeEngine):
     def _loss(self, x, eps, t, k):
         return ((x.float() * 0.5 + eps.float()) * (1.0 + t.float().view(-1, 1, 1, 1) / 1000.0) - self.ctx[k].mean()) ** 2
 
-    def score_conds(self, x, eps, t, n_cond, x_index=None, latent_dtype=None):
-        return torch.cat([self._loss(x, eps, t, k) for k in range(n_cond)])
+    def score_conds(self, x, eps, t, n_cond, x_index=None, latent_dtype=None, slot_table=None):
+        xs = x[torch.as_tensor(x_index).long()] if x_index is not None else x
+        if slot_table is None:
+            return torch.cat([self._loss(xs, eps, t, k) for k in range(n_cond)])
+        st = torch.as_tensor(slot_table).reshape(n_cond, -1)
+        return torch.cat([torch.cat([self._loss(xs[i:i + 1] if xs.shape[0] > 1 else xs, eps[i:i + 1], t[i:i + 1], int(st[k, i]))
+                                     for i in range(eps.shape[0])]) for k in range(n_cond)])
 
     def score(self, x, eps, t, slots, x_index=None, latent_dtype=None):
-        return torch.cat([self._loss(x, eps[i:i + 1], t[i:i + 1], int(s)) for i, s in enumerate(slots)])
+        xs = x[torch.as_tensor(x_index).long()] if x_index is not None else x
+        return torch.cat([self._loss(xs[i:i + 1] if xs.shape[0] > 1 else xs, eps[i:i + 1], t[i:i + 1], int(s)) for i, s in enumerate(slots)])
 
     def reduce_typicality(self, grid):
         m = (grid[:, -1].float().mean(1) - grid[:, 0].float().mean(1)).mean(0)
@@ -463,6 +469,59 @@ def test_sharded_scoring_world2_is_bit_equal_to_one_rank(tmp_path, n_img):
         assert torch.equal(grids, want_g), f"rank {r}: gathered grids differ from the single-rank grids"
         assert torch.equal(scal, want_s)
     assert T.draw_shard(7, 0, 2) == [0, 2, 4, 6] and T.draw_shard(7, 1, 2) == [1, 3, 5]
+
+
+def test_compute_losses_batch_is_the_per_image_loop():
+    """`compute_losses_batch` = the reference's loop over the `path,category` lines of a work list
+    (compute.py:284-290: each image under ITS OWN category and the shared null prompt, D.compute :182-192), n images in one
+    engine call.  Layout [n, N, n_cond, 4, h, w] fp16; every image's slice equals its own `compute_losses` call; repeated
+    prompts (the null prompt, two images of one category) are registered once; explicit per-image draws are honoured."""
+    sc = _fake_scorer(5)
+    g = torch.Generator().manual_seed(9)
+    lat = torch.randn(4, 4, 6, 5, generator=g)
+    cats = torch.randn(3, 77, 768, generator=g).half()
+    null = torch.randn(77, 768, generator=g).half()
+    which = [0, 2, 0, 1]                                           # images 0 and 2 share a category
+    emb = torch.stack([torch.stack([cats[w], null]) for w in which])   # [4, 2, 77, 768]
+    grids = sc.compute_losses_batch(lat, emb, to_host=False)
+    assert grids.shape == (4, 5, 2, 4, 6, 5) and grids.dtype == torch.float16
+    assert sc.engine.n_prompts == 4                                # 3 categories + the null prompt, each once
+    for j in range(4):
+        want = sc.compute_losses(lat[j:j + 1], emb[j], to_host=False)
+        assert torch.equal(grids[j], want), f"image {j}"
+    # one prompt set for all images
+    g2 = sc.compute_losses_batch(lat, emb[1], to_host=False)
+    for j in range(4):
+        assert torch.equal(g2[j], sc.compute_losses(lat[j:j + 1], emb[1], to_host=False))
+    # per-image draws
+    noises = torch.randn(4, 3, 4, 6, 5, generator=g)
+    ts = torch.randint(100, 700, (4, 3), generator=g)
+    g3 = sc.compute_losses_batch(lat, emb, noises=noises, timesteps=ts, to_host=False)
+    for j in range(4):
+        assert torch.equal(g3[j], sc.compute_losses(lat[j:j + 1], emb[j], noises=noises[j], timesteps=ts[j], to_host=False))
+    # the sharded step with per-image categories, one rank
+    sca = T.score_images_sharded(sc, lat, emb, 0, 1, mode="scalars", images_per_call=3)      # 3 + 1 images: two engine calls
+    want = torch.cat([sc.typicality_scalar(grids[j]).reshape(1) for j in range(4)])
+    assert torch.equal(sca, want)
+
+
+def test_identity_fast_paths_survive_inference_mode():
+    """tensors created under `torch.inference_mode()` have no version counter (`t._version` raises); the identity
+    fast paths of UNetCallable / SDFeaturizer must fall through to the value comparison instead of crashing."""
+    eng = _FakeEngine()
+    u = T.UNetCallable(eng)
+    with torch.inference_mode():
+        c = torch.randn(4, 77, 768).half()
+        s1 = u._slots_for(c)
+        s2 = u._slots_for(c)
+    assert s1.tolist() == s2.tolist() and eng.calls == 1 and u.stats["identity_hits"] == 0 and u.stats["key_hits"] == 1
+    import gc
+    c2 = torch.randn(2, 77, 768).half()
+    u._slots_for(c2)
+    ref = u._last[0]
+    del c2
+    gc.collect()
+    assert ref() is None, "the identity cache keeps the caller's tensor alive"
 
 
 def test_persistent_tile_refuses_tensors_beyond_32_bit_offsets():
