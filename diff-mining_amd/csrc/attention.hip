@@ -78,7 +78,7 @@ void attn_kernel(AttnParams p) {
     int kvb = p.kv_slot ? p.kv_slot[b] : (p.slot_div > 0 ? b / p.slot_div : b);
     if (p.n_slots > 0) kvb = kvb < 0 ? 0 : (kvb < p.n_slots ? kvb : p.n_slots - 1);      // memory safety: never beyond the registered prompts
 
-    const f16* Qb = p.Q + (size_t)b * p.bsq + h * D;
+    const f16* Qb = p.Q + (size_t)(p.q_mod > 0 ? b % p.q_mod : b) * p.bsq + h * D;
     const f16* Kb = p.K + (size_t)kvb * p.bsk + h * D;
     const f16* Vb = p.V + (size_t)kvb * p.bsv + h * D;
     f16* Ob = p.O + (size_t)b * p.bso + h * D;
@@ -363,6 +363,9 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     // long head_dim-40 / 80 self-attention: software-pipelined variants (DM_ATTN_PIPE=0 disables)
     if (option(OPT_ATTN_CROSS) && attention_cross_supports(p)) return launch_attention_cross(p, s);   // 77-key cross-attention
     const int pipe = option(OPT_ATTN_PIPE);
+    if (p.q_mod > 0) {                       // only the generic and the 77-key kernels index Q modulo (cross-attention; handled above / below)
+        switch (p.D) { case 40: return launch_t<40, 2>(p, s); case 80: return launch_t<80, 2>(p, s); case 160: return launch_t<160, 2>(p, s); default: return hipErrorInvalidValue; }
+    }
     if (pipe >= 4 && attention_pp_supports(p)) return launch_attention_pp(p, pipe, s);        // anti-phase wave sets (r05)
     // default: the three-set anti-phase kernel where it measured faster (>= 8192 keys: the 128x128 level of a 1024-pixel image, -4...6 %
     // per launch; bit-identical to attn_pipe_kernel) and its 384-query blocks waste < 2 % of their rows; attn_pipe = 2 / 3 keep the r04 kernels

@@ -93,7 +93,7 @@ void attn_cross_kernel(AttnParams p, int nsplit) {
     const int nqb = (p.Tq + 64 * QF - 1) / (64 * QF);
     const int qb0 = (int)((long long)part * nqb / nsplit), qb1 = (int)((long long)(part + 1) * nqb / nsplit);
 
-    const f16* Qb = p.Q + (size_t)b * p.bsq + h * D;
+    const f16* Qb = p.Q + (size_t)(p.q_mod > 0 ? b % p.q_mod : b) * p.bsq + h * D;
     const f16* Kb = p.K + (size_t)kvb * p.bsk + h * D;
     const f16* Vb = p.V + (size_t)kvb * p.bsv + h * D;
     f16* Ob = p.O + (size_t)b * p.bso + h * D;

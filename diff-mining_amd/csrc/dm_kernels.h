@@ -60,7 +60,7 @@ inline void launch_timed(F kernel, const dim3& grid, const dim3& block, size_t l
 
 // Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of
 // the same name in upper case with a DM_ prefix (DM_IGEMM_PERSIST=0 ...), changeable through dm_set_option().
-enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_TAP_REUSE, OPT_UP_FOLD, OPT_COUNT };
+enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_TAP_REUSE, OPT_UP_FOLD, OPT_Q_ONCE, OPT_COUNT };
 int option(Option o);                       // engine.hip
 int set_option(const char* name, int value);   // 0 on success
 int get_option(const char* name, int* value);  // 0 on success
@@ -184,6 +184,8 @@ struct AttnParams {
     const int32_t* kv_slot;          // optional: K/V batch index per sample (prompt slot)
     int slot_div;                    // if > 0 (and kv_slot == nullptr): K/V batch index = sample / slot_div
     int n_slots = 0;                 // > 0: K/V batch indices are clamped to [0, n_slots) on the device (prompt cache rows)
+    int q_mod = 0;                   // > 0: sample b reads the Q rows of sample b % q_mod (cross-attention of the shared-draw prefix: the
+                                     // queries of a draw are the same under every prompt, so they are projected once per draw)
     int B, heads, Tq, Tk, D;
     float scale;
 };

@@ -741,15 +741,21 @@ struct Fwd {
     }
     // second half: cross-attention against the per-prompt K/V cache, GEGLU feed-forward, proj_out + x.
     // Consumes (frees) t1.
-    int transformer_post(const TfmW& t, const Tensor& x, Tensor& t1, const int32_t* slots, Tensor* out) {
+    // LN2 -> attn2.to_q
+    int cross_q(const TfmW& t, const Tensor& t1, Tensor* q) {
+        Tensor ln;
+        if (ln_fold_enabled()) return ln_dense(t.q2_ln, t1, EPI_PLAIN, q);
+        DM_TRY(layernorm(t.ln2, t1, &ln));
+        DM_TRY(dense(t.q2, ln, nullptr, nullptr, EPI_PLAIN, q));
+        free(ln);
+        return 0;
+    }
+    // `qU` (optional, consumed): the queries of the first q_mod samples, shared by every block of q_mod samples (shared-draw prefix)
+    int transformer_post(const TfmW& t, const Tensor& x, Tensor& t1, const int32_t* slots, Tensor* out, Tensor* qU = nullptr, int q_mod = 0) {
         const int C = t.c, T = x.H * x.W, B = x.N;
         Tensor ln, a, q, t2, ff, t3;
-        if (ln_fold_enabled()) DM_TRY(ln_dense(t.q2_ln, t1, EPI_PLAIN, &q));
-        else {
-            DM_TRY(layernorm(t.ln2, t1, &ln));
-            DM_TRY(dense(t.q2, ln, nullptr, nullptr, EPI_PLAIN, &q));
-            free(ln);
-        }
+        if (qU) q = *qU;
+        else DM_TRY(cross_q(t, t1, &q));
         DM_TRY(alloc(&a, B, x.H, x.W, C));
         if (!dry) {
             const f16* kv = e->kv_cache[t.layer];
@@ -758,6 +764,7 @@ struct Fwd {
             ap.ldq = C; ap.ldk = 2 * C; ap.ldv = 2 * C; ap.ldo = C;
             ap.bsq = (long long)T * C; ap.bsk = (long long)CTX_LEN * 2 * C; ap.bsv = ap.bsk; ap.bso = (long long)T * C;
             ap.kv_slot = slot_div > 0 ? nullptr : slots; ap.slot_div = slot_div; ap.n_slots = e->n_prompts;
+            ap.q_mod = qU ? q_mod : 0;
             ap.B = B; ap.heads = HEADS; ap.Tq = T; ap.Tk = CTX_LEN; ap.D = C / HEADS;
             ap.scale = 1.0f / sqrtf((float)ap.D);
             DM_TRY(prof_begin(1, 4.0 * B * HEADS * (double)T * CTX_LEN * ap.D, B * T, CTX_LEN, ap.D, 101));
@@ -881,10 +888,14 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
         DM_TRY(F.alloc(&t1B, U * NC, A.H, A.W, d.tf[0].c));
         t1U = Fwd::first_slot(t1B, NC);
         DM_TRY(F.transformer_pre(d.tf[0], rU, &t1U));
+        // the cross-attention queries of the first transformer depend on the draw only: projected once per draw, read modulo U
+        Tensor qU;
+        const bool q_once = option(OPT_Q_ONCE) != 0;
+        if (q_once) DM_TRY(F.cross_q(d.tf[0], t1U, &qU));
         DM_TRY(F.fill_slots(hB, NC));
         DM_TRY(F.fill_slots(rB, NC));
         DM_TRY(F.fill_slots(t1B, NC));
-        DM_TRY(F.transformer_post(d.tf[0], rB, t1B, A.slots, &a));
+        DM_TRY(F.transformer_post(d.tf[0], rB, t1B, A.slots, &a, q_once ? &qU : nullptr, U));
         F.free(rB);
         skips.push_back(hB);
         skips.push_back(a);
@@ -1118,7 +1129,7 @@ int ensure_arena_for(dm_engine* e, hipStream_t s, const std::vector<long long>& 
 
 std::vector<long long> fwd_key(const FwdArgs& A) {
     return {0, A.B, A.H, A.W, A.n_cond, A.up_ft_index, A.add_noise ? 1 : 0, A.loss ? 1 : 0, A.pred ? 1 : 0, A.feat ? 1 : 0,
-            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD), option(OPT_FF_FOLD), option(OPT_UP_FOLD)};
+            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD), option(OPT_FF_FOLD), option(OPT_UP_FOLD), option(OPT_Q_ONCE)};
 }
 
 int ensure_arena(dm_engine* e, const FwdArgs& A, hipStream_t s) {
@@ -1204,7 +1215,7 @@ namespace {
 struct OptDef { const char* name; const char* env; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
-    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1}, {"tap_reuse", "DM_TAP_REUSE", 1}, {"up_fold", "DM_UP_FOLD", 1},
+    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1}, {"tap_reuse", "DM_TAP_REUSE", 1}, {"up_fold", "DM_UP_FOLD", 1}, {"q_once", "DM_Q_ONCE", 1},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<int> g_opt_init{0};

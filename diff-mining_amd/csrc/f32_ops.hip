@@ -11,20 +11,27 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 // ---- attention -----------------------------------------------------------------------------------------------------------------
 // One block = 64 QT queries of one (sample, head): 4 waves x QT 16-query MFMA tiles (QT = 2; 1 for the VAE's head_dim 512).  Key tiles of KT keys are staged
-// in LDS as [key][D + 4] fp32 rows (the + 4 makes every fragment read below bank-conflict-free for D = 40 / 80 / 160: 16 rows
-// x 4 column groups hit 64 distinct banks).
+// in LDS as fp32 rows: K rows of D + 2 floats, V rows of D + 4 (r05).  The fragment reads are 4-byte reads, which the LDS serves 32
+// lanes at a time over 32 banks: a K read of lanes (c, g in {0, 1}) hits banks c * LDK + g, distinct for the 16 keys c iff LDK / 2 is
+// odd (D + 2: 42 / 82 / 162 / 514); the r04 stride D + 4 put keys c and c + 8 on one bank — a two-way conflict on every K read, the
+// 30.7 % of profiles/r04_final_dift_f32_pmc.json.  A V read (rows 4 g + r, column c) wants the two rows 4 floats * odd * 4 apart:
+// D + 4 (rows r and r + 4 are 16 banks apart) is conflict-free and stays.
 //   S^T[key][query] = K Q^T   : A = K rows  (lane (c, g): key c, d = 4 s + g),  B = Q^T (query c, d = 4 s + g), D/4 k steps — head_dim
 //                                40 needs no padding on the k = 4 instruction
 //   softmax over keys          : a lane holds keys 4 g + r of query c; the row maximum crosses the four g lanes by two shuffles
 //   O^T[d][query] += V^T P^T   : B = P^T is the S^T accumulator AS IT LIES (register r <-> key 4 g + r, lane <-> query c) — P never
 //                                leaves its lane —, A = V^T (lane (c, g): d = 16 dt + c, key 4 g + r)
 // Online softmax (running maximum / sum, exp2 on pre-scaled scores), exact fp32 products and accumulation.
+// head_dim <= 80: two LDS stages; tile t + 1 is written (from the registers its loads landed in) while tile t is being read, the loads
+// of tile t + 2 fly under the MFMAs of tile t, ONE barrier per tile (r04: single stage, store + two barriers per tile).
 template <int D, int KT, int QT>
 __global__ __launch_bounds__(256) void attn32_kernel(AttnParams p) {
-    constexpr int LD = D + 4, DT = (D + 15) / 16, KS = D / 4, NKT = KT / 16;
+    constexpr int LDK = D + 2, LD = D + 4, DT = (D + 15) / 16, KS = D / 4, NKT = KT / 16;
+    constexpr bool PF = D <= 80;           // register prefetch + two LDS stages
+    constexpr int STG = KT * LDK + KT * LD + 16;      // floats per stage; + 16 of slack behind V: the last d tile of D = 40 reads columns 40..47
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
-    float* Vs = smem + KT * LD;            // + 16 floats of slack after it: the last d tile of D = 40 reads columns 40..47
+    float* Vs = smem + KT * LDK;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, c = lane & 15, g = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (64 * QT) + wid * (16 * QT);
     int kb = b;
@@ -53,7 +60,6 @@ __global__ __launch_bounds__(256) void attn32_kernel(AttnParams p) {
     // K / V tiles go global -> registers -> LDS; where the registers allow (head_dim <= 80) the loads of tile t+1 are issued before the
     // MFMAs of tile t, so their latency is covered by the block's own matrix work instead of by other blocks' (r04: 98.1 -> 99.4 TFLOP/s at 4096 keys: the tile fetch was not what the kernel waits for)
     constexpr int NLD = (KT * (D / 4) + 255) / 256;
-    constexpr bool PF = D <= 80;
     v4f kreg[PF ? NLD : 1], vreg[PF ? NLD : 1];
     auto gload = [&](int k0) {
 #pragma unroll
@@ -67,21 +73,25 @@ __global__ __launch_bounds__(256) void attn32_kernel(AttnParams p) {
             }
         }
     };
-    auto lstore = [&]() {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    auto lstore = [&](int stage) {
 #pragma unroll
         for (int j = 0; j < (PF ? NLD : 0); ++j) {
             const int i = tid + 256 * j;
             if (i < KT * (D / 4)) {
                 const int r = i / (D / 4), c4 = i - r * (D / 4);
-                *reinterpret_cast<v4f*>(Ks + r * LD + 4 * c4) = kreg[j];
-                *reinterpret_cast<v4f*>(Vs + r * LD + 4 * c4) = vreg[j];
+                float* kd = Ks + stage * STG + r * LDK + 4 * c4;           // K rows are 8-byte aligned only (LDK = D + 2)
+                *reinterpret_cast<v2f*>(kd) = v2f{kreg[j][0], kreg[j][1]};
+                *reinterpret_cast<v2f*>(kd + 2) = v2f{kreg[j][2], kreg[j][3]};
+                *reinterpret_cast<v4f*>(Vs + stage * STG + r * LD + 4 * c4) = vreg[j];
             }
         }
     };
-    if (PF) gload(0);
+    if (PF) { gload(0); lstore(0); if (KT < p.Tk) gload(KT); __syncthreads(); }
+    int stage = 0;
     for (int k0 = 0; k0 < p.Tk; k0 += KT) {
-        __syncthreads();
         if (!PF) {
+            __syncthreads();
             for (int i = tid; i < KT * (D / 4); i += 256) {
                 const int r = i / (D / 4), c4 = i - r * (D / 4), key = k0 + r;
                 v4f kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
@@ -89,13 +99,17 @@ __global__ __launch_bounds__(256) void attn32_kernel(AttnParams p) {
                     kv = *reinterpret_cast<const v4f*>(Kb + (long long)key * p.ldk + 4 * c4);
                     vv = *reinterpret_cast<const v4f*>(Vb + (long long)key * p.ldv + 4 * c4);
                 }
-                *reinterpret_cast<v4f*>(Ks + r * LD + 4 * c4) = kv;
+                *reinterpret_cast<v2f*>(Ks + r * LDK + 4 * c4) = v2f{kv[0], kv[1]};
+                *reinterpret_cast<v2f*>(Ks + r * LDK + 4 * c4 + 2) = v2f{kv[2], kv[3]};
                 *reinterpret_cast<v4f*>(Vs + r * LD + 4 * c4) = vv;
             }
+            __syncthreads();
+        } else if (k0 + KT < p.Tk) {
+            lstore(stage ^ 1);                                  // tile t + 1 (its loads were issued one tile ago) -> the other stage
+            if (k0 + 2 * KT < p.Tk) gload(k0 + 2 * KT);         // tile t + 2: in flight under this tile's MFMAs
         }
-        lstore();
-        __syncthreads();
-        if (PF && k0 + KT < p.Tk) gload(k0 + KT);
+        const float* Kc = Ks + (PF ? stage * STG : 0);
+        const float* Vc = Vs + (PF ? stage * STG : 0);
         v4f sacc[NKT][QT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
@@ -105,7 +119,7 @@ __global__ __launch_bounds__(256) void attn32_kernel(AttnParams p) {
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
-                const float a = Ks[(kt * 16 + c) * LD + 4 * s + g];
+                const float a = Kc[(kt * 16 + c) * LDK + 4 * s + g];
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) sacc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qf[qt][s], sacc[kt][qt], 0, 0, 0);
             }
@@ -145,10 +159,11 @@ __global__ __launch_bounds__(256) void attn32_kernel(AttnParams p) {
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const float a = Vs[(kt * 16 + 4 * g + r) * LD + dt * 16 + c];
+                    const float a = Vc[(kt * 16 + 4 * g + r) * LD + dt * 16 + c];
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sacc[kt][qt][r], o[dt][qt], 0, 0, 0);
                 }
+        if (PF) { __syncthreads(); stage ^= 1; }                // tile t + 1 is complete in the other stage; everybody has left this one
     }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -169,7 +184,7 @@ __global__ __launch_bounds__(256) void attn32_kernel(AttnParams p) {
 
 template <int D, int KT, int QT>
 hipError_t launch_attn_t(const AttnParams& p, hipStream_t s) {
-    const size_t lds = (size_t)(2 * KT * (D + 4) + 16) * sizeof(float);
+    const size_t lds = (size_t)(KT * (D + 2) + KT * (D + 4) + 16) * (D <= 80 ? 2 : 1) * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn32_kernel<D, KT, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((attn32_kernel<D, KT, QT>), dim3((p.Tq + 64 * QT - 1) / (64 * QT), p.heads, p.B), dim3(256), lds, s, p);

@@ -81,22 +81,31 @@ __device__ long long g_pers_dbg[8];
 #define PTICK(i) do {} while (0)
 #endif
 
-// IGemmParams::zero_page of this translation unit's zero page, per device
-static inline IGemmParams with_zero_page(const IGemmParams& p) {
+// device address of this translation unit's zero page (cached per device; a failed lookup is NOT cached and is reported by the
+// launchers as its hipError_t: with a null zero page the halo / out-of-range LDS-DMA lanes would read from address 0, a GPU fault
+// instead of an error return — ADVICE r04)
+static inline hipError_t zero_page_addr(const void** out) {
     static std::atomic<const void*> cache[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     const void* z = cache[dev & 63].load(std::memory_order_relaxed);
     if (!z) {
         void* a = nullptr;
-        (void)hipGetSymbolAddress(&a, HIP_SYMBOL(g_zero_page_pers));
+        const hipError_t r = hipGetSymbolAddress(&a, HIP_SYMBOL(g_zero_page_pers));
+        if (r != hipSuccess || !a) { *out = nullptr; return r != hipSuccess ? r : hipErrorInvalidSymbol; }
         z = a;
         cache[dev & 63].store(z, std::memory_order_relaxed);
     }
+    *out = z;
+    return hipSuccess;
+}
+// IGemmParams::zero_page of this translation unit's zero page; the launchers call zero_page_addr() first and fail with its error
+static inline IGemmParams with_zero_page(const IGemmParams& p) {
     IGemmParams q = p;
-    q.zero_page = z;
+    (void)zero_page_addr(&q.zero_page);
     return q;
 }
+#define DM_REQUIRE_ZERO_PAGE() do { const void* _z; const hipError_t _r = zero_page_addr(&_z); if (_r != hipSuccess) return _r; } while (0)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -671,6 +680,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
 
 template <bool LN>
 static hipError_t launch_igemm_pers_t(const IGemmParams& p, hipStream_t s) {
+    DM_REQUIRE_ZERO_PAGE();
     constexpr int TP = 256, TC = 320;
     constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 2 * AUX_BYTES;           // 160 KiB: two operand stages + two vector slots
     const int ntiles = ((p.M + TP - 1) / TP) * (p.Cout / TC);
@@ -700,6 +710,7 @@ static hipError_t launch_igemm_pers_t(const IGemmParams& p, hipStream_t s) {
 // the shortcut-in-conv2 variant; only igemm_pers_sc.hip defines DM_IGEMM_PERS_SC
 #ifdef DM_IGEMM_PERS_SC
 static hipError_t launch_igemm_pers_sc_t(const IGemmParams& p, hipStream_t s) {
+    DM_REQUIRE_ZERO_PAGE();
     constexpr int TP = 256, TC = 320;
     constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 2 * AUX_BYTES;
     if ((p.mode != IG_CONV3 && p.mode != IG_DENSE) || p.epi != EPI_PLAIN || p.ln_s || p.temb || p.X2 || !p.X3 || p.Csc <= 0 || p.Csc % BK ||
@@ -723,6 +734,7 @@ static hipError_t launch_igemm_pers_sc_t(const IGemmParams& p, hipStream_t s) {
 // the per-sample-weights variant (GroupNorm folded into proj_in); only igemm_pers_ws.hip defines DM_IGEMM_PERS_WS
 #ifdef DM_IGEMM_PERS_WS
 static hipError_t launch_igemm_pers_ws_t(const IGemmParams& p, hipStream_t s) {
+    DM_REQUIRE_ZERO_PAGE();
     constexpr int TP = 256, TC = 320;
     constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 2 * AUX_BYTES;
     if (p.mode != IG_DENSE || p.epi != EPI_PLAIN || !p.ln_t || p.w_sample_stride <= 0 || p.rows_per_sample <= 0 ||
@@ -744,6 +756,7 @@ static hipError_t launch_igemm_pers_ws_t(const IGemmParams& p, hipStream_t s) {
 // Always this kernel, for every batch size (no 128-row partner, no head / tail cut): a sample's bits cannot depend on its batch.
 #ifdef DM_IGEMM_PERS_UP
 static hipError_t launch_igemm_pers_up4_t(const IGemmParams& p, hipStream_t s) {
+    DM_REQUIRE_ZERO_PAGE();
     constexpr int TP = 256, TC = 320;
     constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 2 * AUX_BYTES;
     if (p.mode != IG_CONV2_UP4 || p.epi != EPI_PLAIN || p.ln_s || p.temb || p.res || p.X2 || p.X3 || p.ksplit > 1 || p.w_sample_stride ||
@@ -767,6 +780,7 @@ static hipError_t launch_igemm_pers_up4_t(const IGemmParams& p, hipStream_t s) {
 
 // split-K form: units = tiles * ksplit, fp32 partials (see EPI_PARTIAL); the caller runs the reduction afterwards
 static hipError_t launch_igemm_pers_partial_t(const IGemmParams& p, hipStream_t s) {
+    DM_REQUIRE_ZERO_PAGE();
     constexpr int TP = 256, TC = 320;
     constexpr size_t lds = 2 * (size_t)(TP + TC) * 128 + 2 * AUX_BYTES;
     const int units = ((p.M + TP - 1) / TP) * (p.Cout / TC) * p.ksplit;

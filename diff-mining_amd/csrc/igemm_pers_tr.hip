@@ -532,6 +532,7 @@ bool igemm_pers_tr_ok(const IGemmParams& p) {
 }
 
 hipError_t launch_igemm_pers_tr(const IGemmParams& p, hipStream_t s) {
+    DM_REQUIRE_ZERO_PAGE();
     if (!igemm_ko_layer(p) || !igemm_pers_tr_ok(p)) return hipErrorInvalidValue;
     if (p.mode == IG_CONV3_UP) return p.OW == 64 ? launch_tr_up64<DM_TR_UP_UNROLL>(p, s) : hipErrorInvalidValue;
     return p.OW == 128 ? launch_tr_w<128>(p, s) : p.OW == 64 ? launch_tr_w<64>(p, s) : p.OW == 32 ? launch_tr_w<32>(p, s) : launch_tr_w<16>(p, s);

@@ -35,7 +35,7 @@ SYMBOLS = [
 ]
 
 
-def get_options(names=("ln_fold", "gn_fold", "ff_fold", "sc_fold", "up_fold", "tap_reuse", "ln_inkernel", "igemm_splitk", "graph")) -> dict:
+def get_options(names=("ln_fold", "gn_fold", "ff_fold", "sc_fold", "up_fold", "tap_reuse", "ln_inkernel", "igemm_splitk", "q_once", "attn_pipe", "graph")) -> dict:
     """Current values of the library's runtime switches (dm_get_option); {} with a library that predates the getter."""
     lib = load_library()
     out = {}

@@ -8,7 +8,8 @@
     SD.compute_loss          compute.py:95-102        TypicalityScorer.compute_loss
     D.noising                compute.py:115-124       TypicalityScorer.noising / draw
     D.compute_losses         compute.py:134-160       TypicalityScorer.compute_losses
-    compute_submission loop  compute.py:284-290       TypicalityScorer.compute_losses_batch (n images, each under its own category, one engine call)
+    compute_submission loop  compute.py:284-290       TypicalityScorer.compute_submission -> compute_losses_batch (n images, each under
+                                                      its own category, one engine call)
     D.get_path / np.save     compute.py:162-163,192   TypicalityScorer.save_grid (same .npy layout)
     D.rescale                compute.py:165-180       TypicalityScorer.rescale
     D.compute / __call__ / exists  compute.py:182-202 TypicalityScorer.compute / __call__ / exists
@@ -363,6 +364,40 @@ class TypicalityScorer:
         with open(out, "wb") as f:
             np.save(f, losses.numpy())
         return out
+
+    @torch.no_grad()
+    def compute_submission(self, lines, images_per_call: int = 8, vae_noise=None):
+        """`compute_submission`'s loop (compute.py:284-290) over `path,country` work-list lines (strings, or (path, country)
+        pairs) — the reference calls `D.compute(country, path)` image by image; here runs of up to `images_per_call` consecutive
+        images of one latent size go through ONE `compute_losses_batch` call, each image under its own [country, ""] prompts.
+        Writes the same `<typicality_path>/<stem>.npy` files (bit-equal to `compute`'s: a sample's bits do not depend on the
+        batch it rides in); returns their paths.  `vae_noise`: {path: posterior draw [1,4,h,w]} (optional, as `compute`'s)."""
+        import PIL.Image
+        assert self.typicality_path is not None and self.country_embeds is not None, "scorer built without D's arguments"
+        items = [tuple(l.strip().split(",")) if isinstance(l, str) else tuple(l) for l in lines]
+        out_paths, run = [], []              # run: (path, country, latent x [1,4,h,w])
+
+        def flush():
+            if not run:
+                return
+            xs = torch.cat([r[2] for r in run])
+            emb = torch.stack([torch.stack([self.country_embeds[r[1]], self.country_embeds[""]]) for r in run])   # 0 = c, 1 = null
+            grids = self.compute_losses_batch(xs, emb)                                 # [n, N, 2, 4, h, w] fp16 on the host
+            for (path, _, _), g in zip(run, grids):
+                out = self.get_path(self.typicality_path, path)
+                os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+                with open(out, "wb") as f:
+                    np.save(f, g.numpy())
+                out_paths.append(out)
+            run.clear()
+        for path, country in items:
+            img = self.rescale(PIL.Image.open(path))
+            x = self.encode_vae(self.load_image(img), None if vae_noise is None else vae_noise.get(path))
+            if run and (tuple(run[0][2].shape) != tuple(x.shape) or len(run) >= images_per_call):
+                flush()
+            run.append((path, country, x))
+        flush()
+        return out_paths
 
     def __call__(self, path: str):
         """`D.__call__`: the stored grid of an image."""

@@ -79,7 +79,7 @@ class _SD:
         return name in self.sd
 
 
-# Rounding-point ablation (tests/test_oracle.py::test_rounding_point_ablation, tools/oracle_ablation.py): every fp16 rounding of
+# Rounding-point ablation (`python tools/oracle_noise.py ablation` -> profiles/r04_oracle_rounding_ablation.txt; no test covers the site tags): every fp16 rounding of
 # the autocast emulation carries a site tag; a tag in ROUND_OFF is skipped (that value stays fp32), so the contribution of one
 # class of roundings to the autocast-vs-fp32 distance can be named.  Empty by default = the emulation described above.
 #   "in"     operand of a conv / linear (what autocast casts to fp16 before the op)       "out"   result of a conv / linear

@@ -331,7 +331,11 @@ def test_fp16_engine_vs_fp32_ground_truth_at_the_baseline_configuration(net32, s
         print(f"[64x64 N=10 image {i}] fp16 grid vs fp32 truth rel-L2 {rl:.2e}; T engine {T:.6f} fp32 {T_ref:.6f} mean loss {ml:.4f}: "
               f"|dT|/|T| {d[1]:.2e}  |dT|/mean-loss {d[2]:.2e}")
     e16.close()
-    assert worst[0] < 1.5 * 1.23e-3                                   # TOL_LOSS of test_gpu_e2e.py
+    # north_star's own number, asserted: "outputs must match the reference ... to <= 1e-3 rel fp16", with exact fp32
+    # as the yardstick — the centre of the cloud every fp16 evaluation of this network (the reference's included) scatters around,
+    # DESIGN.md section 2.  Measured r04: 9.00-9.15e-4 for the fp16 grids of these four images; budget rule for new rewrites in
+    # DESIGN.md section 2a (a fold ships only if this stays <= 9.5e-4)
+    assert worst[0] <= 1.0e-3, f"fp16 loss grid vs exact fp32 at BASELINE configs[1]: {worst[0]:.3e} > 1e-3"
     assert worst[2] <= 1.5 * floor["max_dT_over_mean_loss"] * 1.5     # T10 bound of test_gpu_e2e.py; x 1.5: the grid is fp16-rounded, the truth is not
 
 

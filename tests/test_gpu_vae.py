@@ -322,3 +322,36 @@ def test_compute_writes_the_reference_npy(vae_engine, sd15_weights_f16, tmp_path
     ref = sc.compute_losses_from_image(sc.load_image(img), torch.stack([embeds["1970"], embeds[""]]), vae_noise=vnoise)
     assert np.array_equal(grid, ref.numpy())
     assert np.isfinite(grid.astype(np.float32)).all() and not np.array_equal(grid[:, 0], grid[:, 1])
+
+
+def test_compute_submission_writes_what_compute_writes(vae_engine, sd15_weights_f16, tmp_path):
+    """`compute_submission` (compute.py:284-290) over a work list of `path,country` lines with two categories and two image
+    sizes: runs of same-size images go through ONE `compute_losses_batch` call each, and every `.npy` is bit-equal to the file
+    `D.compute(country, path)` writes for that image alone."""
+    import PIL.Image
+    from diff_mining_amd import synth
+    from diff_mining_amd.typicality import TypicalityScorer
+    eng = vae_engine
+    if not eng._finalized:
+        eng.load_state_dict(sd15_weights_f16)
+    _, _, _, c = synth.synth_inputs(1, 1, 8, 8)
+    g = torch.Generator().manual_seed(3)
+    embeds = {"1970": torch.from_numpy(c[0]), "1985": torch.randn(77, 768, generator=g).half(), "": torch.from_numpy(c[1])}
+    imgs = synth.synth_image(4, 64, 64)
+    work, vnoise = [], {}
+    for i, (country, hw) in enumerate([("1970", (64, 64)), ("1985", (64, 64)), ("1970", (64, 64)), ("1985", (48, 64))]):
+        u8 = ((imgs[i][:, :hw[0], :hw[1]].transpose(1, 2, 0).astype(np.float32) + 1) * 127.5).round().clip(0, 255).astype(np.uint8)
+        path = str(tmp_path / f"{country}__img_{i:03d}.png")
+        PIL.Image.fromarray(u8).save(path)
+        work.append(f"{path},{country}")
+        vnoise[path] = U.f16_randn(1, 4, hw[0] // 8, hw[1] // 8, seed=90 + i)
+    a = TypicalityScorer(eng, seed=42, N=3, t_min=0.1, t_max=0.7, typicality_path=str(tmp_path / "batched"), which="geo", country_embeds=embeds)
+    b = TypicalityScorer(eng, seed=42, N=3, t_min=0.1, t_max=0.7, typicality_path=str(tmp_path / "single"), which="geo", country_embeds=embeds)
+    outs = a.compute_submission(work, images_per_call=8, vae_noise=vnoise)
+    assert len(outs) == 4
+    for line in work:
+        path, country = line.split(",")
+        b.compute(country, path, vae_noise=vnoise[path])
+        ga, gb = a(path), b(path)
+        assert ga.dtype == np.float16 and ga.shape == gb.shape and ga.shape[:3] == (3, 2, 4)
+        assert np.array_equal(ga, gb), f"{os.path.basename(path)}: the batched work list wrote a different grid"

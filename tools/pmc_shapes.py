@@ -33,13 +33,14 @@ SHAPES = [
     ("ff2 1280->320 @64 + res", 0, 64, 64, 1280, 0, 320, 0, "res"),
     ("qkv 320->960 @64 (ln)", 0, 64, 64, 320, 0, 960, 0, "ln"),
     ("conv 3x3 cat 640+320->320 @64 + temb", 1, 64, 64, 640, 320, 320, 0, "temb"),
-    ("up 3x3 640->640 @32->64", 3, 32, 32, 640, 0, 640, 0, ""),
+    ("up 3x3 640->640 @32->64 (up_fold 0)", 3, 32, 32, 640, 0, 640, 0, ""),
+    ("up folded 4 x 2x2 640->640 @32->64", 5, 32, 32, 640, 0, 640, 0, "up4"),       # what ships (option up_fold = 1, igemm_pers_up.hip)
 ]
 
 
 def algo_bytes(mode, H, W, C1, C2, Cout, epi, extra):
-    taps = 1 if mode == 0 else 9
-    OH, OW = (2 * H, 2 * W) if mode == 3 else (H, W)
+    taps = 1 if mode == 0 else (16 if mode == 5 else 9)            # folded up-sampler: four classes x four taps of pre-summed weights
+    OH, OW = (2 * H, 2 * W) if mode in (3, 5) else (H, W)
     M = B * OH * OW
     rd = B * H * W * (C1 + C2) * 2 + Cout * taps * (C1 + C2) * 2
     if extra == "res":
@@ -57,7 +58,7 @@ def run():
     for si, (name, mode, H, W, C1, C2, Cout, epi, extra) in enumerate(SHAPES):
         taps = 1 if mode == 0 else 9
         Cin = C1 + C2
-        OH, OW = (2 * H, 2 * W) if mode == 3 else (H, W)
+        OH, OW = (2 * H, 2 * W) if mode in (3, 5) else (H, W)
         M = B * OH * OW
         x = (torch.randn(B, H, W, C1, device=d, generator=g) * 0.5).half()
         x2 = (torch.randn(B, H, W, C2, device=d, generator=g) * 0.5).half() if C2 else None
@@ -71,9 +72,13 @@ def run():
         big = torch.empty(1 << 28, dtype=torch.float16, device=d)          # 512 MiB: evicts L2 + MALL between launches
         torch.cuda.synchronize()
         torch.zeros(4096 + si, device=d)                                   # marker: a fill kernel of a tagged size
+        w4 = (torch.randn(4, Cout, 4 * Cin, device=d, generator=g) * (4 * Cin) ** -0.5).half() if extra == "up4" else None
+        torch.cuda.synchronize()
         for _ in range(REPS):
             big.fill_(1.0)
-            if extra == "ln":
+            if extra == "up4":
+                assert lib.dm_op_upconv_folded(st, U.ptr(x), U.ptr(w4), U.ptr(bias), U.ptr(y), B, H, W, Cin, Cout) == 0
+            elif extra == "ln":
                 assert lib.dm_op_igemm_ln(st, U.ptr(x), U.ptr(w), U.ptr(ln_s), U.ptr(ln_t), None, U.ptr(y), M, Cin, Cout, epi) == 0
             else:
                 assert lib.dm_op_igemm(st, U.ptr(x), U.ptr(x2), U.ptr(w), U.ptr(bias), U.ptr(temb), U.ptr(res), U.ptr(y),
