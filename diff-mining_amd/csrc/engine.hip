@@ -754,24 +754,38 @@ struct Fwd {
     int transformer_post(const TfmW& t, const Tensor& x, Tensor& t1, const int32_t* slots, Tensor* out, Tensor* qU = nullptr, int q_mod = 0) {
         const int C = t.c, T = x.H * x.W, B = x.N;
         Tensor ln, a, q, t2, ff, t3;
-        if (qU) q = *qU;
-        else DM_TRY(cross_q(t, t1, &q));
+        // LN2 -> to_q inside the cross-attention kernel (attention_crossq.hip): the q tensor is never written or read.  A property of
+        // the layer (head_dim 40, >= 256 tokens per sample, folded LayerNorm), never of the batch
+        const bool fuse_q = option(OPT_ATTN2_FUSE) != 0 && ln_fold_enabled() && C == 320 && T >= 256 && option(OPT_ATTN_CROSS) != 0;
+        const Tensor* xq = &t1;             // the token rows the queries come from
+        if (qU && !fuse_q) q = *qU;
+        else if (!fuse_q) DM_TRY(cross_q(t, t1, &q));
         DM_TRY(alloc(&a, B, x.H, x.W, C));
         if (!dry) {
             const f16* kv = e->kv_cache[t.layer];
             AttnParams ap;
-            ap.Q = q.p; ap.K = kv; ap.V = kv + C; ap.O = a.p;
+            ap.Q = fuse_q ? nullptr : q.p; ap.K = kv; ap.V = kv + C; ap.O = a.p;
             ap.ldq = C; ap.ldk = 2 * C; ap.ldv = 2 * C; ap.ldo = C;
             ap.bsq = (long long)T * C; ap.bsk = (long long)CTX_LEN * 2 * C; ap.bsv = ap.bsk; ap.bso = (long long)T * C;
             ap.kv_slot = slot_div > 0 ? nullptr : slots; ap.slot_div = slot_div; ap.n_slots = e->n_prompts;
-            ap.q_mod = qU ? q_mod : 0;
+            ap.q_mod = (qU && !fuse_q) ? q_mod : 0;
             ap.B = B; ap.heads = HEADS; ap.Tq = T; ap.Tk = CTX_LEN; ap.D = C / HEADS;
             ap.scale = 1.0f / sqrtf((float)ap.D);
-            DM_TRY(prof_begin(1, 4.0 * B * HEADS * (double)T * CTX_LEN * ap.D, B * T, CTX_LEN, ap.D, 101));
-            DM_HIP(e, launch_attention(ap, s));
-            DM_TRY(prof_end());
+            if (fuse_q) {
+                CrossQParams fq;
+                fq.X = xq->p; fq.ldx = C; fq.bsx = (long long)T * C;
+                fq.Wq = t.q2_ln.w.w; fq.ln_s = t.q2_ln.s; fq.ln_t = t.q2_ln.t; fq.ln_eps = LN_EPS;
+                DM_TRY(prof_begin(1, 4.0 * B * HEADS * (double)T * CTX_LEN * ap.D + 2.0 * B * (double)T * C * C, B * T, CTX_LEN, ap.D, 102));
+                DM_HIP(e, launch_attention_crossq(ap, fq, s));
+                DM_TRY(prof_end());
+            } else {
+                DM_TRY(prof_begin(1, 4.0 * B * HEADS * (double)T * CTX_LEN * ap.D, B * T, CTX_LEN, ap.D, 101));
+                DM_HIP(e, launch_attention(ap, s));
+                DM_TRY(prof_end());
+            }
         }
-        free(q);
+        if (fuse_q) { if (qU) free(*qU); }
+        else free(q);
         DM_TRY(dense(t.o2, a, nullptr, &t1, EPI_PLAIN, &t2));
         free(a); free(t1);
         if (ln_fold_enabled()) DM_TRY(ln_dense(t.ff1_ln, t2, EPI_GEGLU, &ff));
@@ -890,7 +904,7 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
         DM_TRY(F.transformer_pre(d.tf[0], rU, &t1U));
         // the cross-attention queries of the first transformer depend on the draw only: projected once per draw, read modulo U
         Tensor qU;
-        const bool q_once = option(OPT_Q_ONCE) != 0;
+        const bool q_once = option(OPT_Q_ONCE) != 0 && !(option(OPT_ATTN2_FUSE) != 0 && Fwd::ln_fold_enabled() && d.tf[0].c == 320 && A.H * A.W >= 256 && option(OPT_ATTN_CROSS) != 0);
         if (q_once) DM_TRY(F.cross_q(d.tf[0], t1U, &qU));
         DM_TRY(F.fill_slots(hB, NC));
         DM_TRY(F.fill_slots(rB, NC));
@@ -1129,7 +1143,7 @@ int ensure_arena_for(dm_engine* e, hipStream_t s, const std::vector<long long>& 
 
 std::vector<long long> fwd_key(const FwdArgs& A) {
     return {0, A.B, A.H, A.W, A.n_cond, A.up_ft_index, A.add_noise ? 1 : 0, A.loss ? 1 : 0, A.pred ? 1 : 0, A.feat ? 1 : 0,
-            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD), option(OPT_FF_FOLD), option(OPT_UP_FOLD), option(OPT_Q_ONCE)};
+            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD), option(OPT_FF_FOLD), option(OPT_UP_FOLD), option(OPT_Q_ONCE), option(OPT_ATTN2_FUSE)};
 }
 
 int ensure_arena(dm_engine* e, const FwdArgs& A, hipStream_t s) {
@@ -1215,7 +1229,7 @@ namespace {
 struct OptDef { const char* name; const char* env; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
-    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1}, {"tap_reuse", "DM_TAP_REUSE", 1}, {"up_fold", "DM_UP_FOLD", 1}, {"q_once", "DM_Q_ONCE", 1},
+    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1}, {"tap_reuse", "DM_TAP_REUSE", 1}, {"up_fold", "DM_UP_FOLD", 1}, {"q_once", "DM_Q_ONCE", 1}, {"attn2_fuse", "DM_ATTN2_FUSE", 0},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<int> g_opt_init{0};
@@ -2095,6 +2109,19 @@ int dm_op_attention(void* stream, const void* Q, const void* K, const void* V, v
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.bsq = bsq; a.bsk = bsk; a.bsv = bsv; a.bso = bso;
     a.kv_slot = kv_slot; a.slot_div = 0; a.B = B; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.D = D; a.scale = scale;
     return launch_attention(a, (hipStream_t)stream) == hipSuccess ? 0 : 1;
+}
+
+int dm_op_cross_attention_q(void* stream, const void* X, const void* Wq_folded, const float* ln_s, const float* ln_t, float ln_eps,
+                            const void* K, const void* V, void* O, int ldk, int ldv, int64_t bsk, int64_t bsv, const int32_t* kv_slot,
+                            int B, int heads, int Tq, int Tk, int D, float scale) {
+    AttnParams a;
+    const int C = heads * D;
+    a.Q = nullptr; a.K = (const f16*)K; a.V = (const f16*)V; a.O = (f16*)O;
+    a.ldq = C; a.ldk = ldk; a.ldv = ldv; a.ldo = C; a.bsq = (long long)Tq * C; a.bsk = bsk; a.bsv = bsv; a.bso = (long long)Tq * C;
+    a.kv_slot = kv_slot; a.slot_div = 0; a.B = B; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.D = D; a.scale = scale;
+    CrossQParams f;
+    f.X = (const f16*)X; f.ldx = C; f.bsx = (long long)Tq * C; f.Wq = (const f16*)Wq_folded; f.ln_s = ln_s; f.ln_t = ln_t; f.ln_eps = ln_eps;
+    return launch_attention_crossq(a, f, (hipStream_t)stream) == hipSuccess ? 0 : 1;
 }
 
 int dm_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, int C, int C1, int G, float eps,

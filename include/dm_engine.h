@@ -284,8 +284,11 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
  *   "q_once" (1 / 0): dm_score_conds — attn2.to_q of the first transformer block runs once per draw (its input is the same under every
  *     prompt) and the cross-attention reads the queries modulo the draw count — bit-identical to 0;
  *   "attn_pipe" (1; 0 / 2 / 3 / 4 / 10 / 12): the head_dim-40 / 80 self-attention kernels: 1 = the software-pipelined kernels, and from
- *     8192 keys the three-wave-set anti-phase kernel (attention_pp.hip, r05); 0 = the generic kernel; 12 / 10 / 4 = the anti-phase kernel
+ *     8192 keys the three-wave-set anti-phase kernel (attention_pp.hip, r05); 9 = the pipelined kernels everywhere (the r04 dispatch); 0 = the generic kernel; 12 / 10 / 4 = the anti-phase kernel
  *     everywhere (three sets with / without static priorities, two sets) — all bit-identical for head_dim 40;
+ *   "attn2_fuse" (0 / 1): 1 = LayerNorm2 -> attn2.to_q computed inside the 77-key cross-attention kernel at the 320-channel level
+ *     (attention_crossq.hip: the q tensor is never written or read) — numerically equivalent, not bit-identical to 0; measured SLOWER than
+ *     the two launches (0.548 vs 0.491 ms per layer, +0.55 ms per step: DESIGN.md section 4g), hence off;
  *   "graph" (0 / 1): replay whole U-Net runs as captured hipGraphs (bit-identical: the same kernels with the same arguments);
  *   "igemm_exp": experimental kernel paths of the current round (0 = shipped). */
 int dm_set_option(const char* name, int value);
@@ -312,6 +315,13 @@ int dm_op_igemm_ln(void* stream, const void* X, const void* Wp_folded, const voi
 int dm_op_igemm_splitk(void* stream, const void* X, const void* X2, const void* Wp, const void* bias, const void* temb,
                        const void* res, void* Y, int N, int H, int W, int C1, int C2, int Cout, int OH, int OW,
                        int mode, int temb_ld, int ksplit, void* workspace_f32);
+/* LayerNorm -> Linear (no bias) -> 77-key cross-attention in one kernel (attention_crossq.hip; head_dim 40, 8 heads): X [B][Tq][C] fp16 token
+ * rows; Wq_folded [C][C] fp16 = W diag(gamma); ln_s[c] = sum_k Wq_folded[c][k], ln_t[c] = sum_k W[c][k] beta[k] (fp32); K / V [P][Tk][ld]
+ * with prompt slots as dm_op_attention; O [B][Tq][C] fp16.  Nonzero for shapes the kernel does not take. */
+int dm_op_cross_attention_q(void* stream, const void* X, const void* Wq_folded, const float* ln_s, const float* ln_t, float ln_eps,
+                            const void* K, const void* V, void* O, int ldk, int ldv, int64_t bsk, int64_t bsv, const int32_t* kv_slot,
+                            int B, int heads, int Tq, int Tk, int D, float scale);
+
 /* single-head attention with head_dim 512 (VAE mid block): Q/K/V [B][T][ld], O [B][T][ldo] */
 int dm_op_attention512(void* stream, const void* Q, const void* K, const void* V, void* O, int B, int T, int ld,
                        int ldo, float scale);
