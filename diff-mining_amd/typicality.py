@@ -117,6 +117,24 @@ class UNetCallable:
         except RuntimeError:
             return None
 
+    def _unique_rows(self, flat):
+        """Distinct rows of flat [n, L] and the row -> distinct-row map.  `torch.unique(dim=0)` sorts the rows lexicographically — 104 ms
+        on the GPU for 16 prompts of 77 x 768 (r05 profile: one rocprim block sort, the longest kernel of a bench run) — so the rows
+        are grouped by their 64-bit hash (a 1-D unique of n values) and the grouping is confirmed by ONE exact comparison; a hash
+        collision (never seen) falls back to the sort."""
+        n = flat.shape[0]
+        if flat.dtype == torch.float16 and flat.shape[1] % 2 == 0 and n > 0:
+            uh, inv = torch.unique(self._row_hash(flat), return_inverse=True)
+            first = torch.full((uh.numel(),), n, dtype=torch.long, device=flat.device).scatter_reduce_(
+                0, inv, torch.arange(n, device=flat.device), reduce="amin")
+            order = torch.argsort(first)                      # slots in order of first appearance
+            rank = torch.empty_like(order)
+            rank[order] = torch.arange(order.numel(), device=flat.device)
+            uniq, inv = flat[first[order]], rank[inv]
+            if bool((flat == uniq[inv]).all()):
+                return uniq, inv
+        return torch.unique(flat, dim=0, return_inverse=True)
+
     def _slots_for(self, c, ident=None):
         """Prompt slot of every row of c [n, 77, 768] (fp16, on the device; or a callable that builds it — only called when the
         identity path misses).  `ident`: the caller's own tensor object when `c` is a derived view / cast of it (default: c).
@@ -145,7 +163,7 @@ class UNetCallable:
                 self.stats["key_hits"] += 1
         if inv is None:
             self.stats["unique_calls"] += 1
-            uniq, inv = torch.unique(flat, dim=0, return_inverse=True)
+            uniq, inv = self._unique_rows(flat)
             eng.set_prompts(uniq.reshape(uniq.shape[0], c.shape[1], c.shape[2]))
             self._ctx_key = uniq
             self._key_hash = self._row_hash(uniq) if uniq.shape[1] % 2 == 0 and uniq.dtype == torch.float16 else None

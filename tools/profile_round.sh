@@ -2,19 +2,19 @@
 # Regenerate the judged artifacts of a round on the GPU box:  bash tools/profile_round.sh <tag>
 # (run through gpurun; outputs land in gpurun_out/<tag>/, copy the summaries into profiles/).
 set -u
-TAG=${1:-r04_final}
+TAG=${1:-r05_final}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 : > $OUT/bench.err
-DM_PROF_DUMP=$OUT/shapes_raw.txt python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+DM_PROF_DUMP=$OUT/shapes_raw.txt python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-side --no-parity > /dev/null 2>&1
 python tools/prof_shapes.py $OUT/shapes_raw.txt 3 > $OUT/shapes.txt; rm -f $OUT/shapes_raw.txt
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline \
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-side \
     > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
-    rocprofv3 --pmc $set --kernel-trace -f csv -d $OUT/pmc_$i -o pmc -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline \
+    rocprofv3 --pmc $set --kernel-trace -f csv -d $OUT/pmc_$i -o pmc -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-side \
         > $OUT/pmc_$i.json 2> $OUT/pmc_$i.err
     i=$((i+1))
 done
@@ -48,7 +48,9 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
 done
 python tools/pmc_to_json.py $OUT/d32 2 "bench.py --workload dift" > $OUT/dift_f32_pmc.json; rm -rf $OUT/d32
 for w in vae pixels; do python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline >> $OUT/side_workloads.jsonl 2>> $OUT/bench.err; done
-DM_BENCH_NOPROF=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_noprof.json 2>> $OUT/bench.err
+DM_BENCH_NOPROF=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-side > $OUT/bench_noprof.json 2>> $OUT/bench.err
+# the X-ray step with the r04 attention dispatch (attn_pipe = 9) and the r05 one (three anti-phase wave sets from 8192 keys), alternating
+for i in 1 2; do for a in 9 1; do echo -n "attn_pipe=$a " >> $OUT/ab_xray_attn.txt; DM_ATTN_PIPE=$a python bench.py --workload xray --steps 5 --warmup 2 --no-cpu-baseline 2>> $OUT/bench.err | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['roofline']['attention_tflops'])" >> $OUT/ab_xray_attn.txt; done; done
 find $OUT/stats -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
 # raw traces are large; keep only the summaries
 rm -rf $OUT/pmc_[0-9] $OUT/stats
