@@ -302,6 +302,24 @@ def test_gpu_fp32_ground_truth_agrees_with_the_cpu_oracle(net32, sd15_weights_to
     assert g.shape == ref.shape and r < TOL_E2E and dT < 1e-6
 
 
+def test_gpu_fp32_ground_truth_agrees_with_the_cpu_oracle_at_the_baseline_size(net32, sd15_weights_torch):
+    """`bench.py`'s `score_deviation` measures the fp16 engine against the fp32 net at 64 x 64; the fp32 net was
+    tied to the CPU oracle at 16 x 16 only.  Here one draw x 2 prompts at the BASELINE latent size itself (two 803-GFLOP forwards of
+    the CPU oracle, a few seconds): the GPU's exact-fp32 grid is the oracle's `autocast=False` grid at fp32 round-off."""
+    N, h, w = 1, 64, 64
+    x, _, _, c = synth.synth_inputs(1, 1, h, w, latent_dtype=np.float32)
+    x, c = torch.from_numpy(x), torch.from_numpy(c)
+    noises, ts = R.draw_noise_and_timesteps((1, 4, h, w), N, 0.1, 0.7, seed=42)
+    g = _grid32(net32, x, c, noises, ts).cpu()
+    cc = torch.cat([c[k:k + 1].float().expand(N, -1, -1) for k in range(2)])
+    ref = R.compute_loss(sd15_weights_torch, x, torch.cat([noises] * 2), torch.cat([ts] * 2), cc, autocast=False)
+    ref = ref.view(2, N, 4, h, w).transpose(0, 1)
+    r = U.rel_l2(g, ref)
+    dT = abs(R.typicality_scalar(g).item() - R.typicality_scalar(ref).item()) / ref.mean().item()
+    print(f"fp32 grid on the GPU vs the fp32 CPU oracle @64x64 N=1: rel-L2 {r:.2e}, |dT|/mean loss {dT:.2e}")
+    assert g.shape == ref.shape and r < TOL_E2E and dT < 1e-6
+
+
 def test_fp16_engine_vs_fp32_ground_truth_at_the_baseline_configuration(net32, sd15_weights_f16):
     """BASELINE configs[1] itself — 512 px (64 x 64 latent), N = 10 draws x 2 prompts per image — for four images: the fp16 engine's
     grid and T(x|c) against the exact-fp32 evaluation of the same U-Net on the same inputs (the CPU oracle reaches this size only
