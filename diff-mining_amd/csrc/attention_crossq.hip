@@ -1,6 +1,6 @@
 // attention_crossq.hip — LayerNorm2 -> attn2.to_q -> the 77-key cross-attention of a transformer block in ONE kernel (r05,
 // head_dim 40 = the 320-channel level), reached from `unet(...)`, diffmining/typicality/compute.py:100
-// (BasicTransformerBlock: norm2, attn2 — restated at oracle/unet_ref.py: basic_transformer_block).
+// (diffusers BasicTransformerBlock: norm2 -> attn2).
 //
 // The chain ran as two launches that are both bound by moving the token matrix: the LayerNorm-folded GEMM writes q [tokens x C]
 // (419 MB at the 64x64 level of the bench batch), attention_cross.hip reads it back.  Here a block owns a (sample, head) pair (or a
