@@ -750,13 +750,19 @@ struct Fwd {
         free(ln);
         return 0;
     }
-    // `qU` (optional, consumed): the queries of the first q_mod samples, shared by every block of q_mod samples (shared-draw prefix)
-    int transformer_post(const TfmW& t, const Tensor& x, Tensor& t1, const int32_t* slots, Tensor* out, Tensor* qU = nullptr, int q_mod = 0) {
-        const int C = t.c, T = x.H * x.W, B = x.N;
+    // `qU` (optional, consumed): the queries of the first q_mod samples, shared by every block of q_mod samples (shared-draw prefix).
+    // `rep` > 1 (shared-draw prefix, with qU): x and t1 hold ONE block of x.N samples that every one of the `rep` prompt blocks shares —
+    // the batch is rep * x.N samples, and the two GEMMs that read x / t1 as their residual run once per prompt block against the
+    // shared rows instead of reading stacked copies (r05: the copies were 3 x 210 MB per step; bit-identical: a sample's bits do not
+    // depend on its position in a launch)
+    int transformer_post(const TfmW& t, const Tensor& x, Tensor& t1, const int32_t* slots, Tensor* out, Tensor* qU = nullptr, int q_mod = 0,
+                         int rep = 1) {
+        const int C = t.c, T = x.H * x.W, B = x.N * rep;
+        if (rep > 1 && !qU) DM_FAIL(e, "transformer_post: shared residual rows need the shared queries");
         Tensor ln, a, q, t2, ff, t3;
         // LN2 -> to_q inside the cross-attention kernel (attention_crossq.hip): the q tensor is never written or read.  A property of
         // the layer (head_dim 40, >= 256 tokens per sample, folded LayerNorm), never of the batch
-        const bool fuse_q = option(OPT_ATTN2_FUSE) != 0 && ln_fold_enabled() && C == 320 && T >= 256 && option(OPT_ATTN_CROSS) != 0;
+        const bool fuse_q = rep == 1 && option(OPT_ATTN2_FUSE) != 0 && ln_fold_enabled() && C == 320 && T >= 256 && option(OPT_ATTN_CROSS) != 0;
         const Tensor* xq = &t1;             // the token rows the queries come from
         if (qU && !fuse_q) q = *qU;
         else if (!fuse_q) DM_TRY(cross_q(t, t1, &q));
@@ -786,7 +792,14 @@ struct Fwd {
         }
         if (fuse_q) { if (qU) free(*qU); }
         else free(q);
-        DM_TRY(dense(t.o2, a, nullptr, &t1, EPI_PLAIN, &t2));
+        if (rep > 1) {
+            DM_TRY(alloc(&t2, B, x.H, x.W, C));
+            for (int k = 0; k < rep; ++k) {
+                const Tensor ak = slot_view(a, k, rep);
+                Tensor t2k = slot_view(t2, k, rep);
+                DM_TRY(dense(t.o2, ak, nullptr, &t1, EPI_PLAIN, &t2k));
+            }
+        } else DM_TRY(dense(t.o2, a, nullptr, &t1, EPI_PLAIN, &t2));
         free(a); free(t1);
         if (ln_fold_enabled()) DM_TRY(ln_dense(t.ff1_ln, t2, EPI_GEGLU, &ff));
         else {
@@ -796,13 +809,27 @@ struct Fwd {
         }
         if (option(OPT_FF_FOLD) && t.ffp.w) {
             // ff.net.2 + residual + proj_out as one GEMM over [ff | t2] (+ x): the [tokens x C] intermediate is never written or read
-            DM_TRY(igemm(t.ffp, IG_DENSE, ff, nullptr, x.H, x.W, nullptr, 0, &x, EPI_PLAIN, out, nullptr, nullptr, &t2, nullptr));
+            if (rep > 1) {
+                DM_TRY(alloc(out, B, x.H, x.W, t.ffp.cout));
+                for (int k = 0; k < rep; ++k) {
+                    const Tensor ffk = slot_view(ff, k, rep), t2k = slot_view(t2, k, rep);
+                    Tensor ok = slot_view(*out, k, rep);
+                    DM_TRY(igemm(t.ffp, IG_DENSE, ffk, nullptr, x.H, x.W, nullptr, 0, &x, EPI_PLAIN, &ok, nullptr, nullptr, &t2k, nullptr));
+                }
+            } else DM_TRY(igemm(t.ffp, IG_DENSE, ff, nullptr, x.H, x.W, nullptr, 0, &x, EPI_PLAIN, out, nullptr, nullptr, &t2, nullptr));
             free(ff); free(t2);
             return 0;
         }
         DM_TRY(dense(t.ff2, ff, nullptr, &t2, EPI_PLAIN, &t3));
         free(ff); free(t2);
-        DM_TRY(dense(t.proj_out, t3, nullptr, &x, EPI_PLAIN, out));
+        if (rep > 1) {
+            DM_TRY(alloc(out, B, x.H, x.W, t.proj_out.cout));
+            for (int k = 0; k < rep; ++k) {
+                const Tensor t3k = slot_view(t3, k, rep);
+                Tensor ok = slot_view(*out, k, rep);
+                DM_TRY(dense(t.proj_out, t3k, nullptr, &x, EPI_PLAIN, &ok));
+            }
+        } else DM_TRY(dense(t.proj_out, t3, nullptr, &x, EPI_PLAIN, out));
         free(t3);
         return 0;
     }
@@ -815,6 +842,12 @@ struct Fwd {
     // first slot of the stacked tensor in place (first_slot() as its output), fill_slots() copies it to the others
     static Tensor first_slot(const Tensor& stacked, int n_cond) {
         Tensor v; v.p = stacked.p; v.off = (size_t)-1; v.view = true; v.N = stacked.N / n_cond; v.H = stacked.H; v.W = stacked.W; v.C = stacked.C;
+        return v;
+    }
+    // block k of n_cond equal sample blocks of a stacked tensor, as a pre-placed window (null in the dry run, like every pointer there)
+    static Tensor slot_view(const Tensor& stacked, int k, int n_cond) {
+        Tensor v = first_slot(stacked, n_cond);
+        if (stacked.p) v.p = stacked.p + (size_t)k * (size_t)(stacked.rows() / n_cond) * stacked.C;
         return v;
     }
     int fill_slots(const Tensor& stacked, int n_cond) {
@@ -896,21 +929,35 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
         // running every (draw, prompt) pair separately (the kernels are batch-position invariant).
         const DownBlockW& d = e->down[0];
         Tensor rU, t1U, rB, t1B, a;
-        DM_TRY(F.alloc(&rB, U * NC, A.H, A.W, d.res[0].cout));
-        rU = Fwd::first_slot(rB, NC);
-        DM_TRY(F.resnet(d.res[0], h, nullptr, tprojU.p, &rU));
-        DM_TRY(F.alloc(&t1B, U * NC, A.H, A.W, d.tf[0].c));
-        t1U = Fwd::first_slot(t1B, NC);
-        DM_TRY(F.transformer_pre(d.tf[0], rU, &t1U));
         // the cross-attention queries of the first transformer depend on the draw only: projected once per draw, read modulo U
-        Tensor qU;
         const bool q_once = option(OPT_Q_ONCE) != 0 && !(option(OPT_ATTN2_FUSE) != 0 && Fwd::ln_fold_enabled() && d.tf[0].c == 320 && A.H * A.W >= 256 && option(OPT_ATTN_CROSS) != 0);
-        if (q_once) DM_TRY(F.cross_q(d.tf[0], t1U, &qU));
-        DM_TRY(F.fill_slots(hB, NC));
-        DM_TRY(F.fill_slots(rB, NC));
-        DM_TRY(F.fill_slots(t1B, NC));
-        DM_TRY(F.transformer_post(d.tf[0], rB, t1B, A.slots, &a, q_once ? &qU : nullptr, U));
-        F.free(rB);
+        // ... and with the queries shared, the only other readers of the stacked ResNet output and of t1 are two residual reads:
+        // those GEMMs can run once per prompt block against the per-draw rows, and two stacking copies disappear (q_once = 2; measured +-0:
+        // 139.00 vs 139.05 ms/step over three alternating pairs, profiles/r05_ab_q_once.txt — the copies cost what the extra launches do)
+        const bool share = q_once && option(OPT_Q_ONCE) == 2;
+        if (share) {
+            DM_TRY(F.resnet(d.res[0], h, nullptr, tprojU.p, &rU));
+            DM_TRY(F.transformer_pre(d.tf[0], rU, &t1U));
+            Tensor qU;
+            DM_TRY(F.cross_q(d.tf[0], t1U, &qU));
+            DM_TRY(F.fill_slots(hB, NC));
+            DM_TRY(F.transformer_post(d.tf[0], rU, t1U, A.slots, &a, &qU, U, NC));
+            F.free(rU);
+        } else {
+            DM_TRY(F.alloc(&rB, U * NC, A.H, A.W, d.res[0].cout));
+            rU = Fwd::first_slot(rB, NC);
+            DM_TRY(F.resnet(d.res[0], h, nullptr, tprojU.p, &rU));
+            DM_TRY(F.alloc(&t1B, U * NC, A.H, A.W, d.tf[0].c));
+            t1U = Fwd::first_slot(t1B, NC);
+            DM_TRY(F.transformer_pre(d.tf[0], rU, &t1U));
+            Tensor qU;
+            if (q_once) DM_TRY(F.cross_q(d.tf[0], t1U, &qU));
+            DM_TRY(F.fill_slots(hB, NC));
+            DM_TRY(F.fill_slots(rB, NC));
+            DM_TRY(F.fill_slots(t1B, NC));
+            DM_TRY(F.transformer_post(d.tf[0], rB, t1B, A.slots, &a, q_once ? &qU : nullptr, U));
+            F.free(rB);
+        }
         skips.push_back(hB);
         skips.push_back(a);
         cur = a;

@@ -281,8 +281,10 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
  *     output parity class, with the 3x3 taps that read the same source pixel pre-summed in fp32 and rounded to fp16 once (4 / 9 of the
  *     layer's MACs; the up-sampled tensor is never formed) — numerically equivalent, not bit-identical to 0; other sizes
  *     (F.interpolate(size=...) of odd latents) always run the unfolded layer;
- *   "q_once" (1 / 0): dm_score_conds — attn2.to_q of the first transformer block runs once per draw (its input is the same under every
- *     prompt) and the cross-attention reads the queries modulo the draw count — bit-identical to 0;
+ *   "q_once" (1 / 0 / 2): dm_score_conds — attn2.to_q of the first transformer block runs once per draw (its input is the same under every
+ *     prompt) and the cross-attention reads the queries modulo the draw count; 2 also runs the two GEMMs that read the prefix's
+ *     outputs as a residual once per prompt block against the per-draw rows, so two of the three stacking copies of the shared
+ *     prefix disappear (measured +-0, hence not the default) — all bit-identical to 0;
  *   "attn_pipe" (1; 0 / 2 / 3 / 4 / 10 / 12): the head_dim-40 / 80 self-attention kernels: 1 = the software-pipelined kernels, and from
  *     8192 keys the three-wave-set anti-phase kernel (attention_pp.hip, r05); 9 = the pipelined kernels everywhere (the r04 dispatch); 0 = the generic kernel; 12 / 10 / 4 = the anti-phase kernel
  *     everywhere (three sets with / without static priorities, two sets) — all bit-identical for head_dim 40;
