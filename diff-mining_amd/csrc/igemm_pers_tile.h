@@ -40,6 +40,10 @@ typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int BK = 64;
+#ifndef DM_TILE_SWZ
+#define DM_TILE_SWZ 8
+#endif
+constexpr int TILE_SWZ_G = DM_TILE_SWZ;       // pixel tiles per group of the wide layers' tile order (0 = channel-minor everywhere)
 
 // erf-GELU  x * Phi(x) = max(x, 0) - |x| * T(|x|),  T(a) = 0.5 * (1 - erf(a / sqrt 2)) by Abramowitz-Stegun 7.1.26
 // (|erf error| < 1.5e-7; measured over all 63 488 finite fp16 inputs: max |error| 3.3e-7, i.e. far below the fp16
@@ -236,6 +240,29 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
     int ld_tap = 0, ld_cc = 0;
     int ld_ph = 0;                    // UP4: output parity class (py << 1 | px) of the tile being fetched
 
+    // tile index -> (pixel tile, channel tile).  Channel-minor order makes the 32 CUs of an XCD, which work on consecutive tiles, share
+    // ONE pixel tile and pull min(32, tiles_c) weight tiles between them — for the wide layers (GEGLU projections: tiles_c = 8 / 16 / 32,
+    // q/k/v: 3 / 6 / 12) that re-streams the weight matrix once per round through a 4 MB L2 (profiles/r05_final_pmc_shapes.txt: 3.5 / 10.8 /
+    // 33 x the algorithmic bytes).  r05: the LayerNorm-folded instantiations (GEGLU, q/k/v, to_q) walk groups of TILE_SWZ_G = 8 pixel
+    // tiles x tiles_c channel tiles, pixel-minor inside a group: 32 consecutive tiles share 8 pixel tiles and 4 weight tiles (8.5 instead of
+    // 26.9 MB per round at N = 10 240).  Same-box round-robin of G = 4 / 8 / 16 / 32 (profiles/r05_ab_tile_swz.txt): 8 is best, 640 -> 5120
+    // -3.5 %, 1280 -> 10240 -1 %, a step -0.6 ms.  For tiles_c <= 4 the 32 tiles of a round are the same set as before.  The order of the
+    // tiles never changes a tile's arithmetic (same checksum).
+    auto decode_tile = [&](int tl, int& pt, int& ct) __attribute__((always_inline)) {
+        if constexpr ((EPI == EPI_GEGLU || LN) && !WS && !PART && !UP4 && TILE_SWZ_G > 0) {
+            constexpr int G = TILE_SWZ_G;
+            const int gsz = G * tiles_c;
+            const int grp = tl / gsz, r = tl - grp * gsz;
+            const int tiles_p = (p.M + TP - 1) / TP;
+            const int left = tiles_p - grp * G;
+            const int gp = left < G ? left : G;          // ragged last group
+            ct = r / gp;
+            pt = grp * G + (r - ct * gp);
+            return;
+        }
+        pt = tl / tiles_c;
+        ct = tl - pt * tiles_c;
+    };
     auto pack_row = [&](int m) __attribute__((always_inline)) -> int {
         if (m >= p.M) return -1;
         if (p.mode == IG_DENSE) return m;
@@ -248,9 +275,10 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
         int tl = PART ? unit / KSP : unit;
         const int tap0 = PART ? (unit - tl * KSP) * (ntaps / KSP) : 0;
         if constexpr (UP4) { ld_ph = tl / tpp; tl -= ld_ph * tpp; }
-        const int pt = tl / tiles_c;
+        int pt, ct;
+        decode_tile(tl, pt, ct);
         lp0 = pt * TP;
-        lc0 = (tl - pt * tiles_c) * TC;
+        lc0 = ct * TC;
         const int ln = hw_lane();
         const int lrow = ln >> 3, lchunk = ((ln & 7) ^ lrow) * 8;
         woff = (unsigned)((size_t)(lc0 + wid * 8 + lrow) * Ktot + lchunk) + (unsigned)(tap0 * p.Cin);
@@ -591,8 +619,9 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
         int rtile = PART ? tile / KSP : tile;
         int cur_ph = 0;
         if constexpr (UP4) { cur_ph = rtile / tpp; rtile -= cur_ph * tpp; }
-        const int pt = rtile / tiles_c;
-        const int p0 = pt * TP, c0out = (rtile - pt * tiles_c) * TC;
+        int pt, ct_;
+        decode_tile(rtile, pt, ct_);
+        const int p0 = pt * TP, c0out = ct_ * TC;
 #pragma unroll
         for (int h = 0; h < CH; ++h)
 #pragma unroll
