@@ -553,6 +553,19 @@ def test_compute_losses_batch_is_bit_equal_to_the_per_image_calls(engine, h, w, 
     _, sc_b = engine.reduce_typicality_batched(grids, n, N, 2)
     for j in range(n):
         assert abs(sc_b[j].item() - sc.typicality_scalar(grids[j]).item()) <= 1e-6 * max(1.0, abs(sc_b[j].item()))
+    if h <= 16:
+        # a single condition per image (n_cond = 1: dm_score with the slot of each image's prompt) and per-image draws
+        g_one = sc.compute_losses_batch(x.to(d), emb[:, :1].to(d), to_host=False)
+        assert g_one.shape == (n, N, 1, 4, h, w)
+        for j in (0, 3, n - 1):
+            assert torch.equal(g_one[j], sc.compute_losses(x[j:j + 1].to(d), emb[j, :1].to(d), to_host=False))
+            assert torch.equal(g_one[j, :, 0], grids[j, :, 0])          # = the category column of the two-condition grid
+        gen = torch.Generator().manual_seed(5)
+        noises = torch.randn(n, 2, 4, h, w, generator=gen)
+        ts = torch.randint(100, 700, (n, 2), generator=gen)
+        g_pd = sc.compute_losses_batch(x.to(d), emb.to(d), noises=noises, timesteps=ts, to_host=False)
+        for j in (1, n - 1):
+            assert torch.equal(g_pd[j], sc.compute_losses(x[j:j + 1].to(d), emb[j].to(d), noises=noises[j], timesteps=ts[j], to_host=False))
 
 
 def test_full_size_properties(engine):
