@@ -247,7 +247,9 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
     // tiles x tiles_c channel tiles, pixel-minor inside a group: 32 consecutive tiles share 8 pixel tiles and 4 weight tiles (8.5 instead of
     // 26.9 MB per round at N = 10 240).  Same-box round-robin of G = 4 / 8 / 16 / 32 (profiles/r05_ab_tile_swz.txt): 8 is best, 640 -> 5120
     // -3.5 %, 1280 -> 10240 -1 %, a step -0.6 ms.  For tiles_c <= 4 the 32 tiles of a round are the same set as before.  The order of the
-    // tiles never changes a tile's arithmetic (same checksum).
+    // tiles never changes a tile's arithmetic (same checksum).  A channel-group-major order (4 weight tiles x ALL pixel tiles, hoping the weights
+    // stay in the L2) fetched exactly the same bytes — the activations and outputs streaming through a 4 MB L2 evict 1.6 - 3.3 MB of weights
+    // every round anyway — and measured -0.1 ms: not kept (profiles/r05_ab_tile_swz.txt).
     auto decode_tile = [&](int tl, int& pt, int& ct) __attribute__((always_inline)) {
         if constexpr ((EPI == EPI_GEGLU || LN) && !WS && !PART && !UP4 && TILE_SWZ_G > 0) {
             constexpr int G = TILE_SWZ_G;
