@@ -9,6 +9,10 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// 2^x for x <= 0 as ONE v_exp_f32 (r05): libm's exp2f wraps the instruction in a denormal rescue (compare, select, add, ldexp: six more
+// VALU per call) for results below 2^-126 — far below the fp32 resolution of a softmax sum that is >= 1; -inf -> 0, NaN-free for finite input
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // ---- attention -----------------------------------------------------------------------------------------------------------------
 // One block = 64 QT queries of one (sample, head): 4 waves x QT 16-query MFMA tiles (QT = 2; 1 for the VAE's head_dim 512).  Key tiles of KT keys are staged
 // in LDS as fp32 rows: K rows of D + 2 floats, V rows of D + 4 (r05).  The fragment reads are 4-byte reads, which the LDS serves 32
@@ -138,13 +142,13 @@ __global__ __launch_bounds__(256) void attn32_kernel(AttnParams p) {
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mnew = fmaxf(mrun[qt], mx);          // finite: every key tile holds at least one real key
-            const float alpha = exp2f(mrun[qt] - mnew);
+            const float alpha = fast_exp2(mrun[qt] - mnew);
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = exp2f(sacc[kt][qt][r] - mnew);
+                    const float pv = fast_exp2(sacc[kt][qt][r] - mnew);
                     sacc[kt][qt][r] = pv;
                     sum += pv;
                 }
