@@ -60,7 +60,7 @@ inline void launch_timed(F kernel, const dim3& grid, const dim3& block, size_t l
 
 // Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of
 // the same name in upper case with a DM_ prefix (DM_IGEMM_PERSIST=0 ...), changeable through dm_set_option().
-enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_TAP_REUSE, OPT_UP_FOLD, OPT_Q_ONCE, OPT_ATTN2_FUSE, OPT_COUNT };
+enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_TAP_REUSE, OPT_UP_FOLD, OPT_Q_ONCE, OPT_ATTN2_FUSE, OPT_GN_EPI, OPT_COUNT };
 int option(Option o);                       // engine.hip
 int set_option(const char* name, int value);   // 0 on success
 int get_option(const char* name, int* value);  // 0 on success
@@ -116,6 +116,10 @@ struct IGemmParams {
     // re-materialises inside the k loop of the register-tight variants (r04: once per k step in the tap-reuse and folded-LayerNorm
     // kernels).
     const void* zero_page = nullptr;
+    // GroupNorm block sums out of the epilogue (r05; the time-embedding launches = ResnetBlock2D.conv1, whose output is norm2's
+    // input): [M / 64][Cout] fp32, entry (b, 2 k + {0, 1}) = (sum, sum of squares) of output channels 2 k, 2 k + 1 over rows
+    // 64 b .. 64 b + 63, in the arithmetic gn_blocks_kernel (norm.hip) defines.  Needs M % 64 == 0; nullptr = not wanted.
+    float* gn_blocks = nullptr;
 };
 constexpr int IGEMM_TILE_CTR_INTS = 8 * 32 + 32;
 // LayerNorm statistics taken inside the folded GEMM are one-pass fp32 sums (var = E[x^2] - mean^2): with |mean| >> std the
@@ -208,7 +212,37 @@ hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, in
                            double* partial /* [N][chunks][G][2] */, hipStream_t s);
 int gn_stats_chunks(int HW);
 hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, float eps, const float* gamma,
-                           const float* beta, const double* partial, int silu, f16* Y, hipStream_t s);
+                           const float* beta, const double* partial, int silu, f16* Y, hipStream_t s, int chunks = 0 /* 0: gn_stats_chunks(HW) */);
+// The same statistics as per-(64-row block, channel pair) fp32 sums that a producing GEMM's epilogue can emit (r05):
+//   blocks [N * HW / 64][C] fp32, entry (b, 2 k + {0, 1}) = (sum, sum of squares) of channels 2 k, 2 k + 1 over rows 64 b .. 64 b + 63:
+//   rows 16 j + e of the block: acc = v_dot2_f32_f16(x_pair, (1, 1) | x_pair, acc) for j = 0..3 from 0, then the fixed tree
+//   e ^ 1, e ^ 2, 7 - e, 15 - e over the 16 lanes e.  launch_gn_blocks computes rows [row0, N * HW) from the tensor in memory;
+//   igemm_gn_rows(p) says how many leading rows a launch_igemm(p) with p.gn_blocks set has already written — bit-identical, so
+//   which of the two produced a block never shows.  launch_gn_blocks_final: fp64 sums in a fixed order -> partial [N][1][G][2]
+//   (launch_gn_apply / launch_gn_fold with chunks = 1).  HW % 64 == 0, C / G even.
+template <int CTRL>
+__device__ __forceinline__ float gn_dpp(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+// the fixed tree over the 16 lanes of a DPP row (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror): every lane
+// ends with the same bits (fp32 addition commutes)
+__device__ __forceinline__ float gn_row16_sum(float x) {
+    x += gn_dpp<0xB1>(x);
+    x += gn_dpp<0x4E>(x);
+    x += gn_dpp<0x141>(x);
+    x += gn_dpp<0x140>(x);
+    return x;
+}
+typedef _Float16 gn_half2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gn_pair_acc(float& s, float& q, unsigned w) {
+    const gn_half2 v = __builtin_bit_cast(gn_half2, w);
+    s = __builtin_amdgcn_fdot2(v, gn_half2{(_Float16)1.0f, (_Float16)1.0f}, s, false);
+    q = __builtin_amdgcn_fdot2(v, v, q, false);
+}
+hipError_t launch_gn_blocks(const f16* X, int rows, int C, int row0, float* blocks, hipStream_t s);
+hipError_t launch_gn_blocks_final(const float* blocks, int N, int HW, int C, int G, double* partial, hipStream_t s);
+int igemm_gn_rows(const IGemmParams& p);
+bool igemm_gn_layer(const IGemmParams& p);      // false: no batch size ever gets block sums for this layer from an epilogue
 // GroupNorm (no activation) folded into the following 1x1 convolution W [Cout][C], bias [Cout]: from the same partial sums,
 // Wn [N][Cout][C] = fp16(W[o][c] * a[n][c]) and tn [N][Cout] = bias[o] + sum_c W[o][c] * b[n][c]  (fp32), y = x * a + b being the
 // normalisation's per-(sample, channel) affine.  The convolution then runs on the RAW x with per-sample weights: the

@@ -538,7 +538,8 @@ struct Fwd {
     // Y = igemm(X [, X2]) with fused epilogue.  Output spatial dims given by (OH, OW).
     int igemm(const ConvW& cv, int mode, const Tensor& x, const Tensor* x2, int OH, int OW,
               const f16* temb, int temb_ld, const Tensor* res, int epi, Tensor* y, const LnFold* ln = nullptr,
-              const float* ln_stats = nullptr, const Tensor* x3 = nullptr, const Tensor* x4 = nullptr) {
+              const float* ln_stats = nullptr, const Tensor* x3 = nullptr, const Tensor* x4 = nullptr, float* gn_blocks = nullptr,
+              int* gn_rows = nullptr) {
         const int cin = x.C + (x2 ? x2->C : 0);
         if (cin != cv.cin) DM_FAIL(e, "igemm: channel mismatch %d vs %d", cin, cv.cin);
         const int cout_y = (epi == EPI_GEGLU) ? cv.cout / 2 : cv.cout;
@@ -566,6 +567,9 @@ struct Fwd {
             DM_TRY(alloc_raw((size_t)parts * p.M * cv.cout * sizeof(float), &poff, &pp));
             p.ksplit = parts; p.partial = (float*)pp;
         }
+        // GroupNorm block sums of the output from the epilogue: *gn_rows = the leading rows that get them (the rest is the caller's)
+        p.gn_blocks = gn_blocks;
+        if (gn_rows) *gn_rows = igemm_gn_layer(p) ? igemm_gn_rows(p) : -1;      // -1: a layer that never gets them (the caller's r04 pass)
         if (!dry) {
             const double flops = 2.0 * (double)p.M * cv.cout * (double)((mode == IG_DENSE ? 1 : 9) * cin + p.Csc);
             DM_TRY(prof_begin(0, flops, p.M, cv.cout, (mode == IG_DENSE ? 1 : 9) * cin + p.Csc, mode + 10 * epi));
@@ -609,6 +613,23 @@ struct Fwd {
             DM_HIP(e, launch_gn_stats(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, GROUPS, (double*)pp, s));
             DM_HIP(e, launch_gn_apply(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, GROUPS, eps, nw.g, nw.b, (const double*)pp,
                                       silu ? 1 : 0, y->p, s));
+        }
+        free_raw(poff);
+        return 0;
+    }
+    // GroupNorm whose statistics arrive as per-(64-row block, channel pair) sums (r05): the producing GEMM's epilogue wrote the
+    // blocks of the first `rows_done` rows; the rest comes from the tensor (same arithmetic, same bits), then the fixed-order fp64 combine.
+    static bool gn_blocks_ok(int HW, int C) { return option(OPT_GN_EPI) != 0 && HW % 64 == 0 && C % 16 == 0 && (C / GROUPS) % 2 == 0 && 256 % GROUPS == 0; }
+    int groupnorm_blocks(const NormW& nw, const Tensor& x, float* blocks, int rows_done, float eps, bool silu, Tensor* y) {
+        const int C = x.C, HW = x.H * x.W;
+        if (C != nw.c) DM_FAIL(e, "groupnorm: channel mismatch %d vs %d", C, nw.c);
+        size_t poff; void* pp;
+        DM_TRY(alloc_raw((size_t)x.N * GROUPS * 2 * sizeof(double), &poff, &pp));
+        DM_TRY(alloc(y, x.N, x.H, x.W, C));
+        if (!dry) {
+            DM_HIP(e, launch_gn_blocks(x.p, (int)x.rows(), C, rows_done, blocks, s));
+            DM_HIP(e, launch_gn_blocks_final(blocks, x.N, HW, C, GROUPS, (double*)pp, s));
+            DM_HIP(e, launch_gn_apply(x.p, nullptr, x.N, HW, C, C, GROUPS, eps, nw.g, nw.b, (const double*)pp, silu ? 1 : 0, y->p, s, 1));
         }
         free_raw(poff);
         return 0;
@@ -678,9 +699,20 @@ struct Fwd {
     int resnet(const ResW& r, const Tensor& x, const Tensor* x2, const f16* tproj, Tensor* out) {
         Tensor n1, h1, n2, sc;
         DM_TRY(groupnorm(r.n1, x, x2, res_eps, true, &n1));
-        DM_TRY(igemm(r.c1, IG_CONV3, n1, nullptr, x.H, x.W, tproj ? tproj + r.temb_off : nullptr, e->tproj_total, nullptr, EPI_PLAIN, &h1));
-        free(n1);
-        DM_TRY(groupnorm(r.n2, h1, nullptr, res_eps, true, &n2));
+        // norm2's statistics: block sums out of conv1's epilogue where the persistent kernels run it, from h1 where they do not
+        if (gn_blocks_ok(x.H * x.W, r.c1.cout)) {
+            size_t boff; void* bp; int rows_done = 0;
+            DM_TRY(alloc_raw((size_t)x.N * (x.H * x.W / 64) * r.c1.cout * sizeof(float), &boff, &bp));
+            DM_TRY(igemm(r.c1, IG_CONV3, n1, nullptr, x.H, x.W, tproj ? tproj + r.temb_off : nullptr, e->tproj_total, nullptr, EPI_PLAIN, &h1,
+                         nullptr, nullptr, nullptr, nullptr, (float*)bp, &rows_done));
+            free(n1);
+            if (rows_done < 0) { free_raw(boff); DM_TRY(groupnorm(r.n2, h1, nullptr, res_eps, true, &n2)); }
+            else { DM_TRY(groupnorm_blocks(r.n2, h1, (float*)bp, rows_done, res_eps, true, &n2)); free_raw(boff); }
+        } else {
+            DM_TRY(igemm(r.c1, IG_CONV3, n1, nullptr, x.H, x.W, tproj ? tproj + r.temb_off : nullptr, e->tproj_total, nullptr, EPI_PLAIN, &h1));
+            free(n1);
+            DM_TRY(groupnorm(r.n2, h1, nullptr, res_eps, true, &n2));
+        }
         free(h1);
         // conv_shortcut folded into conv2 (extra k steps on the block's input instead of a GEMM whose output conv2 reads back as its
         // residual) wherever conv2 runs unsplit (more than 64 positions per sample: the split-K layers keep the pair)
@@ -1190,7 +1222,7 @@ int ensure_arena_for(dm_engine* e, hipStream_t s, const std::vector<long long>& 
 
 std::vector<long long> fwd_key(const FwdArgs& A) {
     return {0, A.B, A.H, A.W, A.n_cond, A.up_ft_index, A.add_noise ? 1 : 0, A.loss ? 1 : 0, A.pred ? 1 : 0, A.feat ? 1 : 0,
-            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD), option(OPT_FF_FOLD), option(OPT_UP_FOLD), option(OPT_Q_ONCE), option(OPT_ATTN2_FUSE)};
+            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD), option(OPT_FF_FOLD), option(OPT_UP_FOLD), option(OPT_Q_ONCE), option(OPT_ATTN2_FUSE), option(OPT_GN_EPI)};
 }
 
 int ensure_arena(dm_engine* e, const FwdArgs& A, hipStream_t s) {
@@ -1276,7 +1308,7 @@ namespace {
 struct OptDef { const char* name; const char* env; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
-    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1}, {"tap_reuse", "DM_TAP_REUSE", 1}, {"up_fold", "DM_UP_FOLD", 1}, {"q_once", "DM_Q_ONCE", 1}, {"attn2_fuse", "DM_ATTN2_FUSE", 0},
+    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1}, {"tap_reuse", "DM_TAP_REUSE", 1}, {"up_fold", "DM_UP_FOLD", 1}, {"q_once", "DM_Q_ONCE", 1}, {"attn2_fuse", "DM_ATTN2_FUSE", 0}, {"gn_epi", "DM_GN_EPI", 0},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<int> g_opt_init{0};
@@ -2179,6 +2211,33 @@ int dm_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, 
     if (hipMalloc((void**)&partial, (size_t)N * chunks * G * 2 * sizeof(double)) != hipSuccess) return 1;
     hipError_t r = launch_gn_stats((const f16*)X, (const f16*)X2, N, HW, C, C1, G, partial, s);
     if (r == hipSuccess) r = launch_gn_apply((const f16*)X, (const f16*)X2, N, HW, C, C1, G, eps, gamma, beta, partial, silu, (f16*)Y, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(partial);
+    return r == hipSuccess ? 0 : 1;
+}
+
+int dm_op_conv_temb_gn_blocks(void* stream, const void* X, const void* Wp, const void* bias, const void* temb, void* Y, int N, int H, int W,
+                              int Cin, int Cout, int temb_ld, float* blocks, int* rows_done) {
+    IGemmParams p;
+    p.X = (const f16*)X; p.X2 = nullptr; p.Wp = (const f16*)Wp; p.bias = (const f16*)bias; p.temb = (const f16*)temb; p.res = nullptr;
+    p.Y = (f16*)Y; p.Cout = Cout; p.Cin = Cin; p.C1 = Cin; p.mode = IG_CONV3; p.epi = EPI_PLAIN; p.ldy = Cout; p.ldres = 0; p.temb_ld = temb_ld;
+    p.M = N * H * W; p.H = H; p.W = W; p.OH = H; p.OW = W;
+    p.gn_blocks = blocks;
+    if (rows_done) *rows_done = igemm_gn_rows(p);
+    return launch_igemm(p, (hipStream_t)stream) == hipSuccess ? 0 : 1;
+}
+
+int dm_op_gn_blocks(void* stream, const void* X, int rows, int C, int row0, float* blocks) {
+    return launch_gn_blocks((const f16*)X, rows, C, row0, blocks, (hipStream_t)stream) == hipSuccess ? 0 : 1;
+}
+
+int dm_op_groupnorm_blocks(void* stream, const void* X, const float* blocks, int N, int HW, int C, int G, float eps, const float* gamma,
+                           const float* beta, int silu, void* Y) {
+    hipStream_t s = (hipStream_t)stream;
+    double* partial = nullptr;
+    if (hipMalloc((void**)&partial, (size_t)N * G * 2 * sizeof(double)) != hipSuccess) return 1;
+    hipError_t r = launch_gn_blocks_final(blocks, N, HW, C, G, partial, s);
+    if (r == hipSuccess) r = launch_gn_apply((const f16*)X, nullptr, N, HW, C, C, G, eps, gamma, beta, partial, silu, (f16*)Y, s, 1);
     (void)hipStreamSynchronize(s);
     (void)hipFree(partial);
     return r == hipSuccess ? 0 : 1;

@@ -197,7 +197,35 @@ static hipError_t launch_small(const IGemmParams& p, hipStream_t s) {
     return (p.Cout % 320 == 0) ? launch_t<4, 5>(p, s) : launch_t<2, 5>(p, s);
 }
 
-hipError_t launch_igemm(const IGemmParams& p, hipStream_t s) {
+// Leading rows of launch_igemm(p) whose GroupNorm block sums (p.gn_blocks) the producing kernel's epilogue writes: the rows the
+// persistent kernels take of a time-embedding launch (ResnetBlock2D.conv1).  The caller computes the remaining blocks from the
+// output (launch_gn_blocks) — the same bits either way, so the cut (a function of the batch size) never shows in a result.
+// Can ANY batch size get block sums for this layer from an epilogue?  A property of the layer (geometry, epilogue, options), never of
+// M: the caller keeps the r04 statistics pass for the layers that never can (the 128- / 32- / 16-pixel tap-reuse kernels, split-K
+// layers, channel counts the persistent tile does not take) — one launch instead of two there.
+bool igemm_gn_layer(const IGemmParams& p) {
+    if (!p.temb || p.epi != EPI_PLAIN || p.w_sample_stride || p.ln_s || p.X3 || (p.OH * p.OW) % 64 != 0) return false;
+    if (p.Cout % 320 != 0 || p.mode == IG_CONV3_S2P0 || p.Cin % BK != 0 || p.C1 % BK != 0) return false;
+    if (igemm_splitk_parts(p, p.OH * p.OW) > 1) return false;
+    if (tap_reuse_layer(p) && p.OW != 64) return false;
+    return true;
+}
+
+int igemm_gn_rows(const IGemmParams& p) {
+    if (!igemm_gn_layer(p)) return 0;
+    if (!p.gn_blocks || !p.temb || p.epi != EPI_PLAIN || p.M % 64 != 0 || (p.ksplit > 1 && p.partial) || p.w_sample_stride || p.ln_s || p.X3) return 0;
+    if (p.Cout % 160 != 0 || p.mode == IG_CONV3_S2P0 || p.Cin % BK != 0 || p.C1 % BK != 0 || p.M <= 0) return 0;
+    if (option(OPT_IGEMM_EXP) == 1 && p.epi == EPI_GEGLU) return 0;
+    const int head = head_rows(p);
+    if (head <= 0) return 0;
+    const IGemmParams h = head < p.M ? row_range(p, 0, head) : p;
+    if (tap_reuse_layer(p) && (!igemm_pers_tr_ok(h) || p.OW != 64)) return 0;      // the tap-reuse kernel emits them for 64-pixel-wide images only (igemm_pers_tr.hip)
+    return head < p.M ? head : p.M;
+}
+
+hipError_t launch_igemm(const IGemmParams& p_in, hipStream_t s) {
+    IGemmParams p = p_in;
+    if (p.gn_blocks && igemm_gn_rows(p) == 0) p.gn_blocks = nullptr;
     if (p.ksplit > 1 && p.partial) {
         if (!splitk_on_pers(p)) return launch_igemm_splitk(p, s);
         const hipError_t rc = launch_igemm_pers_partial(p, s);

@@ -181,7 +181,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
     constexpr int NL = WI + XI;
     // stores per wave per tile (every wave issues all of them: rows beyond M go to the sink page)
     constexpr bool PART = (EPI == EPI_PARTIAL);
-    constexpr int NSTORE = PART ? 40 : (EPI == EPI_GEGLU) ? 16 : 24;
+    constexpr int NSTORE = PART ? 40 : (EPI == EPI_GEGLU) ? 16 : (EXTRA == PX_TEMB) ? 34 : 24;      // time-embedding launches: + 10 GroupNorm block-sum stores
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const aux0 = smem + 2 * STAGE;
 
@@ -474,6 +474,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
         const char* ax = aux0 + slot * AUX_BYTES;
         constexpr int OCH = (EPI == EPI_GEGLU) ? 40 : 80;          // output channels of one (wave, h) sub-tile
         constexpr bool RES = (EXTRA == PX_RES);
+        constexpr bool GNB = (EXTRA == PX_TEMB) && EPI == EPI_PLAIN;          // GroupNorm block sums (IGemmParams::gn_blocks)
         const int c0o = (EPI == EPI_GEGLU) ? c0out / 2 : c0out;
         // the lane id is re-read from the hardware inside every epilogue: anything derived from the kernel-wide `lane`
         // is hoisted out of the tile loop by the compiler and then lives (or spills) across the k loop, which runs
@@ -503,6 +504,13 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
         if (RES) load_res(0);
 #pragma unroll
         for (int h = 0; h < CH; ++h) {
+            // GroupNorm block sums of the (wave, h) sub-tile's 64 rows x 80 channels (time-embedding launches = conv1, norm2's input):
+            // ten channel pairs per lane, accumulated over the four row blocks j, then the fixed 16-lane tree (dm_kernels.h)
+            float gs[GNB ? 10 : 1], gq[GNB ? 10 : 1];
+            if constexpr (GNB) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) { gs[k] = 0.f; gq[k] = 0.f; }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int u = h * 4 + j;
@@ -574,8 +582,30 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
                         *reinterpret_cast<half8*>(yp ? yp + 16 * eg : sink) = lo;
                         *reinterpret_cast<half8*>(yp ? yp + 16 * eg + 8 : sink) = hi;
                         *reinterpret_cast<half4*>(yp ? yp + 64 + 4 * eg : sink) = o4;
+                        if constexpr (GNB) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                gn_pair_acc(gs[GNB ? 2 * i : 0], gq[GNB ? 2 * i : 0], R[i][0]);
+                                gn_pair_acc(gs[GNB ? 2 * i + 1 : 0], gq[GNB ? 2 * i + 1 : 0], R[i][NWD - 1]);
+                            }
+                            gn_pair_acc(gs[GNB ? 8 : 0], gq[GNB ? 8 : 0], R4[0]);
+                            gn_pair_acc(gs[GNB ? 9 : 0], gq[GNB ? 9 : 0], R4[NWD - 1]);
+                        }
                     }
                 }
+            }
+            if constexpr (GNB) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) { gs[k] = gn_row16_sum(gs[k]); gq[k] = gn_row16_sum(gq[k]); }
+                const int r0 = p0 + wp * 64;
+                // every lane issues the five stores (the vmcnt count at the next tile's top is per instruction): lanes other than e15 = 0,
+                // blocks beyond M and launches without a block buffer write their slot of the sink page
+                float* const fsink = reinterpret_cast<float*>(sink);
+                float* const gb = (p.gn_blocks && e15 == 0 && r0 < p.M) ? p.gn_blocks + (size_t)(r0 >> 6) * p.Cout + c0o + wc * (OCH * CH) + h * OCH : nullptr;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<floatx4*>(gb ? gb + 16 * eg + 4 * i : fsink) = floatx4{gs[GNB ? 2 * i : 0], gq[GNB ? 2 * i : 0], gs[GNB ? 2 * i + 1 : 0], gq[GNB ? 2 * i + 1 : 0]};
+                *reinterpret_cast<floatx4*>(gb ? gb + 64 + 4 * eg : fsink) = floatx4{gs[GNB ? 8 : 0], gq[GNB ? 8 : 0], gs[GNB ? 9 : 0], gq[GNB ? 9 : 0]};
             }
         }
         if (RES) {
@@ -636,6 +666,7 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
         // previous tile's stores must have drained (they had the epilogue's own run time plus one k step).
         if (first) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         else if (NSTORE == 40) asm volatile("s_waitcnt vmcnt(40)\n\ts_barrier" ::: "memory");
+        else if (NSTORE == 34) asm volatile("s_waitcnt vmcnt(34)\n\ts_barrier" ::: "memory");
         else if (NSTORE == 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
         first = false;

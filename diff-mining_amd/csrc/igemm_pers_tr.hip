@@ -40,7 +40,10 @@ void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
     constexpr int XI = (XP + NW - 1) / NW;                // pieces per wave (the last one only in the first XP - 8 (XI - 1) waves): 5
     constexpr int WI = TC / 8 / NW;                       // 5 weight pieces per wave and k step
     constexpr int AUX_BYTES = 2048;                       // bias + time-embedding row (shadows the 8 KiB slot of igemm_pers_tile.h)
-    constexpr int NSTORE = 24;
+    // GroupNorm block sums of the output from the epilogue (IGemmParams::gn_blocks): the time-embedding launches (ResnetBlock2D.conv1)
+    // of 64-pixel-wide images — the 128-, 32- and 16-pixel instantiations spill with the 20 extra accumulators (tools/kernel_spills.py)
+    constexpr bool GNBK = (EXTRA == PX_TEMB) && WIMG == 64;
+    constexpr int NSTORE = GNBK ? 34 : 24;      // + 10 block-sum stores
     static_assert(XI == 5 && 2 * WBYTES + 2 * XBYTES + 2 * AUX_BYTES <= 160 * 1024, "LDS budget");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xs0 = smem + 2 * WBYTES;
@@ -228,6 +231,7 @@ void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
         const char* ax = aux0 + slot * AUX_BYTES;
         constexpr int OCH = (EPI == EPI_GEGLU) ? 40 : 80;          // output channels of one (wave, h) sub-tile
         constexpr bool RES = (EXTRA == PX_RES);
+        constexpr bool GNB = GNBK;
         const int c0o = (EPI == EPI_GEGLU) ? c0out / 2 : c0out;
         // the lane id is re-read from the hardware inside every epilogue: anything derived from the kernel-wide `lane`
         // is hoisted out of the tile loop by the compiler and then lives (or spills) across the k loop, which runs
@@ -257,6 +261,13 @@ void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
         if (RES) load_res(0);
 #pragma unroll
         for (int h = 0; h < CH; ++h) {
+            // GroupNorm block sums of the (wave, h) sub-tile's 64 rows x 80 channels (time-embedding launches = conv1, norm2's input):
+            // ten channel pairs per lane, accumulated over the four row blocks j, then the fixed 16-lane tree (dm_kernels.h)
+            float gs[GNB ? 10 : 1], gq[GNB ? 10 : 1];
+            if constexpr (GNB) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) { gs[k] = 0.f; gq[k] = 0.f; }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int u = h * 4 + j;
@@ -322,8 +333,30 @@ void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
                         *reinterpret_cast<half8*>(yp ? yp + 16 * eg : sink) = lo;
                         *reinterpret_cast<half8*>(yp ? yp + 16 * eg + 8 : sink) = hi;
                         *reinterpret_cast<half4*>(yp ? yp + 64 + 4 * eg : sink) = o4;
+                        if constexpr (GNB) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                gn_pair_acc(gs[GNB ? 2 * i : 0], gq[GNB ? 2 * i : 0], R[i][0]);
+                                gn_pair_acc(gs[GNB ? 2 * i + 1 : 0], gq[GNB ? 2 * i + 1 : 0], R[i][NWD - 1]);
+                            }
+                            gn_pair_acc(gs[GNB ? 8 : 0], gq[GNB ? 8 : 0], R4[0]);
+                            gn_pair_acc(gs[GNB ? 9 : 0], gq[GNB ? 9 : 0], R4[NWD - 1]);
+                        }
                     }
                 }
+            }
+            if constexpr (GNB) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) { gs[k] = gn_row16_sum(gs[k]); gq[k] = gn_row16_sum(gq[k]); }
+                const int r0 = p0 + wp * 64;
+                // every lane issues the five stores (the vmcnt count at the next tile's top is per instruction): lanes other than e15 = 0,
+                // blocks beyond M and launches without a block buffer write their slot of the sink page
+                float* const fsink = reinterpret_cast<float*>(sink);
+                float* const gb = (p.gn_blocks && e15 == 0 && r0 < p.M) ? p.gn_blocks + (size_t)(r0 >> 6) * p.Cout + c0o + wc * (OCH * CH) + h * OCH : nullptr;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<floatx4*>(gb ? gb + 16 * eg + 4 * i : fsink) = floatx4{gs[GNB ? 2 * i : 0], gq[GNB ? 2 * i : 0], gs[GNB ? 2 * i + 1 : 0], gq[GNB ? 2 * i + 1 : 0]};
+                *reinterpret_cast<floatx4*>(gb ? gb + 64 + 4 * eg : fsink) = floatx4{gs[GNB ? 8 : 0], gq[GNB ? 8 : 0], gs[GNB ? 9 : 0], gq[GNB ? 9 : 0]};
             }
         }
         if (RES) {
@@ -377,10 +410,16 @@ void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
         // the tile's k step 0 weights, its first activation stage and its vectors were requested BEFORE the previous epilogue's
         // stores, so "at most NSTORE outstanding" proves they have landed (igemm_pers_tile.h)
         if (first) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (NSTORE == 34) asm volatile("s_waitcnt vmcnt(34)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
         first = false;
         int ticket = 0;
-        if (threadIdx.x == 0) ticket = atomicAdd(&ctr[xcd * 32], 1);
+        // thread 0; the block-sum instantiations re-derive it (threadIdx.x kept alive across their k loop is the register that spills)
+        auto thread0 = [&]() __attribute__((always_inline)) -> bool {
+            if constexpr (GNBK) return wid == 0 && hw_lane() == 0;
+            else return threadIdx.x == 0;
+        };
+        if (thread0()) ticket = atomicAdd(&ctr[xcd * 32], 1);
         int next = 0;
         bool has_next = false;
         if constexpr (UNROLL) {
@@ -392,7 +431,7 @@ void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
                 step(g & 1, tg & 1, std::integral_constant<int, 0>{}, p.Cin);
                 ++g;
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                if (tr == 0 && threadIdx.x == 0) *(lds_word_t)(aux0 + slot * AUX_BYTES + 1020) = ticket;
+                if (tr == 0 && thread0()) *(lds_word_t)(aux0 + slot * AUX_BYTES + 1020) = ticket;
                 step(g & 1, tg & 1, std::integral_constant<int, 1>{}, (cc == cpt - 1) ? BK : BK - 2 * p.Cin);
                 ++g;
                 if (last) {        // the weights of the NEXT tile's first k step are requested by this tile's last step
@@ -447,7 +486,7 @@ void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
                     if (++cc == cpt) cc = 0;
                 } else ++dx;
                 if (kt < nk - 1) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                if (kt == 0 && threadIdx.x == 0) *(lds_word_t)(aux0 + slot * AUX_BYTES + 1020) = ticket;
+                if (kt == 0 && thread0()) *(lds_word_t)(aux0 + slot * AUX_BYTES + 1020) = ticket;
             }
         }
         epilogue(p0, c0out, slot);

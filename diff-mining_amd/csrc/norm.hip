@@ -75,6 +75,71 @@ __global__ void gn_stats_partial(const f16* __restrict__ X, const f16* __restric
     }
 }
 
+// ---- GroupNorm statistics as per-(64-row block, channel pair) sums (r05; arithmetic: dm_kernels.h, launch_gn_blocks) ----------
+// One wave = one 64-row block; a pass covers 64 channels: lane (e, lg) reads the 16 channels 64 pass + 16 lg of rows 16 j + e (two
+// 16-byte loads, four lanes = one 128-byte line of the row).  The persistent GEMM epilogues compute the same sums from their
+// packed output registers; this kernel serves the producers that do not (128-row tile, split-K, tails of a head / tail cut).
+__global__ __launch_bounds__(256) void gn_blocks_kernel(const f16* __restrict__ X, int nblk, int C, int blk0, float* __restrict__ blocks) {
+    const int lane = threadIdx.x & 63, e = lane & 15, lg = lane >> 4;
+    const int b = blk0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= nblk) return;
+    const f16* xb = X + (size_t)b * 64 * C;
+    float* ob = blocks + (size_t)b * C;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + 16 * lg;
+        const bool ok = c < C;                       // C % 16 == 0
+        float sa[8], qa[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sa[k] = 0.f; qa[k] = 0.f; }
+        uint4 v[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint4* src = reinterpret_cast<const uint4*>(xb + (size_t)(16 * j + e) * C + (ok ? c : 0));
+            v[j][0] = src[0]; v[j][1] = src[1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            gn_pair_acc(sa[0], qa[0], v[j][0].x); gn_pair_acc(sa[1], qa[1], v[j][0].y);
+            gn_pair_acc(sa[2], qa[2], v[j][0].z); gn_pair_acc(sa[3], qa[3], v[j][0].w);
+            gn_pair_acc(sa[4], qa[4], v[j][1].x); gn_pair_acc(sa[5], qa[5], v[j][1].y);
+            gn_pair_acc(sa[6], qa[6], v[j][1].z); gn_pair_acc(sa[7], qa[7], v[j][1].w);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sa[k] = gn_row16_sum(sa[k]); qa[k] = gn_row16_sum(qa[k]); }
+        if (e == 0 && ok) {
+            float4* o = reinterpret_cast<float4*>(ob + c);
+            o[0] = make_float4(sa[0], qa[0], sa[1], qa[1]);
+            o[1] = make_float4(sa[2], qa[2], sa[3], qa[3]);
+            o[2] = make_float4(sa[4], qa[4], sa[5], qa[5]);
+            o[3] = make_float4(sa[6], qa[6], sa[7], qa[7]);
+        }
+    }
+}
+
+// blocks -> partial [N][1][G][2] fp64: thread (g, sl) adds the blocks sl, sl + S, .. of its sample (pairs of the group ascending
+// inside a block), the S slices are then added in order — a fixed order per (C, HW, G), so a sample's bits do not depend on its batch.
+__global__ __launch_bounds__(256) void gn_blocks_final_kernel(const float* __restrict__ blocks, int nb, int C, int G, double* __restrict__ partial) {
+    __shared__ double sh[2 * 256];
+    const int n = blockIdx.x, t = threadIdx.x;
+    const int S = 256 / G, g = t % G, sl = t / G, cpg = C / G;
+    double ds = 0.0, dq = 0.0;
+    if (sl < S) {
+        const float* in = blocks + (size_t)n * nb * C + (size_t)g * cpg;
+        for (int b = sl; b < nb; b += S) {
+            const float* r = in + (size_t)b * C;
+            for (int k = 0; k < cpg; k += 2) { ds += (double)r[k]; dq += (double)r[k + 1]; }
+        }
+    }
+    sh[2 * t] = ds; sh[2 * t + 1] = dq;
+    __syncthreads();
+    if (t < G) {
+        ds = 0.0; dq = 0.0;
+        for (int k = 0; k < S; ++k) { ds += sh[2 * (k * G + t)]; dq += sh[2 * (k * G + t) + 1]; }
+        partial[((size_t)n * G + t) * 2] = ds;
+        partial[((size_t)n * G + t) * 2 + 1] = dq;
+    }
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // grid (pixel chunks, N); thread = fixed 8-channel column (its affine lives in registers) x row group.
@@ -383,8 +448,22 @@ hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, in
     return hipGetLastError();
 }
 
+hipError_t launch_gn_blocks(const f16* X, int rows, int C, int row0, float* blocks, hipStream_t s) {
+    if (rows % 64 || row0 % 64 || C % 16 || row0 > rows) return hipErrorInvalidValue;
+    const int nblk = rows / 64, blk0 = row0 / 64;
+    if (nblk == blk0) return hipSuccess;
+    hipLaunchKernelGGL(gn_blocks_kernel, dim3((nblk - blk0 + 3) / 4), dim3(256), 0, s, X, nblk, C, blk0, blocks);
+    return hipGetLastError();
+}
+
+hipError_t launch_gn_blocks_final(const float* blocks, int N, int HW, int C, int G, double* partial, hipStream_t s) {
+    if (HW % 64 || C % G || (C / G) % 2 || G > 64 || 256 % G) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_blocks_final_kernel, dim3(N), dim3(256), 0, s, blocks, HW / 64, C, G, partial);
+    return hipGetLastError();
+}
+
 hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, int C1, int G, float eps, const float* gamma,
-                           const float* beta, const double* partial, int silu, f16* Y, hipStream_t s) {
+                           const float* beta, const double* partial, int silu, f16* Y, hipStream_t s, int chunks) {
     if (C % 8 || C % G || C1 % 8 || G > 64) return hipErrorInvalidValue;
     int R, threads; gn_geometry(C, &R, &threads);
     if (threads < G) threads = 64;
@@ -392,7 +471,7 @@ hipError_t launch_gn_apply(const f16* X, const f16* X2, int N, int HW, int C, in
     int ppb = 256;
     while (ppb > 8 && (long long)N * ((HW + ppb - 1) / ppb) < 2048) ppb >>= 1;
     hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + ppb - 1) / ppb, N), dim3(threads), 0, s, X, X2 ? X2 : X, HW, C, C1, R,
-                       ppb, partial, gn_stats_chunks(HW), G, (double)HW * (double)(C / G), eps, gamma, beta, silu, Y);
+                       ppb, partial, chunks > 0 ? chunks : gn_stats_chunks(HW), G, (double)HW * (double)(C / G), eps, gamma, beta, silu, Y);
     return hipGetLastError();
 }
 

@@ -291,6 +291,10 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
  *   "attn2_fuse" (0 / 1): 1 = LayerNorm2 -> attn2.to_q computed inside the 77-key cross-attention kernel at the 320-channel level
  *     (attention_crossq.hip: the q tensor is never written or read) — numerically equivalent, not bit-identical to 0; measured SLOWER than
  *     the two launches (0.548 vs 0.491 ms per layer, +0.55 ms per step: DESIGN.md section 4g), hence off;
+ *   "gn_epi" (0 / 1): 1 = norm2's GroupNorm statistics as per-(64-row block, channel pair) sums written by conv1's epilogue where the
+ *     persistent kernels run it and computed from conv1's output where they do not (bit-identical between the two, so independent of
+ *     the batch); 0 = the statistics pass.  Numerically equivalent, not bit-identical to 0 (another summation order).  Measured +-0 /
+ *     +0.4 ms per step (the 0.4 ms of statistics passes it removes come back as lower clocks on a power-limited chip: DESIGN.md 4g), hence off;
  *   "graph" (0 / 1): replay whole U-Net runs as captured hipGraphs (bit-identical: the same kernels with the same arguments);
  *   "igemm_exp": experimental kernel paths of the current round (0 = shipped). */
 int dm_set_option(const char* name, int value);
@@ -331,6 +335,17 @@ int dm_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, 
                     const float* gamma, const float* beta, int silu, void* Y);
 int dm_op_layernorm(void* stream, const void* X, int rows, int C, const float* gamma, const float* beta, float eps,
                     void* Y);
+/* GroupNorm statistics as per-(64-row block, channel pair) fp32 sums (r05): blocks [rows / 64][C], entry (b, 2 k + {0, 1}) = (sum, sum of
+ * squares) of channels 2 k, 2 k + 1 over rows 64 b .. 64 b + 63.  dm_op_gn_blocks computes the blocks of rows [row0, rows) from X [rows][C];
+ * dm_op_conv_temb_gn_blocks is ResnetBlock2D.conv1 (3x3, + bias, + time-embedding row temb [N][temb_ld]) whose persistent kernels write the
+ * blocks of the first *rows_done rows of Y from their epilogue (bit-identical to dm_op_gn_blocks on Y; 0 rows when another tile kernel takes
+ * the launch); dm_op_groupnorm_blocks = the fixed-order fp64 combine + the apply (+ SiLU) — the path norm2 takes in the engine
+ * (option "gn_epi").  rows % 64 == 0, HW % 64 == 0, C % 16 == 0, C / G even. */
+int dm_op_conv_temb_gn_blocks(void* stream, const void* X, const void* Wp, const void* bias, const void* temb, void* Y, int N, int H, int W,
+                              int Cin, int Cout, int temb_ld, float* blocks, int* rows_done);
+int dm_op_gn_blocks(void* stream, const void* X, int rows, int C, int row0, float* blocks);
+int dm_op_groupnorm_blocks(void* stream, const void* X, const float* blocks, int N, int HW, int C, int G, float eps, const float* gamma,
+                           const float* beta, int silu, void* Y);
 /* A GEMM with a second GEMM on another tensor folded into its k loop: after its own taps on X [N,H,W,Cin] (mode 1: 3x3 stride 1;
  * mode 0: dense) the loop runs a 1x1 convolution on cat([X3 (C3 channels), X4 (C4 channels)]) (same N, H, W).  Wp [Cout][taps*Cin + C3 + C4]:
  * the first GEMM's row (k = (tap, cin)) followed by the second's; bias = the sum of both; res = optional residual [M][Cout].

@@ -1256,3 +1256,87 @@ def test_upconv_folded_refuses_what_it_does_not_take():
     torch.cuda.synchronize()
     assert (y == 7.0).all()
     assert lib.dm_op_fold_upconv_weights(None, 320, 64, None) != 0
+
+
+def _block_sums_torch(y2d):
+    """[rows][C] fp16 -> [rows / 64][C] fp64: (sum, sum of squares) of every channel pair over 64-row blocks, exact in fp64."""
+    rows, C = y2d.shape
+    v = y2d.double().view(rows // 64, 64, C // 2, 2)
+    s = v.sum(dim=(1, 3))
+    q = (v * v).sum(dim=(1, 3))
+    return torch.stack([s, q], dim=-1).reshape(rows // 64, C)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,tap_reuse,expect", [
+    (32, 64, 64, 320, 320, 1, "all"),       # the tap-reuse kernel, 64-pixel-wide images (two whole rounds of tiles): every block from the epilogue
+    (32, 64, 64, 320, 320, 0, "all"),       # the plain persistent kernel
+    (40, 64, 64, 320, 320, 1, "head"),      # 2.5 rounds: the head from the epilogue, the tail rows (128-row tile) from the output
+    (160, 16, 16, 1280, 1280, 1, "head"),   # 2.5 rounds of 256-row tiles: the head from the epilogue, the tail rows from the output
+    (96, 32, 32, 640, 640, 1, "none"),      # the 32-pixel-wide tap-reuse kernel does not emit them
+    (2, 16, 16, 320, 320, 1, "none"),       # a launch the 128-row tile takes
+])
+def test_groupnorm_block_sums_from_the_conv1_epilogue(N, H, W, Cin, Cout, tap_reuse, expect):
+    """r05: norm2's statistics as per-(64-row block, channel pair) fp32 sums.  The persistent kernels write them from conv1's epilogue
+    (dm_op_conv_temb_gn_blocks); dm_op_gn_blocks computes them from the tensor.  Both must give the SAME BITS (which of the two produced a
+    block depends on the batch size through the tile choice), the conv output must not change, and the sums must be the fp64 sums of
+    the fp16 output to fp32 accuracy."""
+    import ctypes
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    x = U.f16_randn(N, H, W, Cin, seed=41, scale=0.7).to(d)
+    w = U.f16_randn(Cout, 9 * Cin, seed=42, scale=(9 * Cin) ** -0.5).to(d)
+    b = U.f16_randn(Cout, seed=43, scale=0.2).to(d)
+    temb = U.f16_randn(N, Cout, seed=44, scale=0.5).to(d)
+    M = N * H * W
+    try:
+        lib.dm_set_option(b"tap_reuse", tap_reuse)              # (the option also selects the k order: the reference output under the same one)
+        y_ref = U.op_igemm(x, w, bias=b, temb=temb, mode=1)
+        y = torch.empty(N, H, W, Cout, dtype=torch.float16, device=d)
+        blocks = torch.full((M // 64, Cout), float("nan"), dtype=torch.float32, device=d)
+        done = ctypes.c_int(-1)
+        assert lib.dm_op_conv_temb_gn_blocks(U.stream(), U.ptr(x), U.ptr(w), U.ptr(b), U.ptr(temb), U.ptr(y), N, H, W, Cin, Cout, Cout,
+                                             U.ptr(blocks), ctypes.byref(done)) == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.dm_set_option(b"tap_reuse", 1)
+    assert torch.equal(y, y_ref)
+    rows_done = done.value
+    if expect == "all":
+        assert rows_done == M
+    elif expect == "none":
+        assert rows_done == 0
+    else:
+        assert 0 < rows_done < M and rows_done % 256 == 0
+    assert torch.isnan(blocks[rows_done // 64:]).all()                # nothing written beyond what was promised
+    full = torch.full_like(blocks, float("nan"))
+    assert lib.dm_op_gn_blocks(U.stream(), U.ptr(y), M, Cout, 0, U.ptr(full)) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(full).all()
+    assert torch.equal(blocks[:rows_done // 64], full[:rows_done // 64])      # bit-identical between the two producers
+    # the caller's completion: rows [rows_done, M) from the tensor
+    assert lib.dm_op_gn_blocks(U.stream(), U.ptr(y), M, Cout, rows_done, U.ptr(blocks)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(blocks, full)
+    ref = _block_sums_torch(y.view(M, Cout))
+    scale = _block_sums_torch(y.view(M, Cout).abs())
+    assert ((full.double() - ref).abs() <= 4e-6 * scale + 1e-6).all()
+    # statistics -> GroupNorm + SiLU vs F.group_norm in fp32 on the same fp16 tensor, at the tolerance of test_groupnorm
+    g = (torch.randn(Cout, generator=torch.Generator().manual_seed(45)) * 0.1 + 1).to(d)
+    be = (torch.randn(Cout, generator=torch.Generator().manual_seed(46)) * 0.1).to(d)
+    n_chk = min(N, 4)
+    out = torch.empty(n_chk, H, W, Cout, dtype=torch.float16, device=d)
+    assert lib.dm_op_groupnorm_blocks(U.stream(), U.ptr(y), U.ptr(full), n_chk, H * W, Cout, 32, 1e-5, U.ptr(g), U.ptr(be), 1, U.ptr(out)) == 0
+    torch.cuda.synchronize()
+    refn = F.silu(F.group_norm(U.to_nchw(y[:n_chk]).float(), 32, g, be, 1e-5))
+    U.assert_close_fp16(U.to_nchw(out), refn, "groupnorm from block sums")
+    # and the same bits as the r04 statistics pass would give after the apply?  Not required (another summation order) — but a sample's
+    # result must not depend on the batch: sample 1 alone
+    if N >= 2:
+        one = torch.empty(1, H, W, Cout, dtype=torch.float16, device=d)
+        bl1 = torch.empty(H * W // 64, Cout, dtype=torch.float32, device=d)
+        y1 = y[1:2].contiguous()
+        assert lib.dm_op_gn_blocks(U.stream(), U.ptr(y1), H * W, Cout, 0, U.ptr(bl1)) == 0
+        assert lib.dm_op_groupnorm_blocks(U.stream(), U.ptr(y1), U.ptr(bl1), 1, H * W, Cout, 32, 1e-5, U.ptr(g), U.ptr(be), 1, U.ptr(one)) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(one[0], out[1])
