@@ -60,7 +60,7 @@ inline void launch_timed(F kernel, const dim3& grid, const dim3& block, size_t l
 
 // Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of
 // the same name in upper case with a DM_ prefix (DM_IGEMM_PERSIST=0 ...), changeable through dm_set_option().
-enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_TAP_REUSE, OPT_UP_FOLD, OPT_Q_ONCE, OPT_ATTN2_FUSE, OPT_GN_EPI, OPT_COUNT };
+enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_TAP_REUSE, OPT_UP_FOLD, OPT_Q_ONCE, OPT_ATTN2_FUSE, OPT_GN_EPI, OPT_CONV_OUT_ROWS, OPT_COUNT };
 int option(Option o);                       // engine.hip
 int set_option(const char* name, int value);   // 0 on success
 int get_option(const char* name, int* value);  // 0 on success
@@ -274,6 +274,11 @@ hipError_t launch_conv_out(const f16* Xn /* NHWC [B,H,W,C0] */, const f16* w /* 
                            const f16* bias, const void* eps /* fp32 if eps_f32 else fp16 */, int eps_f32, int B, int H, int W, int C0,
                            float* loss, f16* pred, int eps_rows, int out_group, int out_stride, int out_off,
                            hipStream_t s);
+// the same layer with the input rows staged once in LDS and walked by all nine taps on the matrix cores (conv_out.hip, r05; option
+// conv_out_rows): launch_conv_out takes it where conv_out_rows_strip(H, W, C0) > 0 (C0 = 320, W <= ~160)
+int conv_out_rows_strip(int H, int W, int C0);
+hipError_t launch_conv_out_rows(const f16* Xn, const f16* w, const f16* bias, const void* eps, int eps_f32, int B, int H, int W, int C0,
+                                float* loss, f16* pred, int eps_rows, int out_group, int out_stride, int out_off, hipStream_t s);
 hipError_t launch_nhwc_to_nchw(const f16* X, int N, int HW, int C, f16* Y, hipStream_t s);
 // mean over groups of `ens` consecutive samples, NHWC fp16 -> NCHW fp32
 hipError_t launch_ensemble_mean(const f16* X, int groups, int ens, int HW, int C, float* Y, hipStream_t s);

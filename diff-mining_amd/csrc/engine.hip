@@ -1222,7 +1222,7 @@ int ensure_arena_for(dm_engine* e, hipStream_t s, const std::vector<long long>& 
 
 std::vector<long long> fwd_key(const FwdArgs& A) {
     return {0, A.B, A.H, A.W, A.n_cond, A.up_ft_index, A.add_noise ? 1 : 0, A.loss ? 1 : 0, A.pred ? 1 : 0, A.feat ? 1 : 0,
-            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD), option(OPT_FF_FOLD), option(OPT_UP_FOLD), option(OPT_Q_ONCE), option(OPT_ATTN2_FUSE), option(OPT_GN_EPI)};
+            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD), option(OPT_FF_FOLD), option(OPT_UP_FOLD), option(OPT_Q_ONCE), option(OPT_ATTN2_FUSE), option(OPT_GN_EPI), option(OPT_CONV_OUT_ROWS)};
 }
 
 int ensure_arena(dm_engine* e, const FwdArgs& A, hipStream_t s) {
@@ -1308,7 +1308,7 @@ namespace {
 struct OptDef { const char* name; const char* env; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
-    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1}, {"tap_reuse", "DM_TAP_REUSE", 1}, {"up_fold", "DM_UP_FOLD", 1}, {"q_once", "DM_Q_ONCE", 1}, {"attn2_fuse", "DM_ATTN2_FUSE", 0}, {"gn_epi", "DM_GN_EPI", 0},
+    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1}, {"tap_reuse", "DM_TAP_REUSE", 1}, {"up_fold", "DM_UP_FOLD", 1}, {"q_once", "DM_Q_ONCE", 1}, {"attn2_fuse", "DM_ATTN2_FUSE", 0}, {"gn_epi", "DM_GN_EPI", 0}, {"conv_out_rows", "DM_CONV_OUT_ROWS", 1},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<int> g_opt_init{0};
@@ -2225,6 +2225,12 @@ int dm_op_conv_temb_gn_blocks(void* stream, const void* X, const void* Wp, const
     p.gn_blocks = blocks;
     if (rows_done) *rows_done = igemm_gn_rows(p);
     return launch_igemm(p, (hipStream_t)stream) == hipSuccess ? 0 : 1;
+}
+
+int dm_op_conv_out(void* stream, const void* Xn, const void* w, const void* bias, const float* eps, int B, int H, int W, int C0, float* loss,
+                   void* pred) {
+    return launch_conv_out((const f16*)Xn, (const f16*)w, (const f16*)bias, eps, 1, B, H, W, C0, loss, (f16*)pred, B, B, 0, 0,
+                           (hipStream_t)stream) == hipSuccess ? 0 : 1;
 }
 
 int dm_op_gn_blocks(void* stream, const void* X, int rows, int C, int row0, float* blocks) {

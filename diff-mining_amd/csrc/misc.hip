@@ -388,6 +388,8 @@ hipError_t launch_im2col_in(const void* x, const int32_t* x_index, const void* e
 hipError_t launch_conv_out(const f16* Xn, const f16* w, const f16* bias, const void* eps, int eps_f32, int B, int H, int W,
                            int C0, float* loss, f16* pred, int eps_rows, int out_group, int out_stride, int out_off,
                            hipStream_t s) {
+    if (option(OPT_CONV_OUT_ROWS) != 0 && conv_out_rows_strip(H, W, C0) > 0)
+        return launch_conv_out_rows(Xn, w, bias, eps, eps_f32, B, H, W, C0, loss, pred, eps_rows, out_group, out_stride, out_off, s);
     const long long npix = (long long)B * H * W;
     const size_t lds = (size_t)4 * 9 * C0 * sizeof(f16);
     const dim3 grid((unsigned)((npix + 32 * CONV_OUT_GROUPS - 1) / (32 * CONV_OUT_GROUPS))), block(256);

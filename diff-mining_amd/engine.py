@@ -23,7 +23,7 @@ SYMBOLS = [
     "dm_engine_set_prompts", "dm_score", "dm_score_conds", "dm_score_conds_slots", "dm_unet_forward", "dm_dift", "dm_dift_shape",
     "dm_reduce_typicality", "dm_typicality_image", "dm_prof_enable", "dm_prof_read", "dm_engine_memory",
     "dm_op_igemm", "dm_op_attention", "dm_op_cross_attention_q", "dm_op_groupnorm", "dm_op_layernorm",
-    "dm_op_conv_temb_gn_blocks", "dm_op_gn_blocks", "dm_op_groupnorm_blocks",
+    "dm_op_conv_temb_gn_blocks", "dm_op_gn_blocks", "dm_op_groupnorm_blocks", "dm_op_conv_out",
     "dm_engine_load_vae_weight", "dm_engine_finalize_vae", "dm_vae_encode", "dm_op_attention512", "dm_patch_embed",
     "dm_engine_load_clip_weight", "dm_engine_finalize_clip", "dm_clip_encode", "dm_op_igemm_splitk",
     "dm_op_ln_stats", "dm_op_igemm_ln", "dm_reduce_typicality_batched", "dm_op_igemm_tile", "dm_op_igemm_head_rows", "dm_set_option",
@@ -36,7 +36,7 @@ SYMBOLS = [
 ]
 
 
-def get_options(names=("ln_fold", "gn_fold", "ff_fold", "sc_fold", "up_fold", "tap_reuse", "ln_inkernel", "igemm_splitk", "q_once", "attn2_fuse", "gn_epi", "attn_pipe", "graph")) -> dict:
+def get_options(names=("ln_fold", "gn_fold", "ff_fold", "sc_fold", "up_fold", "tap_reuse", "ln_inkernel", "igemm_splitk", "q_once", "attn2_fuse", "gn_epi", "conv_out_rows", "attn_pipe", "graph")) -> dict:
     """Current values of the library's runtime switches (dm_get_option); {} with a library that predates the getter."""
     lib = load_library()
     out = {}
@@ -98,6 +98,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_op_attention.argtypes = [vp] * 5 + [i32] * 4 + [i64] * 4 + [vp] + [i32] * 5 + [C.c_float]
     lib.dm_op_cross_attention_q.argtypes = [vp] * 5 + [C.c_float] + [vp] * 3 + [i32] * 2 + [i64] * 2 + [vp] + [i32] * 5 + [C.c_float]
     lib.dm_op_groupnorm.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, C.c_float, vp, vp, i32, vp]
+    if hasattr(lib, "dm_op_conv_out"):
+        lib.dm_op_conv_out.argtypes = [vp] * 5 + [i32] * 4 + [vp, vp]
     if hasattr(lib, "dm_op_gn_blocks"):          # (absent only from older A/B libraries loaded through DM_ENGINE_LIB)
         lib.dm_op_conv_temb_gn_blocks.argtypes = [vp] * 6 + [i32] * 6 + [vp, C.POINTER(C.c_int)]
         lib.dm_op_gn_blocks.argtypes = [vp, vp, i32, i32, i32, vp]

@@ -295,6 +295,8 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
  *     persistent kernels run it and computed from conv1's output where they do not (bit-identical between the two, so independent of
  *     the batch); 0 = the statistics pass.  Numerically equivalent, not bit-identical to 0 (another summation order).  Measured +-0 /
  *     +0.4 ms per step (the 0.4 ms of statistics passes it removes come back as lower clocks on a power-limited chip: DESIGN.md 4g), hence off;
+ *   "conv_out_rows" (1 / 0): conv_out + eps-MSE with the input rows staged once in LDS and walked by all nine taps on the matrix cores
+ *     (conv_out.hip) instead of the per-pixel gather (misc.hip) — equal to fp32 rounding, not bit-identical;
  *   "graph" (0 / 1): replay whole U-Net runs as captured hipGraphs (bit-identical: the same kernels with the same arguments);
  *   "igemm_exp": experimental kernel paths of the current round (0 = shipped). */
 int dm_set_option(const char* name, int value);
@@ -341,6 +343,11 @@ int dm_op_layernorm(void* stream, const void* X, int rows, int C, const float* g
  * blocks of the first *rows_done rows of Y from their epilogue (bit-identical to dm_op_gn_blocks on Y; 0 rows when another tile kernel takes
  * the launch); dm_op_groupnorm_blocks = the fixed-order fp64 combine + the apply (+ SiLU) — the path norm2 takes in the engine
  * (option "gn_epi").  rows % 64 == 0, HW % 64 == 0, C % 16 == 0, C / G even. */
+/* conv_out (3x3, C0 -> 4, + bias, rounded to fp16 = `unet(...).sample`) on Xn [B,H,W,C0] fp16 NHWC with w [4][9*C0] (k = (tap, cin)): pred
+ * [B,4,H,W] fp16 (optional) and, with eps [B,4,H,W] fp32, loss [B,4,H,W] fp32 = (pred - eps)^2 — the last two steps of SD.compute_loss
+ * (compute.py:100-101).  Option "conv_out_rows" selects the kernel (1: input rows staged in LDS, conv_out.hip; 0: per-pixel gather). */
+int dm_op_conv_out(void* stream, const void* Xn, const void* w, const void* bias, const float* eps, int B, int H, int W, int C0, float* loss,
+                   void* pred);
 int dm_op_conv_temb_gn_blocks(void* stream, const void* X, const void* Wp, const void* bias, const void* temb, void* Y, int N, int H, int W,
                               int Cin, int Cout, int temb_ld, float* blocks, int* rows_done);
 int dm_op_gn_blocks(void* stream, const void* X, int rows, int C, int row0, float* blocks);

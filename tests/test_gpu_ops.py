@@ -1340,3 +1340,48 @@ def test_groupnorm_block_sums_from_the_conv1_epilogue(N, H, W, Cin, Cout, tap_re
         assert lib.dm_op_groupnorm_blocks(U.stream(), U.ptr(y1), U.ptr(bl1), 1, H * W, Cout, 32, 1e-5, U.ptr(g), U.ptr(be), 1, U.ptr(one)) == 0
         torch.cuda.synchronize()
         assert torch.equal(one[0], out[1])
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 64, 64), (2, 12, 10), (2, 16, 24), (1, 128, 128), (2, 8, 8), (1, 64, 85), (2, 5, 3), (1, 4, 170)])
+def test_conv_out_with_rows_staged_in_lds(B, H, W):
+    """conv_out + eps-MSE (the last two steps of SD.compute_loss, compute.py:100-101): the r05 kernel (conv_out.hip: a strip's input
+    rows staged once in LDS, nine taps on the matrix cores) and the per-pixel gather kernel (misc.hip) against F.conv2d in fp64 on the
+    same fp16 operands: pred within one fp16 rounding of the exact value, loss = (float(pred) - eps)^2 bit for bit, every strip
+    geometry (ragged last strip, W not a multiple of 16, one-row strips at W = 128, W = 170: the geometry the new kernel leaves
+    to the old one), and a sample's bits independent of the batch."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    d = U.dev()
+    C0 = 320
+    x = U.f16_randn(B, H, W, C0, seed=51, scale=1.0)
+    w4 = U.f16_randn(4, C0, 3, 3, seed=52, scale=(9 * C0) ** -0.5)
+    bias = U.f16_randn(4, seed=53, scale=0.1)
+    eps = torch.randn(B, 4, H, W, generator=torch.Generator().manual_seed(54))
+    ref = F.conv2d(U.to_nchw(x).double(), w4.double(), bias.double(), padding=1)
+    xd, wd, bd, ed = x.to(d), U.pack_conv3(w4).to(d), bias.to(d), eps.to(d)
+    out = {}
+    try:
+        for v in (1, 0):
+            assert lib.dm_set_option(b"conv_out_rows", v) == 0
+            loss = torch.full((B, 4, H, W), float("nan"), device=d)
+            pred = torch.full((B, 4, H, W), float("nan"), dtype=torch.float16, device=d)
+            assert lib.dm_op_conv_out(U.stream(), U.ptr(xd), U.ptr(wd), U.ptr(bd), U.ptr(ed), B, H, W, C0, U.ptr(loss), U.ptr(pred)) == 0
+            torch.cuda.synchronize()
+            out[v] = (loss, pred)
+            err = (pred.double().cpu() - ref).abs()
+            ulp = torch.maximum(ref.abs(), torch.tensor(2.0 ** -14, dtype=torch.float64)) * 2.0 ** -10
+            assert (err <= 0.5 * ulp + 1e-5).all(), (v, (err / ulp).max().item())       # fp16 rounding of an fp32 sum of 2880 exact products
+            assert torch.equal(loss, (pred.float() - ed) ** 2)
+        assert lib.dm_set_option(b"conv_out_rows", 1) == 0
+        if B > 1:
+            l1 = torch.empty(1, 4, H, W, device=d)
+            p1 = torch.empty(1, 4, H, W, dtype=torch.float16, device=d)
+            x1, e1 = xd[1:2].contiguous(), ed[1:2].contiguous()
+            assert lib.dm_op_conv_out(U.stream(), U.ptr(x1), U.ptr(wd), U.ptr(bd), U.ptr(e1), 1, H, W, C0, U.ptr(l1), U.ptr(p1)) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(p1[0], out[1][1][1]) and torch.equal(l1[0], out[1][0][1])
+    finally:
+        lib.dm_set_option(b"conv_out_rows", 1)
+    same = (out[0][1] == out[1][1]).float().mean().item()
+    print(f"conv_out {B}x{H}x{W}: {100 * same:.2f} % of the fp16 outputs equal between the two kernels")
+    assert same > 0.98
