@@ -291,10 +291,10 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
  *   "attn2_fuse" (0 / 1): 1 = LayerNorm2 -> attn2.to_q computed inside the 77-key cross-attention kernel at the 320-channel level
  *     (attention_crossq.hip: the q tensor is never written or read) — numerically equivalent, not bit-identical to 0; measured SLOWER than
  *     the two launches (0.548 vs 0.491 ms per layer, +0.55 ms per step: DESIGN.md section 4g), hence off;
- *   "gn_epi" (0 / 1): 1 = norm2's GroupNorm statistics as per-(64-row block, channel pair) sums written by conv1's epilogue where the
+ *   "gn_epi" (1 / 0): 1 = norm2's GroupNorm statistics as per-(64-row block, channel pair) sums written by conv1's epilogue where the
  *     persistent kernels run it and computed from conv1's output where they do not (bit-identical between the two, so independent of
- *     the batch); 0 = the statistics pass.  Numerically equivalent, not bit-identical to 0 (another summation order).  Measured +-0 /
- *     +0.4 ms per step (the 0.4 ms of statistics passes it removes come back as lower clocks on a power-limited chip: DESIGN.md 4g), hence off;
+ *     the batch); 0 = the statistics pass.  Numerically equivalent, not bit-identical to 0 (another summation order); -0.3 ms per step
+ *     (DESIGN.md 4g);
  *   "conv_out_rows" (1 / 0): conv_out + eps-MSE with the input rows staged once in LDS and walked by all nine taps on the matrix cores
  *     (conv_out.hip) instead of the per-pixel gather (misc.hip) — equal to fp32 rounding, not bit-identical;
  *   "graph" (0 / 1): replay whole U-Net runs as captured hipGraphs (bit-identical: the same kernels with the same arguments);

@@ -1,10 +1,12 @@
 #!/bin/bash
-# per-kernel time with option gn_epi 0 / 1 (rocprofv3 kernel trace of 6 bench steps each): every kernel whose total differs by > 0.1 ms
+# per-kernel time with an engine option at 0 / 1 (rocprofv3 kernel trace of 6 bench steps each): every kernel whose total differs by > 0.1 ms
+#     bash tools/option_kernel_diff.sh DM_CONV_OUT_ROWS
+OPT=${1:-DM_GN_EPI}; ORDER=${2:-0 1}      # second argument: the order the two arms run in ("1 0": the thermal drift of the box falls on the other arm)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-for v in 0 1; do
+for v in $ORDER; do
     rm -rf /tmp/gnp$v
-    DM_GN_EPI=$v rocprofv3 --kernel-trace --stats -f csv -d /tmp/gnp$v -o p -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-side --no-parity > /dev/null 2>&1
+    env $OPT=$v rocprofv3 --kernel-trace --stats -f csv -d /tmp/gnp$v -o p -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-side --no-parity > /dev/null 2>&1
 done
 python - <<PY
 import csv,glob
