@@ -60,7 +60,7 @@ inline void launch_timed(F kernel, const dim3& grid, const dim3& block, size_t l
 
 // Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of
 // the same name in upper case with a DM_ prefix (DM_IGEMM_PERSIST=0 ...), changeable through dm_set_option().
-enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_TAP_REUSE, OPT_UP_FOLD, OPT_Q_ONCE, OPT_ATTN2_FUSE, OPT_GN_EPI, OPT_CONV_OUT_ROWS, OPT_COUNT };
+enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_TAP_REUSE, OPT_UP_FOLD, OPT_Q_ONCE, OPT_ATTN2_FUSE, OPT_GN_EPI, OPT_CONV_OUT_ROWS, OPT_GN_SKIP, OPT_COUNT };
 int option(Option o);                       // engine.hip
 int set_option(const char* name, int value);   // 0 on success
 int get_option(const char* name, int* value);  // 0 on success
@@ -239,6 +239,12 @@ __device__ __forceinline__ void gn_pair_acc(float& s, float& q, unsigned w) {
     s = __builtin_amdgcn_fdot2(v, gn_half2{(_Float16)1.0f, (_Float16)1.0f}, s, false);
     q = __builtin_amdgcn_fdot2(v, v, q, false);
 }
+// GroupNorm over cat([x (C1 channels), skip (C2 channels)]) whose skip half was already summed for an earlier GroupNorm of the skip alone
+// (r05, option gn_skip: the up path's norm1 against the down path's): px [N][chunks][G1][2] = the partial sums of x taken with G1 = C1 / cpg
+// groups (cpg = (C1 + C2) / G), pskip [Ns][chunks][G][2] = the skip's own partial sums (its G groups of C2 / G channels: m = cpg / (C2 / G)
+// consecutive ones make a group of the concatenation); sample n reads skip row n % Ns (the stacked copies of the shared-draw prefix).
+// out [N][1][G][2]: chunks ascending, then the m skip groups ascending — a fixed order, so a sample's bits do not depend on its batch.
+hipError_t launch_gn_merge_skip(const double* px, const double* pskip, int N, int Ns, int chunks, int G, int G1, int m, double* out, hipStream_t s);
 hipError_t launch_gn_blocks(const f16* X, int rows, int C, int row0, float* blocks, hipStream_t s);
 hipError_t launch_gn_blocks_final(const float* blocks, int N, int HW, int C, int G, double* partial, hipStream_t s);
 int igemm_gn_rows(const IGemmParams& p);

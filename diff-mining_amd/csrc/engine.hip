@@ -96,6 +96,8 @@ struct Tensor {            // NHWC activation in the arena
     int N = 0, H = 0, W = 0, C = 0;
     bool view = false;     // a pre-placed window into another tensor (first_slot()): producers write it in place, free() ignores it
                            // (explicit: in the dry run every pointer is null, so "p set, off unset" cannot mark a view)
+    int sid = -1;          // index of this tensor in the U-Net's skip list (r05, option gn_skip): its GroupNorm partial sums, taken for the down path's
+                           // norm1, are kept for the up path's norm1 over cat([x, skip])
     long long rows() const { return (long long)N * H * W; }
 };
 
@@ -497,6 +499,11 @@ struct Fwd {
     hipStream_t s;
     bool dry;
     float res_eps = GN_EPS;   // GroupNorm eps of the ResNet blocks (U-Net 1e-5, VAE 1e-6)
+    struct SkipStat { size_t off = (size_t)-1; const double* p = nullptr; int N = 0, C = 0, HW = 0; };
+    std::vector<SkipStat> skip_stats;      // by Tensor::sid
+    void free_skip_stat(int sid) {
+        if (sid >= 0 && sid < (int)skip_stats.size() && skip_stats[sid].off != (size_t)-1) { e->arena.release(skip_stats[sid].off); skip_stats[sid] = SkipStat(); }
+    }
 
     int alloc(Tensor* t, int N, int H, int W, int C) {
         t->N = N; t->H = H; t->W = W; t->C = C;
@@ -606,6 +613,27 @@ struct Fwd {
         if (C != nw.c) DM_FAIL(e, "groupnorm: channel mismatch %d vs %d", C, nw.c);
         const int HW = x.H * x.W;
         const int chunks = gn_stats_chunks(HW);
+        // the skip half of a concatenated input was summed once already, for the GroupNorm that read the skip alone in the down path: sum x
+        // only (in the concatenation's group width) and merge — one read of the skip tensor less.  Which layers do this is a property of the
+        // network (channel counts, which skips a down-path norm1 reads), never of the batch.
+        if (x2 && x2->sid >= 0 && x2->sid < (int)skip_stats.size() && skip_stats[x2->sid].off != (size_t)-1) {
+            const SkipStat& st = skip_stats[x2->sid];
+            const int cpg = C / GROUPS, cpg2 = x2->C / GROUPS;
+            if (st.C == x2->C && st.HW == HW && C % GROUPS == 0 && x2->C % GROUPS == 0 && x.C % cpg == 0 && cpg % cpg2 == 0 && x.N % st.N == 0 && x.C % 8 == 0) {
+                const int G1 = x.C / cpg, m = cpg / cpg2;
+                size_t poff, moff; void *pp, *mp;
+                DM_TRY(alloc_raw((size_t)x.N * chunks * G1 * 2 * sizeof(double), &poff, &pp));
+                DM_TRY(alloc_raw((size_t)x.N * GROUPS * 2 * sizeof(double), &moff, &mp));
+                DM_TRY(alloc(y, x.N, x.H, x.W, C));
+                if (!dry) {
+                    DM_HIP(e, launch_gn_stats(x.p, nullptr, x.N, HW, x.C, x.C, G1, (double*)pp, s));
+                    DM_HIP(e, launch_gn_merge_skip((const double*)pp, st.p, x.N, st.N, chunks, GROUPS, G1, m, (double*)mp, s));
+                    DM_HIP(e, launch_gn_apply(x.p, x2->p, x.N, HW, C, x.C, GROUPS, eps, nw.g, nw.b, (const double*)mp, silu ? 1 : 0, y->p, s, 1));
+                }
+                free_raw(poff); free_raw(moff);
+                return 0;
+            }
+        }
         size_t poff; void* pp;
         DM_TRY(alloc_raw((size_t)x.N * chunks * GROUPS * 2 * sizeof(double), &poff, &pp));
         DM_TRY(alloc(y, x.N, x.H, x.W, C));
@@ -613,6 +641,12 @@ struct Fwd {
             DM_HIP(e, launch_gn_stats(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, GROUPS, (double*)pp, s));
             DM_HIP(e, launch_gn_apply(x.p, x2 ? x2->p : nullptr, x.N, HW, C, x.C, GROUPS, eps, nw.g, nw.b, (const double*)pp,
                                       silu ? 1 : 0, y->p, s));
+        }
+        // a skip tensor read alone: keep its partial sums for the up path (released with the skip)
+        if (!x2 && x.sid >= 0 && x.sid < (int)skip_stats.size() && skip_stats[x.sid].off == (size_t)-1 && option(OPT_GN_SKIP) != 0) {
+            SkipStat& st = skip_stats[x.sid];
+            st.off = poff; st.p = (const double*)pp; st.N = x.N; st.C = C; st.HW = HW;
+            return 0;
         }
         free_raw(poff);
         return 0;
@@ -939,8 +973,11 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
     Tensor h, hB;
     if (NC > 1) {                  // the stacked skip tensor; conv_in writes its first slot
         DM_TRY(F.alloc(&hB, U * NC, A.H, A.W, BOC[0]));
+        hB.sid = 0;                 // skip 0: its statistics are taken on the per-draw rows (the copies of a draw share them)
         h = Fwd::first_slot(hB, NC);
-    }
+        h.sid = 0;
+    } else h.sid = 0;
+    F.skip_stats.assign(3 * NB + 4, Fwd::SkipStat());
     {
         Tensor col;
         DM_TRY(F.alloc(&col, U, A.H, A.W, 64));
@@ -991,6 +1028,7 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
             F.free(rB);
         }
         skips.push_back(hB);
+        a.sid = (int)skips.size();
         skips.push_back(a);
         cur = a;
         j_start = 1;
@@ -1010,12 +1048,14 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
                 F.free(r);
                 r = a;
             }
+            r.sid = (int)skips.size();
             skips.push_back(r);
             cur = r;
         }
         if (d.has_down) {
             Tensor dn;
             DM_TRY(F.igemm(d.down, IG_CONV3_S2, cur, nullptr, (cur.H + 1) / 2, (cur.W + 1) / 2, nullptr, 0, nullptr, EPI_PLAIN, &dn));
+            dn.sid = (int)skips.size();
             skips.push_back(dn);
             cur = dn;
         }
@@ -1037,7 +1077,7 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
             Tensor skip = skips.back(); skips.pop_back();
             Tensor r;
             DM_TRY(F.resnet(u.res[j], cur, &skip, tproj.p, &r));
-            F.free(cur); F.free(skip);
+            F.free(cur); F.free(skip); F.free_skip_stat(skip.sid);
             if (u.attn) {
                 Tensor a;
                 DM_TRY(F.transformer(u.tf[j], r, A.slots, &a));
@@ -1075,7 +1115,7 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
         F.free(nrm);
     }
     F.free(cur);
-    for (auto& sk : skips) F.free(sk);
+    for (auto& sk : skips) { F.free(sk); F.free_skip_stat(sk.sid); }
     F.free(tproj);
     return 0;
 }
@@ -1222,7 +1262,7 @@ int ensure_arena_for(dm_engine* e, hipStream_t s, const std::vector<long long>& 
 
 std::vector<long long> fwd_key(const FwdArgs& A) {
     return {0, A.B, A.H, A.W, A.n_cond, A.up_ft_index, A.add_noise ? 1 : 0, A.loss ? 1 : 0, A.pred ? 1 : 0, A.feat ? 1 : 0,
-            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD), option(OPT_FF_FOLD), option(OPT_UP_FOLD), option(OPT_Q_ONCE), option(OPT_ATTN2_FUSE), option(OPT_GN_EPI), option(OPT_CONV_OUT_ROWS)};
+            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD), option(OPT_FF_FOLD), option(OPT_UP_FOLD), option(OPT_Q_ONCE), option(OPT_ATTN2_FUSE), option(OPT_GN_EPI), option(OPT_CONV_OUT_ROWS), option(OPT_GN_SKIP)};
 }
 
 int ensure_arena(dm_engine* e, const FwdArgs& A, hipStream_t s) {
@@ -1308,7 +1348,7 @@ namespace {
 struct OptDef { const char* name; const char* env; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
-    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1}, {"tap_reuse", "DM_TAP_REUSE", 1}, {"up_fold", "DM_UP_FOLD", 1}, {"q_once", "DM_Q_ONCE", 1}, {"attn2_fuse", "DM_ATTN2_FUSE", 0}, {"gn_epi", "DM_GN_EPI", 1}, {"conv_out_rows", "DM_CONV_OUT_ROWS", 1},
+    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1}, {"tap_reuse", "DM_TAP_REUSE", 1}, {"up_fold", "DM_UP_FOLD", 1}, {"q_once", "DM_Q_ONCE", 1}, {"attn2_fuse", "DM_ATTN2_FUSE", 0}, {"gn_epi", "DM_GN_EPI", 1}, {"conv_out_rows", "DM_CONV_OUT_ROWS", 1}, {"gn_skip", "DM_GN_SKIP", 1},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<int> g_opt_init{0};

@@ -140,6 +140,23 @@ __global__ __launch_bounds__(256) void gn_blocks_final_kernel(const float* __res
     }
 }
 
+__global__ void gn_merge_skip_kernel(const double* __restrict__ px, const double* __restrict__ pskip, int Ns, int chunks, int G, int G1, int m,
+                                     double* __restrict__ out) {
+    const int n = blockIdx.x, g = threadIdx.x;
+    if (g >= G) return;
+    double ds = 0.0, dq = 0.0;
+    if (g < G1) {
+        const double* in = px + ((size_t)n * chunks * G1 + g) * 2;
+        for (int c = 0; c < chunks; ++c) { ds += in[(size_t)c * G1 * 2]; dq += in[(size_t)c * G1 * 2 + 1]; }
+    } else {
+        const double* in = pskip + ((size_t)(n % Ns) * chunks * G + (size_t)(g - G1) * m) * 2;
+        for (int c = 0; c < chunks; ++c)
+            for (int j = 0; j < m; ++j) { ds += in[((size_t)c * G + j) * 2]; dq += in[((size_t)c * G + j) * 2 + 1]; }
+    }
+    out[((size_t)n * G + g) * 2] = ds;
+    out[((size_t)n * G + g) * 2 + 1] = dq;
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // grid (pixel chunks, N); thread = fixed 8-channel column (its affine lives in registers) x row group.
@@ -445,6 +462,12 @@ hipError_t launch_gn_stats(const f16* X, const f16* X2, int N, int HW, int C, in
     const int chunks = gn_stats_chunks(HW);
     const size_t lds = (size_t)R * C * 2 * sizeof(float);
     hipLaunchKernelGGL(gn_stats_partial, dim3(chunks, N), dim3(threads), lds, s, X, X2 ? X2 : X, HW, C, C1, G, R, gn_pix(HW), partial);
+    return hipGetLastError();
+}
+
+hipError_t launch_gn_merge_skip(const double* px, const double* pskip, int N, int Ns, int chunks, int G, int G1, int m, double* out, hipStream_t s) {
+    if (G > 64 || G1 <= 0 || G1 >= G || m < 1 || (G - G1) * m != G || Ns < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_merge_skip_kernel, dim3(N), dim3(64), 0, s, px, pskip, Ns, chunks, G, G1, m, out);
     return hipGetLastError();
 }
 

@@ -36,7 +36,7 @@ SYMBOLS = [
 ]
 
 
-def get_options(names=("ln_fold", "gn_fold", "ff_fold", "sc_fold", "up_fold", "tap_reuse", "ln_inkernel", "igemm_splitk", "q_once", "attn2_fuse", "gn_epi", "conv_out_rows", "attn_pipe", "graph")) -> dict:
+def get_options(names=("ln_fold", "gn_fold", "ff_fold", "sc_fold", "up_fold", "tap_reuse", "ln_inkernel", "igemm_splitk", "q_once", "attn2_fuse", "gn_epi", "conv_out_rows", "gn_skip", "attn_pipe", "graph")) -> dict:
     """Current values of the library's runtime switches (dm_get_option); {} with a library that predates the getter."""
     lib = load_library()
     out = {}

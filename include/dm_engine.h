@@ -297,6 +297,9 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
  *     (DESIGN.md 4g);
  *   "conv_out_rows" (1 / 0): conv_out + eps-MSE with the input rows staged once in LDS and walked by all nine taps on the matrix cores
  *     (conv_out.hip) instead of the per-pixel gather (misc.hip) — equal to fp32 rounding, not bit-identical;
+ *   "gn_skip" (1 / 0): 1 = the up path's norm1 over cat([x, skip]) sums x only and merges the skip's GroupNorm partial sums kept from the
+ *     down path's norm1 of the same tensor (one read of the skip less, where the group widths nest) — numerically equivalent, not
+ *     bit-identical to 0; a property of the network's channel counts, never of the batch;
  *   "graph" (0 / 1): replay whole U-Net runs as captured hipGraphs (bit-identical: the same kernels with the same arguments);
  *   "igemm_exp": experimental kernel paths of the current round (0 = shipped). */
 int dm_set_option(const char* name, int value);

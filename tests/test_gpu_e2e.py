@@ -975,3 +975,33 @@ def test_gn_epi_option_end_to_end(engine, h, w, n_draws):
     print(f"gn_epi 0 vs 1 @{h}x{w}: loss rel-L2 {rel:.2e}")
     assert rel < 2.5e-3, rel
     assert not torch.equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("h,w,n_draws", [(64, 64, 4), (16, 24, 3)])
+def test_gn_skip_option_end_to_end(engine, h, w, n_draws):
+    """Option "gn_skip" (r05): the up path's norm1 over cat([x, skip]) merges the skip's GroupNorm sums kept from the down path instead of
+    reading the skip again.  Loss grids on / off agree to a re-ordering of the statistics' sums; with the option on the shared-draw path
+    (the skip's sums taken once per draw) equals the tiled batch bit for bit, and a draw's bits do not depend on the batch."""
+    lib = engine.lib
+    x, eps, t, c = _inputs(h, w, n_draws, flow="f32")
+    dev = engine.device
+    xd, ed, td = x.to(dev), eps.to(dev), t.to(dev)
+    engine.set_prompts(c)
+    nb, tb, cc, slots = _tile(eps, t, c)
+    out = {}
+    try:
+        for v in (1, 0):
+            assert lib.dm_set_option(b"gn_skip", v) == 0
+            out[v] = engine.score_conds(xd, ed, td, 2, latent_dtype=torch.float32).clone()
+        assert lib.dm_set_option(b"gn_skip", 1) == 0
+        one = engine.score_conds(xd, ed[:1], td[:1], 2, latent_dtype=torch.float32).clone()
+        tiled = engine.score(x, nb, tb, slots, latent_dtype=torch.float32).clone()
+    finally:
+        lib.dm_set_option(b"gn_skip", 1)
+    n = eps.shape[0]
+    assert torch.equal(one[0], out[1][0]) and torch.equal(one[1], out[1][n]), "a draw's loss depends on the batch with gn_skip on"
+    assert torch.equal(tiled.to(out[1].device), out[1]), "shared-draw path and tiled batch differ with gn_skip on"
+    rel = ((out[0] - out[1]).norm() / out[1].norm()).item()
+    print(f"gn_skip 0 vs 1 @{h}x{w}: loss rel-L2 {rel:.2e}")
+    assert rel < 2.5e-3, rel
+    assert not torch.equal(out[0], out[1])
