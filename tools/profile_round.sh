@@ -20,7 +20,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
 done
 python tools/pmc_to_json.py $OUT 4 > $OUT/pmc.json    # a pass runs 4 steps: 1 warm-up + 1 timed + 2 of the grid-D2H leg
 # the graded line AFTER the counters: bench.py takes roofline.traffic from profiles/<tag>_pmc.json (the same library, the same box)
-mkdir -p profiles && cp $OUT/pmc.json profiles/${TAG}_pmc.json
+mkdir -p profiles && cp $OUT/pmc.json profiles/${TAG}_pmc.json && cp $OUT/pmc.json profiles/r05_end_pmc.json      # (bench.py reads the newest tag first)
 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2>> $OUT/bench.err
 # per-shape HBM traffic of the igemm family (cold caches per launch)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/pmcs_fetch -o pmc -- python tools/pmc_shapes.py run > /dev/null 2>&1
