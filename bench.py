@@ -51,6 +51,141 @@ PEAK_TFLOPS_F32 = 157.3                 # MI355X fp32 matrix (v_mfma_f32_*_f32: 
 STUB = os.environ.get("DM_BENCH_STUB", "0") not in ("", "0")     # CPU test of the launcher / gather path (gloo, no engine)
 
 
+class ClockSampler:
+    """Shader clock and socket power of this rank's GPU, sampled in a thread while the timed steps run (the chip sits
+    at its 1.4 kW cap and clocks ~2.0 GHz under this load, so a fraction of the NOMINAL 2.4 GHz peak mixes kernel inefficiency with
+    clock).  Sources, first that answers: amdsmi's gpu_metrics (current_gfxclk(s), current / average socket power), amdsmi's
+    clock_info(SYS) + power_info, the hwmon files under /sys/class/drm.  A box where none answers yields nulls and says why."""
+
+    def __init__(self, index: int = 0, period_s: float = 0.05):
+        import threading
+        self.index, self.period, self.samples, self.source, self.error = index, period_s, [], None, None
+        self._stop, self._thread, self._read = threading.Event(), None, None
+        self._pick_source()
+
+    @staticmethod
+    def _num(v):
+        try:
+            v = float(v)
+        except (TypeError, ValueError):
+            return None
+        return v if 0.0 < v < 60000.0 else None            # "N/A", 0 and the 0xFFFF placeholder are not readings
+
+    def _pick_source(self):
+        errs = []
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            h = hs[self.index if self.index < len(hs) else 0]
+
+            def metrics():
+                m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+                cl = [self._num(c) for c in (m.get("current_gfxclks") or [])]
+                cl = [c for c in cl if c is not None]
+                clk = sum(cl) / len(cl) if cl else self._num(m.get("current_gfxclk")) or self._num(m.get("average_gfxclk_frequency"))
+                pw = self._num(m.get("current_socket_power")) or self._num(m.get("average_socket_power"))
+                return clk, pw
+
+            def clock_power():
+                c = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.SYS)
+                w = amdsmi.amdsmi_get_power_info(h)
+                return (self._num(c.get("clk")) or self._num(c.get("cur_clk")),
+                        self._num(w.get("current_socket_power")) or self._num(w.get("average_socket_power")))
+            for name, fn in (("amdsmi.gpu_metrics", metrics), ("amdsmi.clock_info+power_info", clock_power)):
+                try:
+                    if fn()[0] is not None:
+                        self._read, self.source = fn, name
+                        return
+                    errs.append(f"{name}: no clock value")
+                except Exception as ex:                      # noqa: BLE001  (a missing reading must not cost the measurement)
+                    errs.append(f"{name}: {type(ex).__name__}")
+        except Exception as ex:                              # noqa: BLE001
+            errs.append(f"amdsmi: {type(ex).__name__}")
+        try:
+            import glob
+            cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+            hw = cards[self.index if self.index < len(cards) else 0]
+
+            def hwmon():
+                def rd(n):
+                    try:
+                        with open(os.path.join(hw, n)) as f:
+                            return float(f.read().strip())
+                    except Exception:                        # noqa: BLE001
+                        return None
+                f1, pw = rd("freq1_input"), rd("power1_input") or rd("power1_average")
+                return (self._num(f1 / 1e6) if f1 else None, self._num(pw / 1e6) if pw else None)
+            if hwmon()[0] is not None:
+                self._read, self.source = hwmon, "sysfs hwmon"
+                return
+            errs.append("hwmon: no freq1_input")
+        except Exception as ex:                              # noqa: BLE001
+            errs.append(f"hwmon: {type(ex).__name__}")
+        try:
+            import re
+            import shutil
+            exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+
+            def cli():                                         # slow (a process per sample): the last resort
+                txt = subprocess.run([exe, "-d", str(self.index), "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+                c = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", txt)
+                w = re.search(r"Socket Graphics Package Power \(W\):\s*([0-9.]+)", txt)
+                return (self._num(c.group(1)) if c else None, self._num(w.group(1)) if w else None)
+            if cli()[0] is not None:
+                self._read, self.source = cli, "rocm-smi --showclocks --showpower (one process per sample)"
+                return
+            errs.append("rocm-smi: no sclk line")
+        except Exception as ex:                              # noqa: BLE001
+            errs.append(f"rocm-smi: {type(ex).__name__}")
+        self.error = "; ".join(errs)
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                c, w = self._read()
+                if c is not None:
+                    self.samples.append((c, w))
+            except Exception:                                # noqa: BLE001
+                pass
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self._read is not None:
+            import threading
+            self.samples = []
+            self._stop.clear()
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self) -> dict:
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+            self._thread = None
+        cl = [c for c, _ in self.samples]
+        pw = [w for _, w in self.samples if w is not None]
+        if not cl:
+            return {"sclk_mhz_mean": None, "power_w_mean": None, "clock_samples": 0, "clock_source": self.source,
+                    "clock_note": self.error or "no sample fell inside the timed region"}
+        return {"sclk_mhz_mean": round(sum(cl) / len(cl), 1), "sclk_mhz_min": round(min(cl), 1), "sclk_mhz_max": round(max(cl), 1),
+                "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "power_w_max": round(max(pw), 1) if pw else None,
+                "clock_samples": len(cl), "clock_source": self.source}
+
+
+NOMINAL_SCLK_MHZ = 2400.0               # the clock PEAK_TFLOPS is quoted at (MI355X_MICROARCH.md: max clock 2400 MHz)
+
+
+def clock_normalised(smi: dict, achieved_tflops: float, peak_tflops: float) -> dict:
+    """`frac_at_sustained_clock` = achieved / (peak x mean sclk / 2400 MHz): the share of what the matrix cores can do at the clock the
+    chip actually held over the timed steps (beside `frac`, which prices against the nominal 2.4 GHz peak)."""
+    out = dict(smi)
+    clk = smi.get("sclk_mhz_mean")
+    out["peak_at_sustained_clock"] = round(peak_tflops * clk / NOMINAL_SCLK_MHZ, 1) if clk else None
+    out["frac_at_sustained_clock"] = round(achieved_tflops / (peak_tflops * clk / NOMINAL_SCLK_MHZ), 4) if clk else None
+    return out
+
+
 def _free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -64,6 +199,29 @@ def launch_ranks(args) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+def SLAB_PATH() -> str:
+    # one name per launch (the launcher's port is unique per run on this node): two benches on one node do not collide
+    return os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp",
+                        f"dm_bench_weights_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}.slab")
+
+
+def node_state_dict(rank: int, world: int, make=None):
+    """The synthetic fp16 U-Net weights of this run.  One rank: synthesised in place.  N ranks of a node: rank 0 synthesises once and
+    writes ONE 1.7 GB slab to /dev/shm, the others map it (same bytes by construction — the generator is a pure function of
+    (seed, name, index) — and 1/N of the host arithmetic and memory); removed again once every rank has loaded (main)."""
+    from diff_mining_amd import synth
+    import torch.distributed as dist
+    make = make or (lambda: synth.synth_state_dict(seed=0, dtype=np.float16))
+    if world == 1:
+        return make()
+    path = SLAB_PATH()
+    if rank == 0:
+        sd = make()
+        synth.save_slab(sd, path)
+    dist.barrier()
+    return sd if rank == 0 else synth.load_slab(path)
 
 
 def main():
@@ -119,14 +277,28 @@ def main():
 
     n_img = args.images
     per_img = N_DRAWS * N_COND
+    slab_check = None
     if STUB:
         eng, sd = None, None
+        if world > 1:
+            # the weight hand-off of the real path on a stand-in dict: rank 0 writes the slab, the others map it; every rank's bytes
+            # must be rank 0's (checked through the process group), and the slab must be gone afterwards
+            fake = node_state_dict(rank, world, make=lambda: {f"w{i}": (np.arange(1000 + 37 * i, dtype=np.float32) * (i + 1)).astype(np.float16).reshape(-1, 1)
+                                                              for i in range(5)})
+            ck = torch.tensor([float(sum(int(np.asarray(v).view(np.uint16).astype(np.int64).sum()) for v in fake.values()))], dtype=torch.float64)
+            allck = [torch.zeros_like(ck) for _ in range(world)]
+            dist.all_gather(allck, ck)
+            dist.barrier()
+            if rank == 0:
+                synth.remove_slab(SLAB_PATH())
+            slab_check = {"equal": all(a.item() == allck[0].item() for a in allck), "mapped": bool(rank == 0 or not fake["w0"].flags.writeable),
+                          "removed": not os.path.exists(SLAB_PATH())}
 
         def step():                       # stands in for the engine: rank-dependent fake T(x|c), same gather path
             return gather_scores(torch.arange(n_img, dtype=torch.float32) + 100.0 * rank, n_img * world, rank, world)
     else:
         from diff_mining_amd.engine import UNetEngine, UNetEngineF32
-        sd = synth.synth_state_dict(seed=0, dtype=np.float16)
+        sd = node_state_dict(rank, world)
         eng = UNetEngineF32(local_rank) if (args.workload == "dift" and args.dift_dtype == "f32") else UNetEngine(local_rank)
         eng.load_state_dict(sd)
         if args.workload != "typicality":
@@ -158,6 +330,10 @@ def main():
             last["grids"], last["loss"] = grids, scorer.last_loss32
             return gather_scores(scores, n_img * world, rank, world)     # world 1: the tensor itself (no kernel)
 
+    if world > 1 and not STUB:
+        dist.barrier()                     # every rank has copied its weights to its GPU: the node's slab in /dev/shm can go
+        if rank == 0:
+            synth.remove_slab(SLAB_PATH())
     if eng is not None and os.environ.get("DM_GRAPH", "0") not in ("", "0"):
         # hipGraph replay (diagnostic, with DM_BENCH_NOPROF=1: a replay carries no per-launch events): the legacy default
         # stream cannot be captured, so the steps run on a stream of their own
@@ -169,9 +345,12 @@ def main():
     if eng is not None:
         eng.prof_enable(os.environ.get("DM_BENCH_NOPROF", "0") in ("", "0"))     # DM_BENCH_NOPROF=1: cost of the per-launch events (diagnostic)
         eng.prof_read()
+    sampler = ClockSampler(local_rank) if (rank == 0 and not STUB) else None
     if world > 1:
         dist.barrier()
     sync()
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         all_scores = step()
@@ -179,6 +358,8 @@ def main():
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    smi = sampler.stop() if sampler else {"sclk_mhz_mean": None, "power_w_mean": None, "clock_samples": 0, "clock_source": None,
+                                           "clock_note": "stub run"}
     prof = eng.prof_read() if eng is not None else {"igemm_ms": 0.0, "igemm_flops": 0.0, "igemm_launches": 0,
                                                     "attn_ms": 0.0, "attn_flops": 0.0, "attn_launches": 0}
     if eng is not None:
@@ -262,7 +443,10 @@ def main():
                          "executed_tflop_per_step": round(executed / 1e12, 3),
                          "nominal_tflop_per_step": round(nominal / 1e12, 3),
                          "whole_path_tflops_nominal": round(nominal / step_s / 1e12, 2),
-                         "attention_tflops": round(at_tf, 2), "attention_ms_total": round(prof["attn_ms"], 3)},
+                         "attention_tflops": round(at_tf, 2), "attention_ms_total": round(prof["attn_ms"], 3),
+                         **clock_normalised(smi, ig_tf, PEAK_TFLOPS),
+                         "whole_path_frac_at_sustained_clock": (round(executed / step_s / 1e12 / (PEAK_TFLOPS * smi["sclk_mhz_mean"] / NOMINAL_SCLK_MHZ), 4)
+                                                                if smi.get("sclk_mhz_mean") else None)},
             "allgather_ms": None if ag_ms is None else round(ag_ms, 4),
             "grid_d2h": ("excluded from `value` (scores are reduced on the device)" if d2h is None else
                          {"in_value": False, "ms_per_step_with_fp16_grid_d2h": round(d2h * 1e3, 3),
@@ -277,7 +461,10 @@ def main():
             out["config"]["engine_options"] = get_options()
         out["roofline"]["traffic_recorded_from"] = TRAFFIC_SOURCE.get("file")
         if world > 1:
-            out["ranks_seen"] = dist.get_world_size()
+            # every rank's clock arrived through the all-gather above: a line for N GPUs is printed only if N ranks measured
+            if len(rank_ms) != args.gpus or dist.get_world_size() != args.gpus:
+                sys.exit(f"bench.py: {len(rank_ms)} rank timings / world size {dist.get_world_size()} for --gpus {args.gpus}; no line")
+            out["ranks_seen"] = len(rank_ms)
             out["backend"] = dist.get_backend()
             try:
                 out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if not STUB else None
@@ -287,6 +474,7 @@ def main():
                                        "all": [round(v, 3) for v in rank_ms]}
         if STUB:
             out["data"] = "stub (DM_BENCH_STUB=1: launcher / gather path only, no engine)"
+            out["weight_slab_check"] = slab_check
         net32 = None
         if world == 1 and not STUB and (not args.no_parity or not args.no_side):
             from diff_mining_amd.engine import UNetEngineF32
@@ -342,10 +530,6 @@ def single_image_call(eng, x0, embeds, ldt):
     res["note"] = ("one image per engine call, scores left on the device; the batched entry (`value`) rides 8 images per call. "
                    "N100 per 10 draws compares with `value`: the same engine batch (160 samples), one image's prompts")
     return res
-
-
-    if world > 1:
-        dist.destroy_process_group()
 
 
 def score_deviation(net, x0, eps, t, c, loss, n_img):
@@ -455,12 +639,15 @@ def side_workload(args, eng, dev, sd):
         step()
     eng.prof_enable(os.environ.get("DM_BENCH_NOPROF", "0") in ("", "0"))
     eng.prof_read()
+    sampler = ClockSampler(dev.index or 0)
     torch.cuda.synchronize()
+    sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    smi = sampler.stop()
     prof = eng.prof_read()
     eng.prof_enable(False)
     val = units * args.steps / dt
@@ -477,7 +664,8 @@ def side_workload(args, eng, dev, sd):
                          "launches": prof["igemm_launches"], "kernel_ms_total": round(prof["igemm_ms"], 3),
                          "attention_tflops": round(at_tf, 2), "attention_ms_total": round(prof["attn_ms"], 3),
                          "whole_path_tflops_nominal": round(val * flop / 1e12, 2),
-                         "whole_path_frac_nominal": round(val * flop / 1e12 / peak, 4)},
+                         "whole_path_frac_nominal": round(val * flop / 1e12 / peak, 4),
+                         **clock_normalised(smi, ig_tf, peak)},
             "out_shape": list(out.shape), "memory": eng.memory()}
     if args.workload == "dift":
         line["reference_dtype"] = "f32"

@@ -366,7 +366,12 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.q_mod > 0) {                       // only the generic and the 77-key kernels index Q modulo (cross-attention; handled above / below)
         switch (p.D) { case 40: return launch_t<40, 2>(p, s); case 80: return launch_t<80, 2>(p, s); case 160: return launch_t<160, 2>(p, s); default: return hipErrorInvalidValue; }
     }
-    if (pipe >= 4 && pipe != 9 && attention_pp_supports(p)) return launch_attention_pp(p, pipe, s);        // anti-phase wave sets (r05); 9 = the r04 dispatch (A/B)
+    // the anti-phase kernel everywhere it applies (A/B): 10 / 12 = three wave sets without / with static priorities; 9 = the r04 dispatch.
+    // set_option() admits no other value (a stray value used to select timing-only ablation instantiations)
+    if ((pipe == 10 || pipe == 12) && attention_pp_supports(p)) return launch_attention_pp(p, pipe, s);
+#ifdef DM_ATTN_PP_ABLATE
+    if (pipe >= 4 && pipe != 9 && attention_pp_supports(p)) return launch_attention_pp(p, pipe, s);        // debug library only
+#endif
     // default: the three-set anti-phase kernel where it measured faster (>= 8192 keys: the 128x128 level of a 1024-pixel image, -4...6 %
     // per launch; bit-identical to attn_pipe_kernel) and its 384-query blocks waste < 2 % of their rows; attn_pipe = 2 / 3 keep the r04 kernels
     if (pipe == 1 && p.Tk >= 8192 && attention_pp_supports(p) && (long long)((p.Tq + 383) / 384) * 384 * 50 <= 51LL * p.Tq)

@@ -374,13 +374,17 @@ static hipError_t launch_pp(const AttnParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-// variant (= option attn_pipe): 4 = two sets; 10 = three sets; 12 = three sets with static priorities (the one the dispatcher uses);
-// 14 / 15 = 4 / 10 with phase timers; 21... = timing-only ablations of 12
+// variant (= option attn_pipe): 10 = three sets; 12 = three sets with static priorities (the one the dispatcher uses from 8192 keys).
+// The product library holds these two only (r06: the two-set kernel measured -21 % and is gone; its record is DESIGN.md 4f and
+// profiles/r05_ab_attn_antiphase_variants.txt).  A build with -DDM_ATTN_PP_ABLATE (tools/ab_attn_pp.py's debug library) adds 4 = two
+// sets, 14 / 15 = phase timers and 21... = the timing-only ablations of 12, whose RESULTS ARE GARBAGE by construction.
 hipError_t launch_attention_pp(const AttnParams& p, int variant, hipStream_t s) {
     if (!attention_pp_supports(p)) return hipErrorInvalidValue;
     switch (variant) {
         case 10: return launch_pp<3, 0, 0>(p, s);
         case 12: return launch_pp<3, 2, 0>(p, s);
+#ifdef DM_ATTN_PP_ABLATE
+        case 4: return launch_pp<2, 0, 0>(p, s);
         case 14: return launch_pp<2, 0, 1>(p, s);
         case 15: return launch_pp<3, 0, 1>(p, s);
         case 21: return launch_pp<3, 2, 0, 1>(p, s);       // ablations (timing only)
@@ -395,7 +399,8 @@ hipError_t launch_attention_pp(const AttnParams& p, int variant, hipStream_t s) 
         case 40: return launch_pp<3, 2, 0, 20>(p, s);      // no fragment reads, no max
         case 32: return launch_pp<3, 2, 0, 12>(p, s);      // no fragment reads, no DMA
         case 51: return launch_pp<3, 2, 0, 31>(p, s);      // barriers only
-        default: return launch_pp<2, 0, 0>(p, s);
+#endif
+        default: return hipErrorInvalidValue;
     }
 }
 

@@ -60,8 +60,9 @@ inline void launch_timed(F kernel, const dim3& grid, const dim3& block, size_t l
 
 // Runtime switches (A/B measurements; every default is the measured best).  Initialised from the environment variable of
 // the same name in upper case with a DM_ prefix (DM_IGEMM_PERSIST=0 ...), changeable through dm_set_option().
-enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_TAP_REUSE, OPT_UP_FOLD, OPT_Q_ONCE, OPT_ATTN2_FUSE, OPT_GN_EPI, OPT_CONV_OUT_ROWS, OPT_GN_SKIP, OPT_COUNT };
+enum Option { OPT_IGEMM_BIG = 0, OPT_IGEMM_SPLITK, OPT_LN_FOLD, OPT_ATTN_PIPE, OPT_IGEMM_TAIL, OPT_ATTN_CROSS, OPT_LN_STATS_G, OPT_IGEMM_EXP, OPT_LN_INKERNEL, OPT_GRAPH, OPT_GN_FOLD, OPT_SC_FOLD, OPT_FF_FOLD, OPT_TAP_REUSE, OPT_UP_FOLD, OPT_Q_ONCE, OPT_GN_EPI, OPT_CONV_OUT_ROWS, OPT_GN_SKIP, OPT_COUNT };
 int option(Option o);                       // engine.hip
+unsigned options_epoch();                   // engine.hip: changes with every set_option() that changed a value
 int set_option(const char* name, int value);   // 0 on success
 int get_option(const char* name, int* value);  // 0 on success
 
@@ -120,6 +121,10 @@ struct IGemmParams {
     // input): [M / 64][Cout] fp32, entry (b, 2 k + {0, 1}) = (sum, sum of squares) of output channels 2 k, 2 k + 1 over rows
     // 64 b .. 64 b + 63, in the arithmetic gn_blocks_kernel (norm.hip) defines.  Needs M % 64 == 0; nullptr = not wanted.
     float* gn_blocks = nullptr;
+    // host-side only (launch rules; no kernel reads it): the layer HAS a time embedding.  The engine's dry run walks the schedule with
+    // data pointers that are bare arena offsets (temb may be null there for a real layer), and the rules that pick an allocation path
+    // (igemm_gn_layer, tap_reuse_layer) must answer the same in both walks.  Last member: no other field moves.
+    bool has_temb = false;
 };
 constexpr int IGEMM_TILE_CTR_INTS = 8 * 32 + 32;
 // LayerNorm statistics taken inside the folded GEMM are one-pass fp32 sums (var = E[x^2] - mean^2): with |mean| >> std the
@@ -194,16 +199,6 @@ struct AttnParams {
     float scale;
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
-// LayerNorm2 -> attn2.to_q folded into the 77-key cross-attention (attention_crossq.hip, head_dim 40): the queries are projected inside
-// the attention kernel from the token matrix X [B][Tq][ldx] with the LayerNorm-folded weight Wq = W diag(gamma) [C][C] and its epilogue
-// vectors (pack_ln_fold: ln_s[c] = sum_k Wq[c][k], ln_t[c] = sum_k W[c][k] beta[k]); AttnParams::Q / ldq / bsq are unused.
-struct CrossQParams {
-    const f16* X = nullptr; int ldx = 0; long long bsx = 0;
-    const f16* Wq = nullptr; const float* ln_s = nullptr; const float* ln_t = nullptr;
-    float ln_eps = 1e-5f;
-};
-bool attention_crossq_supports(const AttnParams& p, const CrossQParams& f);
-hipError_t launch_attention_crossq(const AttnParams& p, const CrossQParams& f, hipStream_t s);
 
 // ---- K6: GroupNorm statistics + apply(+SiLU); K7: LayerNorm ----------------------------------
 // x = concat(X[...,C1], X2[...,C-C1]) NHWC.  Two kernels: per-(sample, pixel chunk, group) fp64 partial sums (one read of x),

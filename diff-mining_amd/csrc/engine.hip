@@ -148,6 +148,7 @@ struct dm_engine {
     std::map<std::vector<long long>, size_t> arena_need;   // exact peak per (schedule, shape) key: the dry run is done once
     long long n_device_allocs = 0;                         // every hipMalloc this engine ever did (dm_engine_stats)
     long long n_dry_runs = 0;
+    unsigned opt_epoch = 0;                                // options_epoch() the two caches below / above belong to
     int kv_capacity = 0;                                   // prompts the K/V cache buffers hold
     int* tile_ctr = nullptr;                               // tile hand-out counters of the persistent igemm (this engine's own)
     void* slot_scratch = nullptr; size_t slot_scratch_cap = 0;   // chunk-local prompt-slot tables of dm_score_conds_slots
@@ -546,7 +547,7 @@ struct Fwd {
     int igemm(const ConvW& cv, int mode, const Tensor& x, const Tensor* x2, int OH, int OW,
               const f16* temb, int temb_ld, const Tensor* res, int epi, Tensor* y, const LnFold* ln = nullptr,
               const float* ln_stats = nullptr, const Tensor* x3 = nullptr, const Tensor* x4 = nullptr, float* gn_blocks = nullptr,
-              int* gn_rows = nullptr) {
+              int* gn_rows = nullptr, bool has_temb = false) {
         const int cin = x.C + (x2 ? x2->C : 0);
         if (cin != cv.cin) DM_FAIL(e, "igemm: channel mismatch %d vs %d", cin, cv.cin);
         const int cout_y = (epi == EPI_GEGLU) ? cv.cout / 2 : cv.cout;
@@ -558,6 +559,7 @@ struct Fwd {
         p.res = res ? res->p : nullptr; p.Y = y->p;
         p.Cout = cv.cout; p.Cin = cin; p.C1 = x.C;
         p.mode = mode; p.epi = epi; p.ldy = cout_y; p.ldres = res ? res->C : 0; p.temb_ld = temb_ld;
+        p.has_temb = has_temb || temb != nullptr;
         if (mode == IG_DENSE) { p.M = (int)x.rows(); p.H = 1; p.W = p.M; p.OH = 1; p.OW = p.M; }
         else { p.M = x.N * OH * OW; p.H = x.H; p.W = x.W; p.OH = OH; p.OW = OW; }
         if (ln) { p.ln_stats = ln_stats; p.ln_s = ln->s; p.ln_t = ln->t; p.ln_eps = LN_EPS; }
@@ -730,20 +732,25 @@ struct Fwd {
         return 0;
     }
 
-    int resnet(const ResW& r, const Tensor& x, const Tensor* x2, const f16* tproj, Tensor* out) {
+    // `tproj`: the stacked time-embedding projections (the U-Net's ResNets) or nullptr (the VAE's).  A Tensor*, not its data pointer:
+    // in the dry run every data pointer is arena offset + 0, so "is there a time embedding" must not be read off a pointer
+    int resnet(const ResW& r, const Tensor& x, const Tensor* x2, const Tensor* tproj, Tensor* out) {
         Tensor n1, h1, n2, sc;
+        const bool has_temb = tproj != nullptr;
+        const f16* temb = has_temb ? tproj->p + r.temb_off : nullptr;
         DM_TRY(groupnorm(r.n1, x, x2, res_eps, true, &n1));
         // norm2's statistics: block sums out of conv1's epilogue where the persistent kernels run it, from h1 where they do not
-        if (gn_blocks_ok(x.H * x.W, r.c1.cout)) {
+        if (has_temb && gn_blocks_ok(x.H * x.W, r.c1.cout)) {       // (only time-embedding layers ever emit block sums: igemm_gn_layer)
             size_t boff; void* bp; int rows_done = 0;
             DM_TRY(alloc_raw((size_t)x.N * (x.H * x.W / 64) * r.c1.cout * sizeof(float), &boff, &bp));
-            DM_TRY(igemm(r.c1, IG_CONV3, n1, nullptr, x.H, x.W, tproj ? tproj + r.temb_off : nullptr, e->tproj_total, nullptr, EPI_PLAIN, &h1,
-                         nullptr, nullptr, nullptr, nullptr, (float*)bp, &rows_done));
+            DM_TRY(igemm(r.c1, IG_CONV3, n1, nullptr, x.H, x.W, temb, e->tproj_total, nullptr, EPI_PLAIN, &h1,
+                         nullptr, nullptr, nullptr, nullptr, (float*)bp, &rows_done, has_temb));
             free(n1);
             if (rows_done < 0) { free_raw(boff); DM_TRY(groupnorm(r.n2, h1, nullptr, res_eps, true, &n2)); }
             else { DM_TRY(groupnorm_blocks(r.n2, h1, (float*)bp, rows_done, res_eps, true, &n2)); free_raw(boff); }
         } else {
-            DM_TRY(igemm(r.c1, IG_CONV3, n1, nullptr, x.H, x.W, tproj ? tproj + r.temb_off : nullptr, e->tproj_total, nullptr, EPI_PLAIN, &h1));
+            DM_TRY(igemm(r.c1, IG_CONV3, n1, nullptr, x.H, x.W, temb, e->tproj_total, nullptr, EPI_PLAIN, &h1,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, has_temb));
             free(n1);
             DM_TRY(groupnorm(r.n2, h1, nullptr, res_eps, true, &n2));
         }
@@ -826,38 +833,24 @@ struct Fwd {
         const int C = t.c, T = x.H * x.W, B = x.N * rep;
         if (rep > 1 && !qU) DM_FAIL(e, "transformer_post: shared residual rows need the shared queries");
         Tensor ln, a, q, t2, ff, t3;
-        // LN2 -> to_q inside the cross-attention kernel (attention_crossq.hip): the q tensor is never written or read.  A property of
-        // the layer (head_dim 40, >= 256 tokens per sample, folded LayerNorm), never of the batch
-        const bool fuse_q = rep == 1 && option(OPT_ATTN2_FUSE) != 0 && ln_fold_enabled() && C == 320 && T >= 256 && option(OPT_ATTN_CROSS) != 0;
-        const Tensor* xq = &t1;             // the token rows the queries come from
-        if (qU && !fuse_q) q = *qU;
-        else if (!fuse_q) DM_TRY(cross_q(t, t1, &q));
+        if (qU) q = *qU;
+        else DM_TRY(cross_q(t, t1, &q));
         DM_TRY(alloc(&a, B, x.H, x.W, C));
         if (!dry) {
             const f16* kv = e->kv_cache[t.layer];
             AttnParams ap;
-            ap.Q = fuse_q ? nullptr : q.p; ap.K = kv; ap.V = kv + C; ap.O = a.p;
+            ap.Q = q.p; ap.K = kv; ap.V = kv + C; ap.O = a.p;
             ap.ldq = C; ap.ldk = 2 * C; ap.ldv = 2 * C; ap.ldo = C;
             ap.bsq = (long long)T * C; ap.bsk = (long long)CTX_LEN * 2 * C; ap.bsv = ap.bsk; ap.bso = (long long)T * C;
             ap.kv_slot = slot_div > 0 ? nullptr : slots; ap.slot_div = slot_div; ap.n_slots = e->n_prompts;
-            ap.q_mod = (qU && !fuse_q) ? q_mod : 0;
+            ap.q_mod = qU ? q_mod : 0;
             ap.B = B; ap.heads = HEADS; ap.Tq = T; ap.Tk = CTX_LEN; ap.D = C / HEADS;
             ap.scale = 1.0f / sqrtf((float)ap.D);
-            if (fuse_q) {
-                CrossQParams fq;
-                fq.X = xq->p; fq.ldx = C; fq.bsx = (long long)T * C;
-                fq.Wq = t.q2_ln.w.w; fq.ln_s = t.q2_ln.s; fq.ln_t = t.q2_ln.t; fq.ln_eps = LN_EPS;
-                DM_TRY(prof_begin(1, 4.0 * B * HEADS * (double)T * CTX_LEN * ap.D + 2.0 * B * (double)T * C * C, B * T, CTX_LEN, ap.D, 102));
-                DM_HIP(e, launch_attention_crossq(ap, fq, s));
-                DM_TRY(prof_end());
-            } else {
-                DM_TRY(prof_begin(1, 4.0 * B * HEADS * (double)T * CTX_LEN * ap.D, B * T, CTX_LEN, ap.D, 101));
-                DM_HIP(e, launch_attention(ap, s));
-                DM_TRY(prof_end());
-            }
+            DM_TRY(prof_begin(1, 4.0 * B * HEADS * (double)T * CTX_LEN * ap.D, B * T, CTX_LEN, ap.D, 101));
+            DM_HIP(e, launch_attention(ap, s));
+            DM_TRY(prof_end());
         }
-        if (fuse_q) { if (qU) free(*qU); }
-        else free(q);
+        free(q);
         if (rep > 1) {
             DM_TRY(alloc(&t2, B, x.H, x.W, C));
             for (int k = 0; k < rep; ++k) {
@@ -999,13 +992,13 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
         const DownBlockW& d = e->down[0];
         Tensor rU, t1U, rB, t1B, a;
         // the cross-attention queries of the first transformer depend on the draw only: projected once per draw, read modulo U
-        const bool q_once = option(OPT_Q_ONCE) != 0 && !(option(OPT_ATTN2_FUSE) != 0 && Fwd::ln_fold_enabled() && d.tf[0].c == 320 && A.H * A.W >= 256 && option(OPT_ATTN_CROSS) != 0);
+        const bool q_once = option(OPT_Q_ONCE) != 0;
         // ... and with the queries shared, the only other readers of the stacked ResNet output and of t1 are two residual reads:
         // those GEMMs can run once per prompt block against the per-draw rows, and two stacking copies disappear (q_once = 2; measured +-0:
         // 139.00 vs 139.05 ms/step over three alternating pairs, profiles/r05_ab_q_once.txt — the copies cost what the extra launches do)
         const bool share = q_once && option(OPT_Q_ONCE) == 2;
         if (share) {
-            DM_TRY(F.resnet(d.res[0], h, nullptr, tprojU.p, &rU));
+            DM_TRY(F.resnet(d.res[0], h, nullptr, &tprojU, &rU));
             DM_TRY(F.transformer_pre(d.tf[0], rU, &t1U));
             Tensor qU;
             DM_TRY(F.cross_q(d.tf[0], t1U, &qU));
@@ -1015,7 +1008,7 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
         } else {
             DM_TRY(F.alloc(&rB, U * NC, A.H, A.W, d.res[0].cout));
             rU = Fwd::first_slot(rB, NC);
-            DM_TRY(F.resnet(d.res[0], h, nullptr, tprojU.p, &rU));
+            DM_TRY(F.resnet(d.res[0], h, nullptr, &tprojU, &rU));
             DM_TRY(F.alloc(&t1B, U * NC, A.H, A.W, d.tf[0].c));
             t1U = Fwd::first_slot(t1B, NC);
             DM_TRY(F.transformer_pre(d.tf[0], rU, &t1U));
@@ -1041,7 +1034,7 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
         const DownBlockW& d = e->down[i];
         for (int j = (i == 0 ? j_start : 0); j < LAYERS; ++j) {
             Tensor r;
-            DM_TRY(F.resnet(d.res[j], cur, nullptr, tproj.p, &r));
+            DM_TRY(F.resnet(d.res[j], cur, nullptr, &tproj, &r));
             if (d.attn) {
                 Tensor a;
                 DM_TRY(F.transformer(d.tf[j], r, A.slots, &a));
@@ -1062,10 +1055,10 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
     }
     // ---- mid ------------------------------------------------------------------------------------
     Tensor m0, m1, m2;
-    DM_TRY(F.resnet(e->mid_res[0], cur, nullptr, tproj.p, &m0));
+    DM_TRY(F.resnet(e->mid_res[0], cur, nullptr, &tproj, &m0));
     DM_TRY(F.transformer(e->mid_tf, m0, A.slots, &m1));
     F.free(m0);
-    DM_TRY(F.resnet(e->mid_res[1], m1, nullptr, tproj.p, &m2));
+    DM_TRY(F.resnet(e->mid_res[1], m1, nullptr, &tproj, &m2));
     F.free(m1);
     cur = m2;                       // owned from here on
     // ---- up -------------------------------------------------------------------------------------
@@ -1076,7 +1069,7 @@ int run_forward(dm_engine* e, const FwdArgs& A, hipStream_t s, bool dry) {
         for (int j = 0; j < LAYERS + 1; ++j) {
             Tensor skip = skips.back(); skips.pop_back();
             Tensor r;
-            DM_TRY(F.resnet(u.res[j], cur, &skip, tproj.p, &r));
+            DM_TRY(F.resnet(u.res[j], cur, &skip, &tproj, &r));
             F.free(cur); F.free(skip); F.free_skip_stat(skip.sid);
             if (u.attn) {
                 Tensor a;
@@ -1234,6 +1227,13 @@ void drop_graphs(dm_engine* e) {
 template <class RunFn>
 int ensure_arena_for(dm_engine* e, hipStream_t s, const std::vector<long long>& key, RunFn run_dry) {
     size_t need;
+    // a switch changed since the cached peaks / captured graphs were made: not every switch is part of every key (tap_reuse and gn_epi
+    // choose allocation paths too), so both caches start over — correct for any switch, and set_option is not a steady-state call
+    if (e->opt_epoch != options_epoch()) {
+        if (!e->graphs.empty()) { DM_HIP(e, hipStreamSynchronize(s)); drop_graphs(e); }
+        e->arena_need.clear(); e->graph_seen.clear();
+        e->opt_epoch = options_epoch();
+    }
     auto it = e->arena_need.find(key);
     if (it != e->arena_need.end()) need = it->second;
     else {
@@ -1262,7 +1262,7 @@ int ensure_arena_for(dm_engine* e, hipStream_t s, const std::vector<long long>& 
 
 std::vector<long long> fwd_key(const FwdArgs& A) {
     return {0, A.B, A.H, A.W, A.n_cond, A.up_ft_index, A.add_noise ? 1 : 0, A.loss ? 1 : 0, A.pred ? 1 : 0, A.feat ? 1 : 0,
-            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD), option(OPT_FF_FOLD), option(OPT_UP_FOLD), option(OPT_Q_ONCE), option(OPT_ATTN2_FUSE), option(OPT_GN_EPI), option(OPT_CONV_OUT_ROWS), option(OPT_GN_SKIP)};
+            A.feat_mean ? 1 : 0, option(OPT_LN_FOLD), option(OPT_IGEMM_SPLITK), option(OPT_LN_INKERNEL), option(OPT_GN_FOLD), option(OPT_SC_FOLD), option(OPT_FF_FOLD), option(OPT_UP_FOLD), option(OPT_Q_ONCE), option(OPT_GN_EPI), option(OPT_CONV_OUT_ROWS), option(OPT_GN_SKIP)};
 }
 
 int ensure_arena(dm_engine* e, const FwdArgs& A, hipStream_t s) {
@@ -1348,21 +1348,44 @@ namespace {
 struct OptDef { const char* name; const char* env; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"igemm_big", "DM_IGEMM_BIG", -1}, {"igemm_splitk", "DM_IGEMM_SPLITK", 1},
-    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1}, {"tap_reuse", "DM_TAP_REUSE", 1}, {"up_fold", "DM_UP_FOLD", 1}, {"q_once", "DM_Q_ONCE", 1}, {"attn2_fuse", "DM_ATTN2_FUSE", 0}, {"gn_epi", "DM_GN_EPI", 1}, {"conv_out_rows", "DM_CONV_OUT_ROWS", 1}, {"gn_skip", "DM_GN_SKIP", 1},
+    {"ln_fold", "DM_LN_FOLD", 1}, {"attn_pipe", "DM_ATTN_PIPE", 1}, {"igemm_tail", "DM_IGEMM_TAIL", 1}, {"attn_cross", "DM_ATTN_CROSS", 1}, {"ln_stats_g", "DM_LN_STATS_G", 1}, {"igemm_exp", "DM_IGEMM_EXP", 0}, {"ln_inkernel", "DM_LN_INKERNEL", 1}, {"graph", "DM_GRAPH", 0}, {"gn_fold", "DM_GN_FOLD", 1}, {"sc_fold", "DM_SC_FOLD", 1}, {"ff_fold", "DM_FF_FOLD", 1}, {"tap_reuse", "DM_TAP_REUSE", 1}, {"up_fold", "DM_UP_FOLD", 1}, {"q_once", "DM_Q_ONCE", 1}, {"gn_epi", "DM_GN_EPI", 1}, {"conv_out_rows", "DM_CONV_OUT_ROWS", 1}, {"gn_skip", "DM_GN_SKIP", 1},
 };
+// The values a switch may take: attn_pipe selects kernels by number, and a number outside the list used to fall through to
+// whatever instantiation the launcher's switch held (timing-only ablations included).  Every other switch is 0 / 1 / 2 / -1 by meaning.
+static bool option_value_ok(int i, int value) {
+    if (i == OPT_ATTN_PIPE) {
+#ifdef DM_ATTN_PP_ABLATE
+        return value >= 0 && value <= 51;
+#else
+        return value == 0 || value == 1 || value == 2 || value == 3 || value == 9 || value == 10 || value == 12;
+#endif
+    }
+    if (i == OPT_IGEMM_BIG) return value >= -1 && value <= 2;
+    return value >= 0 && value <= 2;
+}
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<int> g_opt_init{0};
+std::atomic<unsigned> g_opt_epoch{1};      // bumped by every set_option(): engines drop cached arena peaks and captured graphs
 void opts_init() {
     if (g_opt_init.load() == 2) return;
     int expect = 0;
     if (g_opt_init.compare_exchange_strong(expect, 1)) {
-        for (int i = 0; i < OPT_COUNT; ++i) { const char* e = getenv(kOpts[i].env); g_opt[i] = e ? atoi(e) : kOpts[i].def; }
+        for (int i = 0; i < OPT_COUNT; ++i) {
+            const char* e = getenv(kOpts[i].env);
+            int v = e ? atoi(e) : kOpts[i].def;
+            if (e && !option_value_ok(i, v)) {              // an environment value outside the switch's set: say so and keep the default
+                fprintf(stderr, "dm_engine: %s=%s is not a value of option \"%s\"; using the default %d\n", kOpts[i].env, e, kOpts[i].name, kOpts[i].def);
+                v = kOpts[i].def;
+            }
+            g_opt[i] = v;
+        }
         g_opt_init = 2;
     } else while (g_opt_init.load() != 2) {}
 }
 }  // namespace
 
 int option(Option o) { opts_init(); return g_opt[o].load(std::memory_order_relaxed); }
+unsigned options_epoch() { return g_opt_epoch.load(std::memory_order_relaxed); }
 
 void fold_upconv_weights(const f16* w, int cout, int cin, f16* out) {
     // parity class p (0 / 1) of an output coordinate, 2x2 tap a (0 / 1): the 3x3 taps d whose up-sampled coordinate 2 y + p + d - 1
@@ -1392,7 +1415,11 @@ int get_option(const char* name, int* value) {
 int set_option(const char* name, int value) {
     opts_init();
     for (int i = 0; i < OPT_COUNT; ++i)
-        if (name && !strcmp(name, kOpts[i].name)) { g_opt[i] = value; return 0; }
+        if (name && !strcmp(name, kOpts[i].name)) {
+            if (!option_value_ok(i, value)) return 2;          // known switch, value outside its documented set: refused, nothing changes
+            if (g_opt[i].exchange(value) != value) g_opt_epoch.fetch_add(1);
+            return 0;
+        }
     return 1;
 }
 
@@ -2228,19 +2255,6 @@ int dm_op_attention(void* stream, const void* Q, const void* K, const void* V, v
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.bsq = bsq; a.bsk = bsk; a.bsv = bsv; a.bso = bso;
     a.kv_slot = kv_slot; a.slot_div = 0; a.B = B; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.D = D; a.scale = scale;
     return launch_attention(a, (hipStream_t)stream) == hipSuccess ? 0 : 1;
-}
-
-int dm_op_cross_attention_q(void* stream, const void* X, const void* Wq_folded, const float* ln_s, const float* ln_t, float ln_eps,
-                            const void* K, const void* V, void* O, int ldk, int ldv, int64_t bsk, int64_t bsv, const int32_t* kv_slot,
-                            int B, int heads, int Tq, int Tk, int D, float scale) {
-    AttnParams a;
-    const int C = heads * D;
-    a.Q = nullptr; a.K = (const f16*)K; a.V = (const f16*)V; a.O = (f16*)O;
-    a.ldq = C; a.ldk = ldk; a.ldv = ldv; a.ldo = C; a.bsq = (long long)Tq * C; a.bsk = bsk; a.bsv = bsv; a.bso = (long long)Tq * C;
-    a.kv_slot = kv_slot; a.slot_div = 0; a.B = B; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.D = D; a.scale = scale;
-    CrossQParams f;
-    f.X = (const f16*)X; f.ldx = C; f.bsx = (long long)Tq * C; f.Wq = (const f16*)Wq_folded; f.ln_s = ln_s; f.ln_t = ln_t; f.ln_eps = ln_eps;
-    return launch_attention_crossq(a, f, (hipStream_t)stream) == hipSuccess ? 0 : 1;
 }
 
 int dm_op_groupnorm(void* stream, const void* X, const void* X2, int N, int HW, int C, int C1, int G, float eps,

@@ -187,7 +187,7 @@ static bool tap_reuse_layer(const IGemmParams& p) {
     const int on = option(OPT_TAP_REUSE);
     if (on == 0 || !igemm_ko_layer(p)) return false;
     if (p.mode == IG_CONV3_UP) return on == 2 && p.OW == 64;           // Upsample2D.conv onto 64 pixels: built, +3 % (1.33 PFLOP/s without it: its taps share source pixels), A/B only
-    return on == 2 || p.OW >= 64 || (p.OW == 32 && p.temb != nullptr);       // (128 wide: the first level of a 1024-pixel image, the X-ray configuration)
+    return on == 2 || p.OW >= 64 || (p.OW == 32 && (p.temb != nullptr || p.has_temb));       // (128 wide: the first level of a 1024-pixel image, the X-ray configuration)
 }
 
 static hipError_t launch_small(const IGemmParams& p, hipStream_t s) {
@@ -204,7 +204,7 @@ static hipError_t launch_small(const IGemmParams& p, hipStream_t s) {
 // M: the caller keeps the r04 statistics pass for the layers that never can (the 128- / 32- / 16-pixel tap-reuse kernels, split-K
 // layers, channel counts the persistent tile does not take) — one launch instead of two there.
 bool igemm_gn_layer(const IGemmParams& p) {
-    if (!p.temb || p.epi != EPI_PLAIN || p.w_sample_stride || p.ln_s || p.X3 || (p.OH * p.OW) % 64 != 0) return false;
+    if (!(p.temb || p.has_temb) || p.epi != EPI_PLAIN || p.w_sample_stride || p.ln_s || p.X3 || (p.OH * p.OW) % 64 != 0) return false;
     if (p.Cout % 320 != 0 || p.mode == IG_CONV3_S2P0 || p.Cin % BK != 0 || p.C1 % BK != 0) return false;
     if (igemm_splitk_parts(p, p.OH * p.OW) > 1) return false;
     if (tap_reuse_layer(p) && p.OW != 64) return false;

@@ -22,7 +22,7 @@ SYMBOLS = [
     "dm_engine_destroy", "dm_last_error", "dm_engine_load_weight", "dm_engine_finalize",
     "dm_engine_set_prompts", "dm_score", "dm_score_conds", "dm_score_conds_slots", "dm_unet_forward", "dm_dift", "dm_dift_shape",
     "dm_reduce_typicality", "dm_typicality_image", "dm_prof_enable", "dm_prof_read", "dm_engine_memory",
-    "dm_op_igemm", "dm_op_attention", "dm_op_cross_attention_q", "dm_op_groupnorm", "dm_op_layernorm",
+    "dm_op_igemm", "dm_op_attention", "dm_op_groupnorm", "dm_op_layernorm",
     "dm_op_conv_temb_gn_blocks", "dm_op_gn_blocks", "dm_op_groupnorm_blocks", "dm_op_conv_out",
     "dm_engine_load_vae_weight", "dm_engine_finalize_vae", "dm_vae_encode", "dm_op_attention512", "dm_patch_embed",
     "dm_engine_load_clip_weight", "dm_engine_finalize_clip", "dm_clip_encode", "dm_op_igemm_splitk",
@@ -36,7 +36,7 @@ SYMBOLS = [
 ]
 
 
-def get_options(names=("ln_fold", "gn_fold", "ff_fold", "sc_fold", "up_fold", "tap_reuse", "ln_inkernel", "igemm_splitk", "q_once", "attn2_fuse", "gn_epi", "conv_out_rows", "gn_skip", "attn_pipe", "graph")) -> dict:
+def get_options(names=("ln_fold", "gn_fold", "ff_fold", "sc_fold", "up_fold", "tap_reuse", "ln_inkernel", "igemm_splitk", "q_once", "gn_epi", "conv_out_rows", "gn_skip", "attn_pipe", "graph")) -> dict:
     """Current values of the library's runtime switches (dm_get_option); {} with a library that predates the getter."""
     lib = load_library()
     out = {}
@@ -96,7 +96,6 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_engine_memory.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.dm_op_igemm.argtypes = [vp] * 8 + [i32] * 11
     lib.dm_op_attention.argtypes = [vp] * 5 + [i32] * 4 + [i64] * 4 + [vp] + [i32] * 5 + [C.c_float]
-    lib.dm_op_cross_attention_q.argtypes = [vp] * 5 + [C.c_float] + [vp] * 3 + [i32] * 2 + [i64] * 2 + [vp] + [i32] * 5 + [C.c_float]
     lib.dm_op_groupnorm.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, C.c_float, vp, vp, i32, vp]
     if hasattr(lib, "dm_op_conv_out"):
         lib.dm_op_conv_out.argtypes = [vp] * 5 + [i32] * 4 + [vp, vp]
@@ -717,15 +716,24 @@ class UNetEngineF32:
                                           C.c_void_p(out.data_ptr()), self._stream()), "dm_f32_score")
         return out
 
-    def score_conds(self, x, eps, t, n_cond: int, x_index=None):
-        """Each of the U draws (x, eps, t) under prompts 0..n_cond-1 -> loss [n_cond*U,4,h,w] fp32, cond-major (row k*U+i), like
-        `UNetEngine.score_conds`."""
+    def score_conds(self, x, eps, t, n_cond: int, x_index=None, latent_dtype=None, slot_table=None):
+        """Each of the U draws (x, eps, t) under n_cond prompts -> loss [n_cond*U,4,h,w] fp32, cond-major (row k*U+i), like
+        `UNetEngine.score_conds` — the same keywords, so `TypicalityScorer.compute_losses_batch` / `compute_submission` run on either
+        engine: `slot_table` [n_cond, U] = the registered prompt of draw i in its k-th condition (default: prompt k for
+        every draw); `latent_dtype` must be None or float32 (this net has one dtype flow: everything fp32)."""
         torch = self._torch
+        if latent_dtype not in (None, torch.float32):
+            raise ValueError("UNetEngineF32.score_conds: the fp32 net has no fp16 latent flow (latent_dtype must be None or torch.float32)")
         U = eps.shape[0]
         t = torch.as_tensor(t).reshape(-1)
         xi = None if x_index is None else torch.as_tensor(x_index).reshape(-1).repeat(n_cond)
         xx = x if (x.shape[0] == 1 or x_index is not None) else x.repeat(n_cond, 1, 1, 1)
-        slots = torch.arange(n_cond, dtype=torch.int32).repeat_interleave(U)
+        if slot_table is not None:
+            slots = torch.as_tensor(slot_table).to(torch.int32).reshape(-1)
+            if slots.numel() != n_cond * U:
+                raise ValueError(f"slot_table must hold n_cond * U = {n_cond * U} entries, got {slots.numel()}")
+        else:
+            slots = torch.arange(n_cond, dtype=torch.int32).repeat_interleave(U)
         return self.score(xx, eps.repeat(n_cond, 1, 1, 1), t.repeat(n_cond), slots, x_index=xi)
 
     def dift(self, noisy, t, slots, up_ft_index: int = 1, ensemble: Optional[int] = None):

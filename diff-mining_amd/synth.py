@@ -191,6 +191,56 @@ def synth_state_dict(cfg: UNetConfig = SD15, seed: int = 0, dtype=np.float32, mo
     return out
 
 
+# ---- one slab for the ranks of a node (bench.py --gpus N; VERDICT r05 #8b) ---------------------------------------------------------
+# The 686 tensors take ~50 s of host arithmetic to synthesise; N ranks doing it side by side cost N x the cores and N x 1.7 GB of
+# transient memory for identical bytes.  Rank 0 writes them once as ONE flat file (tensor bytes back to back, 256-byte aligned) with a
+# JSON index beside it; the other ranks map the file read-only and hand the engine views into it.  /dev/shm is memory: the writer
+# removes the pair once every rank has loaded (remove_slab).
+def save_slab(sd: dict, path: str) -> None:
+    """Writes {name: ndarray} to `path` (+ `path`.json) atomically (temporary name, then rename: a reader never sees a partial file)."""
+    import json
+    index, off = {}, 0
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "wb") as f:
+        for name, a in sd.items():
+            a = np.asarray(a)                                  # (tobytes() below is C order whatever the strides; 0-d stays 0-d)
+            pad = (-off) % 256
+            if pad:
+                f.write(b"\0" * pad)
+                off += pad
+            f.write(a.tobytes())
+            index[name] = {"dtype": a.dtype.str, "shape": list(a.shape), "offset": off}
+            off += a.nbytes
+    with open(path + ".json.tmp%d" % os.getpid(), "w") as f:
+        json.dump({"bytes": off, "tensors": index}, f)
+    os.replace(path + ".json.tmp%d" % os.getpid(), path + ".json")
+    os.replace(tmp, path)
+
+
+def load_slab(path: str) -> dict:
+    """{name: read-only ndarray view} over a file written by save_slab (np.memmap: pages are shared between the ranks)."""
+    import json
+    with open(path + ".json") as f:
+        meta = json.load(f)
+    if os.path.getsize(path) != meta["bytes"]:
+        raise RuntimeError(f"{path}: {os.path.getsize(path)} bytes on disk, the index says {meta['bytes']}")
+    raw = np.memmap(path, dtype=np.uint8, mode="r")
+    out = {}
+    for name, m in meta["tensors"].items():
+        dt = np.dtype(m["dtype"])
+        n = int(np.prod(m["shape"])) if m["shape"] else 1
+        out[name] = raw[m["offset"]:m["offset"] + n * dt.itemsize].view(dt).reshape(m["shape"])
+    return out
+
+
+def remove_slab(path: str) -> None:
+    for p in (path, path + ".json"):
+        try:
+            os.remove(p)
+        except FileNotFoundError:
+            pass
+
+
 def synth_vae_state_dict(cfg=None, seed: int = 0, dtype=np.float32) -> dict:
     """Synthetic `encoder.*` / `quant_conv.*` tensors of the SDv1.5 VAE (see vae_spec.py)."""
     from .vae_spec import SD15_VAE, vae_encoder_tensor_spec

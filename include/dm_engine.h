@@ -257,7 +257,9 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
                 const void* res, void* Y, int N, int H, int W, int C1, int C2, int Cout, int OH, int OW,
                 int mode, int epi, int temb_ld);
 /* Runtime switches for A/B measurements (process-wide; each defaults to the measured best and is initialised from the
- * environment variable DM_<NAME>).  Returns nonzero for an unknown name.
+ * environment variable DM_<NAME>).  Returns 1 for an unknown name and 2 for a value outside the switch's set (nothing changes then:
+ * 0 / 1 / 2 for every switch, -1 too for "igemm_big", the list below for "attn_pipe"); an environment value outside the set is
+ * reported on stderr and the default is kept.
  *   bit-neutral (the same arithmetic in the same order, asserted by tests/test_gpu_ops.py): "igemm_big" (-1 per shape /
  *     0 / 1: which tile geometry), "igemm_tail" (head / tail row split), "igemm_splitk" 0 vs 1 only for layers that
  *     do not split (a split layer sums its k parts in fp32 in a different order than the unsplit k loop);
@@ -285,12 +287,11 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
  *     prompt) and the cross-attention reads the queries modulo the draw count; 2 also runs the two GEMMs that read the prefix's
  *     outputs as a residual once per prompt block against the per-draw rows, so two of the three stacking copies of the shared
  *     prefix disappear (measured +-0, hence not the default) — all bit-identical to 0;
- *   "attn_pipe" (1; 0 / 2 / 3 / 4 / 10 / 12): the head_dim-40 / 80 self-attention kernels: 1 = the software-pipelined kernels, and from
- *     8192 keys the three-wave-set anti-phase kernel (attention_pp.hip, r05); 9 = the pipelined kernels everywhere (the r04 dispatch); 0 = the generic kernel; 12 / 10 / 4 = the anti-phase kernel
- *     everywhere (three sets with / without static priorities, two sets) — all bit-identical for head_dim 40;
- *   "attn2_fuse" (0 / 1): 1 = LayerNorm2 -> attn2.to_q computed inside the 77-key cross-attention kernel at the 320-channel level
- *     (attention_crossq.hip: the q tensor is never written or read) — numerically equivalent, not bit-identical to 0; measured SLOWER than
- *     the two launches (0.548 vs 0.491 ms per layer, +0.55 ms per step: DESIGN.md section 4g), hence off;
+ *   "attn_pipe" (1; 0 / 2 / 3 / 9 / 10 / 12 — any other value is refused): the head_dim-40 / 80 self-attention kernels: 1 = the
+ *     software-pipelined kernels, and from 8192 keys the three-wave-set anti-phase kernel (attention_pp.hip, r05); 9 = the pipelined
+ *     kernels everywhere (the r04 dispatch); 0 = the generic kernel; 2 = pipelined head_dim 40 only; 3 = head_dim 80 with constant-chunk
+ *     rows (A/B); 12 / 10 = the anti-phase kernel everywhere (three sets with / without static priorities) — all bit-identical for
+ *     head_dim 40.  (The two-set kernel and the timing-only ablation instantiations of r05 exist only in a -DDM_ATTN_PP_ABLATE debug build.)
  *   "gn_epi" (1 / 0): 1 = norm2's GroupNorm statistics as per-(64-row block, channel pair) sums written by conv1's epilogue where the
  *     persistent kernels run it and computed from conv1's output where they do not (bit-identical between the two, so independent of
  *     the batch); 0 = the statistics pass.  Numerically equivalent, not bit-identical to 0 (another summation order); -0.3 ms per step
@@ -326,13 +327,6 @@ int dm_op_igemm_ln(void* stream, const void* X, const void* Wp_folded, const voi
 int dm_op_igemm_splitk(void* stream, const void* X, const void* X2, const void* Wp, const void* bias, const void* temb,
                        const void* res, void* Y, int N, int H, int W, int C1, int C2, int Cout, int OH, int OW,
                        int mode, int temb_ld, int ksplit, void* workspace_f32);
-/* LayerNorm -> Linear (no bias) -> 77-key cross-attention in one kernel (attention_crossq.hip; head_dim 40, 8 heads): X [B][Tq][C] fp16 token
- * rows; Wq_folded [C][C] fp16 = W diag(gamma); ln_s[c] = sum_k Wq_folded[c][k], ln_t[c] = sum_k W[c][k] beta[k] (fp32); K / V [P][Tk][ld]
- * with prompt slots as dm_op_attention; O [B][Tq][C] fp16.  Nonzero for shapes the kernel does not take. */
-int dm_op_cross_attention_q(void* stream, const void* X, const void* Wq_folded, const float* ln_s, const float* ln_t, float ln_eps,
-                            const void* K, const void* V, void* O, int ldk, int ldv, int64_t bsk, int64_t bsv, const int32_t* kv_slot,
-                            int B, int heads, int Tq, int Tk, int D, float scale);
-
 /* single-head attention with head_dim 512 (VAE mid block): Q/K/V [B][T][ld], O [B][T][ldo] */
 int dm_op_attention512(void* stream, const void* Q, const void* K, const void* V, void* O, int B, int T, int ld,
                        int ldo, float scale);

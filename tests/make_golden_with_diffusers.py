@@ -1,6 +1,9 @@
 """Pins the oracle (and through it the engine) to the REAL dependency of the reference's hot path.
 
-    python tests/make_golden_with_diffusers.py        # needs: pip install diffusers==0.24.0 (environment.yaml:15)
+    pip install "diffusers==0.24.0" "transformers>=4.30" "accelerate"     # the reference's pin (environment.yaml:15); torch as installed
+    python tests/make_golden_with_diffusers.py             # writes tests/golden/{score,dift,vae}_diffusers.npz (CPU: ~2 min; a GPU adds the autocast arrays)
+    python tests/make_golden_with_diffusers.py --check     # validates existing fixtures against the keys / shapes / dtypes the tests read
+                                                           # (needs neither diffusers nor a GPU: it only opens the .npz files)
 
 NOT runnable in the build image (diffusers is absent there and there is no network — SURVEY.md §0 F4), and never
 imported by the product, the GPU tests or bench.py: it only WRITES fixtures.  Anyone with the reference's
@@ -52,7 +55,83 @@ def _tile(eps, t, c):
             torch.cat([c[k:k + 1].expand(N, -1, -1) for k in range(n_cond)]))
 
 
+# What the consumers of the fixtures read (tests/test_oracle.py::test_oracle_against_real_diffusers_fixture,
+# tests/test_gpu_e2e.py::test_against_real_diffusers_fixture, tests/test_gpu_f32.py::test_fp32_net_against_real_diffusers_fixture):
+# key -> (dtype kind, shape as a function of the case).  `--check` holds a fixture to this table, so whoever generates it learns
+# at once — without a GPU and without the test-suite — whether the files will be picked up.
+SCORE_CASES = ((8, 8, 2), (16, 16, 1), (12, 10, 1), (32, 42, 1), (32, 48, 1))        # (h, w, draws) as written below
+
+
+def expected_score_keys():
+    exp = {"diffusers_version": ("U", None)}
+    for (h, w, n) in SCORE_CASES:
+        tag, B = f"{h}x{w}", 2 * n
+        exp.update({f"x_{tag}": ("f4", (1, 4, h, w)), f"eps_{tag}": ("f4", (n, 4, h, w)), f"t_{tag}": ("i8", (n,)),
+                    f"c_{tag}": ("f", (2, 77, 768)), f"noisy_fp32_cpu_{tag}": ("f4", (B, 4, h, w)),
+                    f"pred_fp32_cpu_{tag}": ("f4", (B, 4, h, w)), f"loss_fp32_cpu_{tag}": ("f4", (B, 4, h, w))})
+    exp.update({"x": ("f4", (1, 4, 8, 8)), "eps": ("f4", (2, 4, 8, 8)), "t": ("i8", (2,)), "c": ("f", (2, 77, 768)),
+                "loss_fp32_cpu": ("f4", (4, 4, 8, 8)), "pred_fp32_cpu": ("f4", (4, 4, 8, 8))})
+    return exp
+
+
+OPTIONAL_SCORE_KEYS = ("loss_autocast_cuda", "pred_autocast_cuda", "noisy_dtype")          # written only where a GPU ran the autocast leg
+
+
+def expected_dift_keys():
+    return {"diffusers_version": ("U", None), "noisy": ("f4", (2, 4, 16, 16)), "t": ("i8", ()), "prompt": ("f", (1, 77, 768)),
+            "feat_fp32": ("f2", (2, 1280, 8, 8)), "feat_f32_full": ("f4", (2, 1280, 8, 8)),
+            "noisy_12x10": ("f4", (2, 4, 12, 10)), "feat_fp32_12x10": ("f2", (2, 1280, 6, 5)), "feat_f32_full_12x10": ("f4", (2, 1280, 6, 5))}
+
+
+def expected_vae_keys():
+    return {"diffusers_version": ("U", None), "image": ("f2", (2, 3, 64, 64)), "moments": ("f4", (2, 8, 8, 8))}
+
+
+def check_fixture(path, expected, optional_prefixes=()):
+    """Problems of one fixture file as a list of strings (empty = the tests will read it)."""
+    if not os.path.exists(path):
+        return [f"{os.path.basename(path)}: absent"]
+    g = np.load(path)
+    bad = []
+    for k, (kind, shape) in expected.items():
+        if k not in g:
+            bad.append(f"{os.path.basename(path)}: key {k!r} missing")
+            continue
+        a = g[k]
+        dt = a.dtype.kind + (str(a.dtype.itemsize) if a.dtype.kind in "fi" else "")
+        if kind == "U":
+            if a.dtype.kind != "U":
+                bad.append(f"{os.path.basename(path)}: {k} should be a string, is {a.dtype}")
+            continue
+        if not (dt == kind or (kind == "f" and a.dtype.kind == "f")):
+            bad.append(f"{os.path.basename(path)}: {k} dtype {a.dtype}, expected {kind}")
+        if shape is not None and tuple(a.shape) != tuple(shape):
+            bad.append(f"{os.path.basename(path)}: {k} shape {tuple(a.shape)}, expected {tuple(shape)}")
+        if a.dtype.kind == "f" and not np.isfinite(a).all():
+            bad.append(f"{os.path.basename(path)}: {k} holds non-finite values")
+    known = set(expected)
+    for k in g.files:
+        if k not in known and not any(k == o or k.startswith(o + "_") for o in optional_prefixes):
+            bad.append(f"{os.path.basename(path)}: unexpected key {k!r} (a fixture is data the tests read; nothing else belongs in it)")
+    if "diffusers_version" in g and "0.24" not in str(g["diffusers_version"]):
+        bad.append(f"{os.path.basename(path)}: written with {g['diffusers_version']} — the reference pins diffusers==0.24.0 (environment.yaml:15)")
+    return bad
+
+
+def check(out_dir=OUT):
+    bad = check_fixture(os.path.join(out_dir, "score_diffusers.npz"), expected_score_keys(), OPTIONAL_SCORE_KEYS)
+    bad += check_fixture(os.path.join(out_dir, "dift_diffusers.npz"), expected_dift_keys())
+    bad += check_fixture(os.path.join(out_dir, "vae_diffusers.npz"), expected_vae_keys())
+    return bad
+
+
 def main():
+    if "--check" in sys.argv:
+        bad = check()
+        for b in bad:
+            print("PROBLEM:", b)
+        print("fixtures OK: the three *_diffusers tests will run" if not bad else f"{len(bad)} problem(s)")
+        sys.exit(1 if bad else 0)
     try:
         import diffusers
         from diffusers import AutoencoderKL, PNDMScheduler, UNet2DConditionModel

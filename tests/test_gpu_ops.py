@@ -264,67 +264,7 @@ def test_attention_pipelined_kernels_ragged_queries_and_rescale(D, Tq, Tk, spike
     U.assert_close_fp16(o, o_plain.float().cpu(), f"pipelined vs plain D={D}", rel=3e-3, abs_frac=4e-3)
 
 
-@pytest.mark.parametrize("B,Tq,mean_over_std", [(3, 1000, 0.5), (2, 4096, 3.0), (2, 300, 100.0)])
-def test_cross_attention_with_the_query_projection_inside(B, Tq, mean_over_std):
-    """attention_crossq.hip (r05): LayerNorm2 -> attn2.to_q -> 77-key cross-attention in ONE kernel (head_dim 40).
-    Against `F.layer_norm` + `F.linear` + SDPA in fp32, and against the two-launch chain it replaces (LayerNorm-folded GEMM ->
-    attention_cross.hip): the fused kernel must be no further from fp32 than the chain (x 1.1), ragged query counts, prompt slots,
-    a dominating key, and token rows whose mean dwarfs their spread (the one-pass variance's re-take path)."""
-    from diff_mining_amd import engine as E
-    lib = E.load_library()
-    heads, D, Tk, P = 8, 40, 77, 3
-    Cc = heads * D
-    g = torch.Generator().manual_seed(41)
-    x = torch.randn(B, Tq, Cc, generator=g)
-    x = (x + mean_over_std).half()                               # unit spread around a common offset
-    gamma = (1.0 + 0.2 * torch.randn(Cc, generator=g))
-    beta = 0.1 * torch.randn(Cc, generator=g)
-    Wq = (torch.randn(Cc, Cc, generator=g) * Cc ** -0.5).half()
-    kv = U.f16_randn(P, Tk, 2 * Cc, seed=42)
-    slots = torch.tensor([2, 0, 1][:B], dtype=torch.int32)
-    # fp32 reference
-    ln = F.layer_norm(x.float(), (Cc,), gamma, beta, 1e-5)
-    q = F.linear(ln, Wq.float())
-    kv[1, 70, :Cc] = (q[1 % B, 9] * 2.0).half()                   # one late key dominates some rows of prompt 1
-    k, v = kv[..., :Cc][slots.long()], kv[..., Cc:][slots.long()]
-
-    def split(t, T):
-        return t.float().view(B, T, heads, D).transpose(1, 2)
-    ref = F.scaled_dot_product_attention(split(q, Tq), split(k, Tk), split(v, Tk)).transpose(1, 2).reshape(B, Tq, Cc)
-    # the folded operands (engine.hip pack_ln_fold)
-    Wf = (Wq.float() * gamma[None, :]).half()
-    ln_s = Wf.double().sum(1).float()
-    ln_t = (Wq.double() * beta.double()[None, :]).sum(1).float()
-    d = U.dev()
-    xd, Wd, sd_, td_, kvd, sl = x.to(d), Wf.to(d), ln_s.to(d), ln_t.to(d), kv.to(d), slots.to(d)
-    o = torch.empty(B, Tq, Cc, dtype=torch.float16, device=d)
-    rc = lib.dm_op_cross_attention_q(U.stream(), U.ptr(xd), U.ptr(Wd), U.ptr(sd_), U.ptr(td_), 1e-5, U.ptr(kvd), U.ptr(kvd[..., Cc:]), U.ptr(o),
-                                     2 * Cc, 2 * Cc, Tk * 2 * Cc, Tk * 2 * Cc, U.ptr(sl), B, heads, Tq, Tk, D, float(D) ** -0.5)
-    assert rc == 0
-    torch.cuda.synchronize()
-    # the chain it replaces
-    qd = torch.empty(B, Tq, Cc, dtype=torch.float16, device=d)
-    assert lib.dm_op_igemm_ln(U.stream(), U.ptr(xd), U.ptr(Wd), U.ptr(sd_), U.ptr(td_), None, U.ptr(qd), B * Tq, Cc, Cc, 0) == 0
-    o_chain = U.op_attention(qd, kvd[..., :Cc], kvd[..., Cc:], heads, slots=sl)
-    e_f, e_c = U.rel_l2(o, ref), U.rel_l2(o_chain, ref)
-    print(f"LN -> to_q -> cross-attention, B={B} Tq={Tq} |mean|/std={mean_over_std}: fused {e_f:.2e}, two launches {e_c:.2e} (rel-L2 vs fp32)")
-    U.assert_close_fp16(o, ref, "fused cross-attention", rel=3e-3, abs_frac=6e-3)
-    assert e_f <= 1.1 * e_c + 2e-5
-    o2 = torch.empty_like(o)
-    assert lib.dm_op_cross_attention_q(U.stream(), U.ptr(xd), U.ptr(Wd), U.ptr(sd_), U.ptr(td_), 1e-5, U.ptr(kvd), U.ptr(kvd[..., Cc:]), U.ptr(o2),
-                                       2 * Cc, 2 * Cc, Tk * 2 * Cc, Tk * 2 * Cc, U.ptr(sl), B, heads, Tq, Tk, D, float(D) ** -0.5) == 0
-    torch.cuda.synchronize()
-    assert torch.equal(o, o2)
-    # batch independence: sample 1 alone
-    if B > 1:
-        o1 = torch.empty(1, Tq, Cc, dtype=torch.float16, device=d)
-        assert lib.dm_op_cross_attention_q(U.stream(), U.ptr(xd[1:2].contiguous()), U.ptr(Wd), U.ptr(sd_), U.ptr(td_), 1e-5, U.ptr(kvd), U.ptr(kvd[..., Cc:]),
-                                           U.ptr(o1), 2 * Cc, 2 * Cc, Tk * 2 * Cc, Tk * 2 * Cc, U.ptr(sl[1:2].contiguous()), 1, heads, Tq, Tk, D, float(D) ** -0.5) == 0
-        torch.cuda.synchronize()
-        assert torch.equal(o1[0], o[1])
-
-
-@pytest.mark.parametrize("variant", [4, 10, 12])
+@pytest.mark.parametrize("variant", [10, 12])
 @pytest.mark.parametrize("Tq,Tk,spike", [(4096, 4096, 3000), (300, 384, 300), (256, 320, None), (1000, 256, 100), (512, 1024, -1)])
 def test_attention_antiphase_kernel(variant, Tq, Tk, spike):
     """attention_pp.hip (head_dim 40; two wave sets per SIMD half an iteration apart): ragged query counts, key counts that are

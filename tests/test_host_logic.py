@@ -287,11 +287,37 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     rk = out["rank_ms_per_step"]
     assert len(rk["all"]) == 2 and rk["min"] <= rk["max"] and abs(rk["max"] - out["ms_per_step"]) < 1e-2
     assert "traffic_recorded_from" in out["roofline"]
+    # VERDICT r05 #8b: one weight slab per node — rank 0 writes it to /dev/shm, rank 1 maps it, same bytes, removed afterwards
+    assert out["weight_slab_check"] == {"equal": True, "mapped": True, "removed": True}
     # a launcher that gives a different world size than --gpus asks for is refused, not silently reported
     env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                         env=env2, timeout=120)
     assert r2.returncode != 0 and "WORLD_SIZE=3" in r2.stderr
+
+
+def test_weight_slab_round_trip(tmp_path):
+    """synth.save_slab / load_slab (bench.py --gpus N: the ranks of a node share one copy of the synthetic weights): every tensor back
+    bit for bit with its dtype and shape (0-d and empty ones included), views are read-only maps of ONE file, a truncated file is refused."""
+    from diff_mining_amd import synth
+    sd = {"a.weight": np.arange(24, dtype=np.float16).reshape(2, 3, 4), "b.bias": np.linspace(-1, 1, 7).astype(np.float32),
+          "c.scalar": np.array(3.5, dtype=np.float32), "d.empty": np.zeros((0, 4), np.float16),
+          "e.big": (np.arange(100003) % 251).astype(np.float16)}
+    path = str(tmp_path / "w.slab")
+    synth.save_slab(sd, path)
+    got = synth.load_slab(path)
+    assert list(got) == list(sd)
+    for k, v in sd.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape and np.array_equal(got[k], v), k
+        assert not got[k].flags.writeable
+    assert not [f for f in os.listdir(tmp_path) if ".tmp" in f]
+    with open(path, "ab") as f:
+        f.write(b"x")
+    with pytest.raises(RuntimeError, match="the index says"):
+        synth.load_slab(path)
+    synth.remove_slab(path)
+    synth.remove_slab(path)                                    # idempotent
+    assert os.listdir(tmp_path) == []
 
 
 # ---- r03: surface leftovers (VERDICT r02 "missing" 2, 3, 4, 6; ADVICE r02) -----------------------------------------

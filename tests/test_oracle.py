@@ -287,6 +287,42 @@ def test_category_prompt_templates():
 _DIFFUSERS_FIXTURE = os.path.join(os.path.dirname(__file__), "golden", "score_diffusers.npz")
 
 
+def test_diffusers_fixture_checker(tmp_path):
+    """`tests/make_golden_with_diffusers.py --check` (VERDICT r05 #8a): the table of keys / shapes / dtypes it holds a fixture to is the
+    one the three fixture tests read.  A stand-in of the right geometry (zeros — never committed, never compared with anything) passes;
+    a missing key, a wrong shape, a foreign diffusers version and a stray array are each reported."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mgd", os.path.join(os.path.dirname(__file__), "make_golden_with_diffusers.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+
+    def stand_in(exp):
+        kinds = {"f4": np.float32, "f2": np.float16, "i8": np.int64, "f": np.float16}
+        return {k: (np.array("diffusers 0.24.0, torch x") if kind == "U" else np.zeros(shape, kinds[kind])) for k, (kind, shape) in exp.items()}
+    score = stand_in(M.expected_score_keys())
+    score["loss_autocast_cuda_8x8"] = np.zeros((4, 4, 8, 8), np.float32)          # an optional (GPU-leg) array is tolerated
+    np.savez(tmp_path / "score_diffusers.npz", **score)
+    np.savez(tmp_path / "dift_diffusers.npz", **stand_in(M.expected_dift_keys()))
+    np.savez(tmp_path / "vae_diffusers.npz", **stand_in(M.expected_vae_keys()))
+    assert M.check(str(tmp_path)) == []
+    # every key the fixture tests index is in the table (the tests' own reads, listed here so that a new read fails this test first)
+    for k in ("x", "eps", "t", "c", "loss_fp32_cpu", "x_16x16", "loss_fp32_cpu_32x42", "noisy_fp32_cpu_12x10", "pred_fp32_cpu_32x48"):
+        assert k in M.expected_score_keys()
+    for k in ("noisy", "t", "prompt", "feat_fp32", "feat_f32_full", "noisy_12x10", "feat_fp32_12x10", "feat_f32_full_12x10"):
+        assert k in M.expected_dift_keys()
+    bad = dict(score)
+    del bad["pred_fp32_cpu_16x16"]
+    bad["loss_fp32_cpu"] = np.zeros((4, 4, 8, 9), np.float32)
+    bad["diffusers_version"] = np.array("diffusers 0.27.2, torch x")
+    bad["source_text"] = np.zeros(3, np.uint8)
+    np.savez(tmp_path / "score_diffusers.npz", **bad)
+    msgs = "\n".join(M.check(str(tmp_path)))
+    for needle in ("'pred_fp32_cpu_16x16' missing", "loss_fp32_cpu shape (4, 4, 8, 9)", "0.27.2", "unexpected key 'source_text'"):
+        assert needle in msgs, (needle, msgs)
+    os.remove(tmp_path / "vae_diffusers.npz")
+    assert any("vae_diffusers.npz: absent" in m for m in M.check(str(tmp_path)))
+
+
 @pytest.mark.skipif(not os.path.exists(_DIFFUSERS_FIXTURE), reason="tests/golden/score_diffusers.npz absent: it is written by "
                     "tests/make_golden_with_diffusers.py where diffusers 0.24 exists (not in this image) — until then the "
                     "U-Net oracle stays structurally pinned only (PARITY UNPINNED)")
