@@ -455,6 +455,18 @@ def main():
             "scores_checksum": float(all_scores.double().sum().item()),
         }
         if eng is not None:
+            # the matrix cores' own ceiling on this box, measured right behind the timed steps (the chip is warm and at its power cap):
+            # the igemm tile's MFMA stream with nothing else in the loop, random fp16 operands (~60 ms) and zeros (what a zero-filled
+            # benchmark would see).  `frac` prices against the nominal 2.5 PFLOP/s; `frac_of_measured_mfma_rate` against this.
+            try:
+                pk, pz = eng.measure_mfma_rate(30000, False), eng.measure_mfma_rate(10000, True)
+                out["roofline"].update({"mfma_only_tflops_measured": round(pk["tflops"], 1), "mfma_only_sclk_ghz": round(pk["sclk_ghz"], 3),
+                                        "mfma_only_tflops_zero_operands": round(pz["tflops"], 1), "mfma_only_sclk_ghz_zero_operands": round(pz["sclk_ghz"], 3),
+                                        "frac_of_measured_mfma_rate": round(ig_tf / pk["tflops"], 4),
+                                        "whole_path_frac_of_measured_mfma_rate": round(executed / step_s / 1e12 / pk["tflops"], 4)})
+            except Exception as ex:                            # noqa: BLE001  (an optional measurement must not cost the line)
+                out["roofline"]["mfma_only_tflops_measured"] = None
+                out["roofline"]["mfma_only_note"] = f"{type(ex).__name__}: {ex}"
             out["engine_stats"] = eng.stats()
             from diff_mining_amd.engine import get_options
             # the algebraic rewrites / schedules the line was measured with (all numerically equivalent to the layer-by-layer order)
@@ -491,8 +503,9 @@ def main():
                 ln = side_workload(a2, e_, dev, sd)
                 out["side_workloads"][w] = {"metric": ln["metric"], "value": ln["value"], "unit": ln["unit"], "ms_per_step": ln["ms_per_step"],
                                             "steps": 3, "dtype": ln["dtype"], "config": ln["config"]["workload"],
-                                            "roofline": {k: ln["roofline"][k] for k in ("kernel", "achieved", "peak", "frac", "attention_tflops",
-                                                                                       "whole_path_frac_nominal")}}
+                                            "roofline": {k: ln["roofline"].get(k) for k in ("kernel", "achieved", "peak", "frac", "attention_tflops",
+                                                                                           "whole_path_frac_nominal", "sclk_mhz_mean", "power_w_mean",
+                                                                                           "frac_at_sustained_clock")}}
         if net32 is not None:
             net32.close()
         if not args.no_cpu_baseline and world == 1 and not STUB:

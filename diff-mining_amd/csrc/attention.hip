@@ -355,6 +355,8 @@ hipError_t launch_attention_pipe80(const AttnParams& p, hipStream_t s);  // atte
 bool attention_pipe80_supports(const AttnParams& p);
 hipError_t launch_attention_cross(const AttnParams& p, hipStream_t s);   // attention_cross.hip
 bool attention_cross_supports(const AttnParams& p);
+hipError_t launch_attention_qk32(const AttnParams& p, hipStream_t s);    // attention_qk32.hip (r06: scores on 32x32x16 MFMAs)
+bool attention_qk32_supports(const AttnParams& p);
 hipError_t launch_attention_pp(const AttnParams& p, int variant, hipStream_t s);   // attention_pp.hip
 bool attention_pp_supports(const AttnParams& p);
 
@@ -369,6 +371,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     // the anti-phase kernel everywhere it applies (A/B): 10 / 12 = three wave sets without / with static priorities; 9 = the r04 dispatch.
     // set_option() admits no other value (a stray value used to select timing-only ablation instantiations)
     if ((pipe == 10 || pipe == 12) && attention_pp_supports(p)) return launch_attention_pp(p, pipe, s);
+    if (pipe == 5 && attention_qk32_supports(p)) return launch_attention_qk32(p, s);      // r06: QK^T on 32x32x16 wherever it applies (A/B)
 #ifdef DM_ATTN_PP_ABLATE
     if (pipe >= 4 && pipe != 9 && attention_pp_supports(p)) return launch_attention_pp(p, pipe, s);        // debug library only
 #endif
@@ -376,6 +379,9 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     // per launch; bit-identical to attn_pipe_kernel) and its 384-query blocks waste < 2 % of their rows; attn_pipe = 2 / 3 keep the r04 kernels
     if (pipe == 1 && p.Tk >= 8192 && attention_pp_supports(p) && (long long)((p.Tq + 383) / 384) * 384 * 50 <= 51LL * p.Tq)
         return launch_attention_pp(p, 12, s);
+    // r06: head_dim 40 on the kernel whose scores run on 32x32x16 MFMAs (attention_qk32.hip: -1.3 % per launch, -0.16 ms per step ABBA,
+    // the same distance to fp32 SDPA; profiles/r06_ab_attn_qk32.txt); attn_pipe = 9 / 2 keep attn_pipe_kernel (A/B)
+    if (pipe == 1 && attention_qk32_supports(p)) return launch_attention_qk32(p, s);
     if (pipe && attention_pipe_supports(p)) return launch_attention_pipe(p, s);
     if ((pipe == 1 || pipe >= 3) && attention_pipe80_supports(p)) return launch_attention_pipe80(p, s);     // attn_pipe = 2: head_dim 40 only (A/B)
     switch (p.D) {

@@ -1357,7 +1357,7 @@ static bool option_value_ok(int i, int value) {
 #ifdef DM_ATTN_PP_ABLATE
         return value >= 0 && value <= 51;
 #else
-        return value == 0 || value == 1 || value == 2 || value == 3 || value == 9 || value == 10 || value == 12;
+        return value == 0 || value == 1 || value == 2 || value == 3 || value == 5 || value == 9 || value == 10 || value == 12;
 #endif
     }
     if (i == OPT_IGEMM_BIG) return value >= -1 && value <= 2;

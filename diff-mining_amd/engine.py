@@ -28,7 +28,7 @@ SYMBOLS = [
     "dm_engine_load_clip_weight", "dm_engine_finalize_clip", "dm_clip_encode", "dm_op_igemm_splitk",
     "dm_op_ln_stats", "dm_op_igemm_ln", "dm_reduce_typicality_batched", "dm_op_igemm_tile", "dm_op_igemm_head_rows", "dm_set_option",
     "dm_engine_reserve", "dm_engine_stats", "dm_op_groupnorm_conv1x1", "dm_op_igemm_shortcut", "dm_normalize_map",
-    "dm_op_fold_upconv_weights", "dm_op_upconv_folded", "dm_prof_read_folded", "dm_get_option",
+    "dm_op_fold_upconv_weights", "dm_op_upconv_folded", "dm_prof_read_folded", "dm_get_option", "dm_measure_mfma_rate",
     "dm_f32_create", "dm_f32_destroy", "dm_f32_last_error", "dm_f32_load_weight", "dm_f32_finalize", "dm_f32_set_prompts",
     "dm_f32_unet_forward", "dm_f32_dift", "dm_f32_prof_enable", "dm_f32_prof_read", "dm_f32_memory", "dm_f32_op_gemm",
     "dm_f32_op_attention", "dm_f32_op_groupnorm", "dm_f32_op_layernorm", "dm_f32_load_vae_weight", "dm_f32_finalize_vae",
@@ -89,6 +89,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.dm_reduce_typicality.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.dm_typicality_image.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.dm_prof_enable.argtypes = [vp, i32]
+    lib.dm_measure_mfma_rate.argtypes = [vp, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if hasattr(lib, "dm_prof_read_folded"):
         lib.dm_prof_read_folded.argtypes = [vp, C.POINTER(C.c_double)]
     lib.dm_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64),
@@ -556,6 +557,13 @@ class UNetEngine:
     # -- measurement -----------------------------------------------------------------------------
     def prof_enable(self, on: bool = True):
         self._check(self.lib.dm_prof_enable(self._h, 1 if on else 0), "prof_enable")
+
+    def measure_mfma_rate(self, steps: int = 20000, zero_operands: bool = False) -> dict:
+        """Measurement only: TFLOP/s and shader clock the matrix cores sustain on the igemm tile's MFMA stream alone (dm_measure_mfma_rate;
+        ~10 us per 100 steps).  bench.py quotes the kernel family against it beside the nominal peak."""
+        tf, ghz = C.c_double(), C.c_double()
+        self._check(self.lib.dm_measure_mfma_rate(self._stream(), int(steps), 1 if zero_operands else 0, C.byref(tf), C.byref(ghz)), "measure_mfma_rate")
+        return {"tflops": tf.value, "sclk_ghz": ghz.value}
 
     def prof_read(self) -> dict:
         a, b, c2 = C.c_double(), C.c_double(), C.c_int64()

@@ -163,6 +163,12 @@ int dm_normalize_map(dm_engine* e, const void* map_dev, int64_t n, int mode, voi
  * kernel is bracketed by hipEvents on the launch stream.  dm_prof_read synchronises and returns
  * the accumulated kernel milliseconds, launch count and algorithmic FLOPs since the last reset. */
 int dm_prof_enable(dm_engine* e, int on);
+/* Measurement only (bench.py's roofline; no product path calls it): the rate the matrix cores of this device sustain on
+ * v_mfma_f32_16x16x32_f16 alone — the igemm tile's MFMA stream (8 waves per CU, 80 MFMAs per wave and step, 160 accumulator registers)
+ * with nothing else in the loop, `steps` steps per CU, on random fp16 operands (zero_operands = 0) or zeros (1).  At the package power
+ * cap the clock this returns is well below the nominal 2.4 GHz and depends on the operand statistics: it is the ceiling a
+ * GEMM-shaped kernel can reach on real data (csrc/probe_peak.hip).  sclk_ghz (optional) = shader cycles of one block / its wall time. */
+int dm_measure_mfma_rate(void* stream, int steps, int zero_operands, double* tflops, double* sclk_ghz);
 int dm_prof_read(dm_engine* e, double* igemm_ms, double* igemm_flops, int64_t* igemm_launches,
                  double* attn_ms, double* attn_flops, int64_t* attn_launches);
 /* igemm_flops above counts the multiply-adds the launches EXECUTE.  With "up_fold" an Upsample2D + conv launch executes 4 / 9 of the
@@ -287,11 +293,14 @@ int dm_op_igemm(void* stream, const void* X, const void* X2, const void* Wp, con
  *     prompt) and the cross-attention reads the queries modulo the draw count; 2 also runs the two GEMMs that read the prefix's
  *     outputs as a residual once per prompt block against the per-draw rows, so two of the three stacking copies of the shared
  *     prefix disappear (measured +-0, hence not the default) — all bit-identical to 0;
- *   "attn_pipe" (1; 0 / 2 / 3 / 9 / 10 / 12 — any other value is refused): the head_dim-40 / 80 self-attention kernels: 1 = the
- *     software-pipelined kernels, and from 8192 keys the three-wave-set anti-phase kernel (attention_pp.hip, r05); 9 = the pipelined
- *     kernels everywhere (the r04 dispatch); 0 = the generic kernel; 2 = pipelined head_dim 40 only; 3 = head_dim 80 with constant-chunk
- *     rows (A/B); 12 / 10 = the anti-phase kernel everywhere (three sets with / without static priorities) — all bit-identical for
- *     head_dim 40.  (The two-set kernel and the timing-only ablation instantiations of r05 exist only in a -DDM_ATTN_PP_ABLATE debug build.)
+ *   "attn_pipe" (1; 0 / 2 / 3 / 5 / 9 / 10 / 12 — any other value is refused): the head_dim-40 / 80 self-attention kernels: 1 = head_dim 40
+ *     on attention_qk32.hip (r06: scores on 32x32x16 MFMAs, P moved to the PV layout by v_permlane16_swap), head_dim 80 on the
+ *     software-pipelined kernel, and from 8192 keys the three-wave-set anti-phase kernel (attention_pp.hip, r05); 5 = attention_qk32.hip
+ *     wherever it applies; 9 = the r04 pipelined kernels everywhere; 0 = the generic kernel; 2 = pipelined head_dim 40 only; 3 = head_dim 80
+ *     with constant-chunk rows (A/B); 12 / 10 = the anti-phase kernel everywhere (three sets with / without static priorities).  9, 2, 10 and
+ *     12 are bit-identical to each other for head_dim 40; 1 / 5 differ from them by the summation order of a score (k = 48 in one fp32
+ *     chain instead of 64), at the same distance from fp32 SDPA.  (The two-set kernel and the timing-only ablation instantiations of
+ *     r05 exist only in a -DDM_ATTN_PP_ABLATE debug build.)
  *   "gn_epi" (1 / 0): 1 = norm2's GroupNorm statistics as per-(64-row block, channel pair) sums written by conv1's epilogue where the
  *     persistent kernels run it and computed from conv1's output where they do not (bit-identical between the two, so independent of
  *     the batch); 0 = the statistics pass.  Numerically equivalent, not bit-identical to 0 (another summation order); -0.3 ms per step

@@ -264,6 +264,46 @@ def test_attention_pipelined_kernels_ragged_queries_and_rescale(D, Tq, Tk, spike
     U.assert_close_fp16(o, o_plain.float().cpu(), f"pipelined vs plain D={D}", rel=3e-3, abs_frac=4e-3)
 
 
+@pytest.mark.parametrize("Tq,Tk,spike", [(4096, 4096, 3000), (300, 384, 300), (256, 256, None), (1000, 256, 100), (512, 1024, -1), (130, 512, 400)])
+def test_attention_scores_on_32x32_mfma(Tq, Tk, spike):
+    """attention_qk32.hip (r06, head_dim 40): S^T = K Q'^T on v_mfma_f32_32x32x16_f16 (k = 48 instead of 64), P moved to the PV operand
+    layout by v_permlane16_swap, V rows / K chunks permuted in LDS.  Ragged query counts, K/V longer and shorter than Q, the minimum of
+    four tiles, a late dominating key (lazy rescale: the factor of the OTHER 16-query block travels 16 lanes), all-negative logits;
+    against fp32 SDPA and the kernel it replaces; deterministic; batch-independent."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    heads, B, D = 8, 2, 40
+    Cc = heads * D
+    q = U.f16_randn(B, Tq, Cc, seed=31)
+    k = U.f16_randn(B, Tk, Cc, seed=32)
+    v = U.f16_randn(B, Tk, Cc, seed=33)
+    if spike is not None and spike >= 0:
+        k[:, spike] = q[:, 7] * 4.0                              # query 7 (and whoever correlates) meets a dominating key late
+        k[:, spike - 70, :40] = q[:, 21, :40] * 3.0              # ... and query 21 of head 0 (the other 16-query block) one tile earlier
+    if spike == -1:
+        k, q = -k.abs(), q.abs()                                 # every logit negative: the first tile must set the running max
+
+    def split(t, T):
+        return t.float().view(B, T, heads, D).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(split(q, Tq), split(k, Tk), split(v, Tk)).transpose(1, 2).reshape(B, Tq, Cc)
+    d = U.dev()
+    qd, kd, vd = q.to(d), k.to(d), v.to(d)
+    try:
+        assert lib.dm_set_option(b"attn_pipe", 5) == 0
+        o = U.op_attention(qd, kd, vd, heads)
+        o2 = U.op_attention(qd, kd, vd, heads)
+        o1 = U.op_attention(qd[1:2].contiguous(), kd[1:2].contiguous(), vd[1:2].contiguous(), heads)
+        assert lib.dm_set_option(b"attn_pipe", 9) == 0
+        o_pipe = U.op_attention(qd, kd, vd, heads)
+    finally:
+        lib.dm_set_option(b"attn_pipe", 1)
+    e32, e16 = U.rel_l2(o, ref), U.rel_l2(o_pipe, ref)
+    print(f"qk32 attention Tq={Tq} Tk={Tk} spike={spike}: rel-L2 vs fp32 SDPA {e32:.2e} (attn_pipe_kernel {e16:.2e})")
+    U.assert_close_fp16(o, ref, f"qk32 attn Tq={Tq} Tk={Tk}", rel=3e-3, abs_frac=4e-3)
+    assert e32 <= 1.1 * e16 + 2e-5                               # VERDICT r05 #2: no further from fp32 than the kernel it replaces
+    assert torch.equal(o, o2) and torch.equal(o1[0], o[1])
+
+
 @pytest.mark.parametrize("variant", [10, 12])
 @pytest.mark.parametrize("Tq,Tk,spike", [(4096, 4096, 3000), (300, 384, 300), (256, 320, None), (1000, 256, 100), (512, 1024, -1)])
 def test_attention_antiphase_kernel(variant, Tq, Tk, spike):

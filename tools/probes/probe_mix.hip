@@ -1,0 +1,140 @@
+// r06: what would a k step of the persistent 3x3-convolution tile cost at OTHER operand byte mixes?
+// The 256 px x 320 ch x 64 k step of igemm_pers_tr_kernel moves 5 weight pieces + 1.67 activation pieces of 1 KiB per wave
+// (41 + 11 KB per block) beside its 80 MFMAs and 28 fragment reads per wave.  A pixel-heavy 512 px x 160 ch tile (the same 160
+// accumulator registers per wave) would move 2.5 + 2.8 pieces with horizontal tap reuse, 2.5 + 0.94 with all nine taps sharing one
+// activation strip — IF its LDS stages fitted 160 KB (they do not: DESIGN.md 4i).  This probe answers the prior question: does the
+// step get shorter when the bytes go away?  Same structure as tools/probes/probe_feed.hip's mix_kernel (two stages, drain + barrier
+// per step, one block of 8 waves per CU, pieces spread two per MFMA group), but
+//   * operands are RANDOM fp16 (probe_feed's were zero-filled: zeros clock ~15-20 % higher, MI355X_MICROARCH.md "DVFS give-back"),
+//   * the number of weight / activation pieces per wave and step is a template parameter in thirds (WP3 / 3, XP3 / 3 per step,
+//     realised over three consecutive steps like the tap-reuse kernel's 2 + 2 + 1),
+//   * MFMAs and fragment reads are those of the real step (80 + 28 per wave).
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/probe_mix.hip -o probe_mix && ./probe_mix
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int TP = 256, TC = 320, NW = 8;
+
+// WP3 / XP3: weight / activation pieces per wave per THREE steps (15 / 12 = the plain tile, 15 / 5 = tap reuse)
+template <int WP3, int XP3, int RD, int MF>
+__global__ __launch_bounds__(512, 2) void mix_kernel(const _Float16* __restrict__ Wp, const _Float16* __restrict__ X, int K, int C, int nk,
+                                                     int tiles_c, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lrow = lane >> 3, lchunk = ((lane & 7) ^ lrow) * 8;
+    const int b = blockIdx.x;
+    const int pt = b / tiles_c, ct = b % tiles_c;
+    const _Float16* wsrc = Wp + (size_t)(ct * TC + wid * 8 + lrow) * K + lchunk;
+    const _Float16* xsrc = X + (size_t)(pt * TP + wid * 8 + lrow) * C + lchunk;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int roff = ((wid & 3) * 64 + l15) * 128 + ((lg ^ (l15 & 7)) << 4);
+    f4 acc[20];
+    for (int i = 0; i < 20; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    h8 fa, fb;
+    for (int k = 0; k < 8; ++k) { fa[k] = (_Float16)(0.01f * (lane + k) - 0.3f); fb[k] = (_Float16)(0.02f * (lane - k) - 0.5f); }
+    // the stages hold random fp16 data from the start (values in [-1.9, 1.9]); the variants without DMA keep reading it
+    for (int i = threadIdx.x; i < 2 * (TP + TC) * 64; i += 512) {
+        unsigned hsh = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+        hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+        reinterpret_cast<_Float16*>(smem)[i] = (_Float16)(((float)(hsh & 0xFFFF) / 32768.0f - 1.0f) * 1.9f);
+    }
+    __syncthreads();
+    const long long t_begin = (long long)__builtin_readcyclecounter();
+    for (int kt = 0; kt < nk; ++kt) {
+        char* st = smem + ((kt + 1) & 1) * (TP + TC) * 128;
+        const char* cur = smem + (kt & 1) * (TP + TC) * 128;
+        const int ko = ((kt + 1) * 64) % C;
+        const int ph = kt % 3;
+        // pieces of this step: thirds distributed 2 + 2 + 1 style (the remainder goes to the early steps)
+        const int nw = WP3 / 3 + (ph < WP3 % 3 ? 1 : 0);
+        const int nx = XP3 / 3 + (ph < XP3 % 3 ? 1 : 0);
+        const int npieces = nw + nx;
+        int piece = 0;
+#pragma unroll
+        for (int g = 0; g < 20; ++g) {
+            if (RD) {          // 28 fragment reads per step: one per group + 8 extra
+                const h8 v = *reinterpret_cast<const h8*>(cur + roff + (g % 5) * 2048 + (g / 5) * 10240);
+                if (MF) fa = v; else { asm volatile("" :: "v"(v)); }
+                if (g < 8) { const h8 u = *reinterpret_cast<const h8*>(cur + 40960 + roff + (g % 4) * 2048); if (MF) fb = u; else { asm volatile("" :: "v"(u)); } }
+            }
+            if (MF) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[(g % 5) * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc[(g % 5) * 4 + j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {     // two pieces per MFMA group, all out within the first quarter (the real kernel's placement)
+                if (piece < npieces) {
+                    const int i = piece++;
+                    const int kw = (kt + 1) % nk;
+                    const _Float16* src = (i < nw) ? wsrc + (size_t)i * NW * 8 * K + kw * 64 : xsrc + (size_t)(i - nw) * NW * 8 * C + ko;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + (wid + i * NW) * 1024), 16, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    float sum = 0.f;
+    for (int i = 0; i < 20; ++i) sum += acc[i][0] + acc[i][3];
+    if (sum == 1.2345f) sink[1] = 1;
+    // shader cycles of this block's k loop (s_memtime counts shader clocks): cycles / step, and with the event time the clock itself
+    if (blockIdx.x == 5 && threadIdx.x == 0) { *reinterpret_cast<long long*>(sink + 4) = (long long)__builtin_readcyclecounter() - t_begin; }
+}
+
+int main() {
+    const int K = 5760, C = 640, Cout = 1280, M = 65536, tiles_c = Cout / TC, nblk = (M / TP) * tiles_c;   // 1024 tiles = 4 per CU
+    _Float16 *W, *X; unsigned* sink;
+    hipMalloc(&W, (size_t)Cout * K * 2); hipMalloc(&X, (size_t)M * C * 2); hipMalloc(&sink, 64);
+    {   // random fp16 operands, N(0, 0.5)-like (uniform sum), |x| < 2
+        std::vector<_Float16> h((size_t)M * C);
+        unsigned s = 12345u;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((s >> 8) & 0xFFFF) / 65536.0f; };
+        for (size_t i = 0; i < h.size(); ++i) h[i] = (_Float16)((rnd() + rnd() + rnd() + rnd() - 2.0f) * 0.9f);
+        hipMemcpy(X, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(W, h.data(), (size_t)Cout * K * 2, hipMemcpyHostToDevice);
+    }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int nk = K / 64;
+    const size_t lds = 2 * (TP + TC) * 128;
+    auto runm = [&](const char* name, auto kern, double kb) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, 0, W, X, K, C, nk, tiles_c, sink);
+        float best = 1e9f;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0, 0);
+            for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, 0, W, X, K, C, nk, tiles_c, sink);
+            hipEventRecord(e1, 0); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+            best = ms < best ? ms : best;
+        }
+        const double ns = best * 1e6 / (nblk / 256.0) / nk;
+        long long cyc = 0;
+        hipMemcpy(&cyc, sink + 4, 8, hipMemcpyDeviceToHost);
+        const double cps = (double)cyc / nk;               // shader cycles per step of block 5 (one of its CU's 4 consecutive blocks)
+        printf("%-66s %6.1f KB/step  %7.3f ms  per step: %5.0f ns = %5.0f cycles (%.2f GHz; MFMA pipe 2560)  = %5.0f TFLOP/s\n", name, kb, best, ns,
+               cps, cps / ns, 2.0 * 256 * 320 * 64 / ns * 256 / 1e3);
+    };
+    printf("random fp16 operands; 256x320x64 MACs per step and CU (80 MFMAs + 28 fragment reads per wave), 2 stages, drain + barrier per step\n");
+    runm("MFMA only (register operands)", mix_kernel<0, 0, 0, 1>, 0);
+    runm("MFMA + fragment reads (random LDS contents), no DMA", mix_kernel<0, 0, 1, 1>, 0);
+    runm("plain tile: 5 W + 4 X pieces/wave/step", mix_kernel<15, 12, 1, 1>, 72);
+    runm("tap reuse (shipped): 5 W + 1.67 X", mix_kernel<15, 5, 1, 1>, 53.3);
+    runm("512x160-like, horizontal reuse: 2.5 W + 2.67 X  [needs 176 KB of LDS]", mix_kernel<8, 8, 1, 1>, 42.7);
+    runm("512x160-like, nine-tap strip: 2.67 W + 1 X       [needs 210 KB]", mix_kernel<8, 3, 1, 1>, 29.3);
+    runm("weights only: 5 W + 0 X", mix_kernel<15, 0, 1, 1>, 40);
+    runm("half the weights: 2.67 W + 0 X", mix_kernel<8, 0, 1, 1>, 21.3);
+    runm("one piece per wave and step: 1 W", mix_kernel<3, 0, 1, 1>, 8);
+    runm("tap reuse (shipped) again", mix_kernel<15, 5, 1, 1>, 53.3);
+    runm("plain tile again", mix_kernel<15, 12, 1, 1>, 72);
+    runm("DMA only: 5 W + 4 X", mix_kernel<15, 12, 0, 0>, 72);
+    runm("DMA only: 5 W + 1.67 X", mix_kernel<15, 5, 0, 0>, 53.3);
+    runm("DMA only: 2.67 W + 2.67 X", mix_kernel<8, 8, 0, 0>, 42.7);
+    runm("DMA + reads: 5 W + 1.67 X", mix_kernel<15, 5, 1, 0>, 53.3);
+    return 0;
+}
