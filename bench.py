@@ -459,9 +459,15 @@ def main():
             # the igemm tile's MFMA stream with nothing else in the loop, random fp16 operands (~60 ms) and zeros (what a zero-filled
             # benchmark would see).  `frac` prices against the nominal 2.5 PFLOP/s; `frac_of_measured_mfma_rate` against this.
             try:
-                pk, pz = eng.measure_mfma_rate(30000, False), eng.measure_mfma_rate(10000, True)
-                out["roofline"].update({"mfma_only_tflops_measured": round(pk["tflops"], 1), "mfma_only_sclk_ghz": round(pk["sclk_ghz"], 3),
-                                        "mfma_only_tflops_zero_operands": round(pz["tflops"], 1), "mfma_only_sclk_ghz_zero_operands": round(pz["sclk_ghz"], 3),
+                smp = ClockSampler(local_rank, period_s=0.01)
+                torch.cuda.synchronize()
+                smp.start()
+                pk = eng.measure_mfma_rate(120000, False)                     # ~170 ms: long enough for the clock to settle and be sampled
+                ck = smp.stop()
+                pz = eng.measure_mfma_rate(20000, True)
+                out["roofline"].update({"mfma_only_tflops_measured": round(pk["tflops"], 1),
+                                        "mfma_only_sclk_mhz": ck.get("sclk_mhz_mean"), "mfma_only_power_w": ck.get("power_w_mean"),
+                                        "mfma_only_tflops_zero_operands": round(pz["tflops"], 1),
                                         "frac_of_measured_mfma_rate": round(ig_tf / pk["tflops"], 4),
                                         "whole_path_frac_of_measured_mfma_rate": round(executed / step_s / 1e12 / pk["tflops"], 4)})
             except Exception as ex:                            # noqa: BLE001  (an optional measurement must not cost the line)

@@ -22,7 +22,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdm_engine.so")
-SOURCES = ["igemm.hip", "igemm_pers.hip", "igemm_pers_ln.hip", "igemm_pers_part.hip", "igemm_pers_ws.hip", "igemm_ws.hip", "igemm_pers_sc.hip", "igemm_sc.hip", "igemm_pers_tr.hip", "igemm_pers_up.hip", "igemm_ko.hip", "igemm_ln.hip", "igemm64.hip", "igemm_splitk.hip", "attention.hip", "attention_pipe.hip", "attention_qk32.hip", "attention_pp.hip", "attention_pipe80.hip", "attention_cross.hip", "norm.hip", "misc.hip", "conv_out.hip", "vae.hip", "clip.hip", "f32_gemm.hip", "f32_ops.hip", "unet_f32.hip", "probe_peak.hip", "engine.hip"]
+SOURCES = ["igemm.hip", "igemm_pers.hip", "igemm_pers_ln.hip", "igemm_pers_part.hip", "igemm_pers_ws.hip", "igemm_ws.hip", "igemm_pers_sc.hip", "igemm_sc.hip", "igemm_pers_tr.hip", "igemm_pers_up.hip", "igemm_ko.hip", "igemm_ln.hip", "igemm64.hip", "igemm_splitk.hip", "attention.hip", "attention_pipe.hip", "attention_qk32.hip", "attention_d160.hip", "attention_pp.hip", "attention_pipe80.hip", "attention_cross.hip", "norm.hip", "misc.hip", "conv_out.hip", "vae.hip", "clip.hip", "f32_gemm.hip", "f32_ops.hip", "unet_f32.hip", "probe_peak.hip", "engine.hip"]
 HEADERS = [os.path.join(CSRC, "dm_kernels.h"), os.path.join(CSRC, "f32_kernels.h"), os.path.join(CSRC, "arena.h"), os.path.join(CSRC, "igemm_tile.h"), os.path.join(CSRC, "igemm_pers_tile.h"), os.path.join(os.path.dirname(HERE), "include", "dm_engine.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
          "-mllvm", "-amdgpu-mfma-vgpr-form=1"]

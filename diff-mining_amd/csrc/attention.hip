@@ -355,6 +355,10 @@ hipError_t launch_attention_pipe80(const AttnParams& p, hipStream_t s);  // atte
 bool attention_pipe80_supports(const AttnParams& p);
 hipError_t launch_attention_cross(const AttnParams& p, hipStream_t s);   // attention_cross.hip
 bool attention_cross_supports(const AttnParams& p);
+hipError_t launch_attention_d160(const AttnParams& p, hipStream_t s);    // attention_d160.hip (r06: head_dim 160, eight waves per block)
+bool attention_d160_supports(const AttnParams& p);
+hipError_t launch_attention_d160_cross(const AttnParams& p, hipStream_t s);   // the 77-key cross-attention at head_dim 160 (one pass)
+bool attention_d160_cross_supports(const AttnParams& p);
 hipError_t launch_attention_qk32(const AttnParams& p, hipStream_t s);    // attention_qk32.hip (r06: scores on 32x32x16 MFMAs)
 bool attention_qk32_supports(const AttnParams& p);
 hipError_t launch_attention_pp(const AttnParams& p, int variant, hipStream_t s);   // attention_pp.hip
@@ -364,6 +368,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.Tq <= 0 || p.Tk <= 0 || p.B <= 0) return hipErrorInvalidValue;
     // long head_dim-40 / 80 self-attention: software-pipelined variants (DM_ATTN_PIPE=0 disables)
     if (option(OPT_ATTN_CROSS) && attention_cross_supports(p)) return launch_attention_cross(p, s);   // 77-key cross-attention
+    if (option(OPT_ATTN_CROSS) && attention_d160_cross_supports(p)) return launch_attention_d160_cross(p, s);      // ... at head_dim 160 (r06)
     const int pipe = option(OPT_ATTN_PIPE);
     if (p.q_mod > 0) {                       // only the generic and the 77-key kernels index Q modulo (cross-attention; handled above / below)
         switch (p.D) { case 40: return launch_t<40, 2>(p, s); case 80: return launch_t<80, 2>(p, s); case 160: return launch_t<160, 2>(p, s); default: return hipErrorInvalidValue; }
@@ -384,6 +389,9 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (pipe == 1 && attention_qk32_supports(p)) return launch_attention_qk32(p, s);
     if (pipe && attention_pipe_supports(p)) return launch_attention_pipe(p, s);
     if ((pipe == 1 || pipe >= 3) && attention_pipe80_supports(p)) return launch_attention_pipe80(p, s);     // attn_pipe = 2: head_dim 40 only (A/B)
+    // head_dim 160 (r06): eight waves sharing one (sample, head)'s K / V, <= 256 registers; bit-identical to the generic kernel.  attn_pipe = 9 / 2
+    // keep the generic kernel (A/B)
+    if ((pipe == 1 || pipe == 5) && attention_d160_supports(p)) return launch_attention_d160(p, s);
     switch (p.D) {
         case 40: return launch_t<40, 2>(p, s);
         case 80: return launch_t<80, 2>(p, s);

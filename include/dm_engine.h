@@ -167,7 +167,8 @@ int dm_prof_enable(dm_engine* e, int on);
  * v_mfma_f32_16x16x32_f16 alone — the igemm tile's MFMA stream (8 waves per CU, 80 MFMAs per wave and step, 160 accumulator registers)
  * with nothing else in the loop, `steps` steps per CU, on random fp16 operands (zero_operands = 0) or zeros (1).  At the package power
  * cap the clock this returns is well below the nominal 2.4 GHz and depends on the operand statistics: it is the ceiling a
- * GEMM-shaped kernel can reach on real data (csrc/probe_peak.hip).  sclk_ghz (optional) = shader cycles of one block / its wall time. */
+ * GEMM-shaped kernel can reach on real data (csrc/probe_peak.hip).  sclk_ghz (optional) = s_memtime ticks of one block per ns of wall time:
+ * a diagnostic only — on the boxes of r06 it read ~0.5 x the clock amdsmi reports, so bench.py does not print it. */
 int dm_measure_mfma_rate(void* stream, int steps, int zero_operands, double* tflops, double* sclk_ghz);
 int dm_prof_read(dm_engine* e, double* igemm_ms, double* igemm_flops, int64_t* igemm_launches,
                  double* attn_ms, double* attn_flops, int64_t* attn_launches);

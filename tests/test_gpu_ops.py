@@ -304,6 +304,42 @@ def test_attention_scores_on_32x32_mfma(Tq, Tk, spike):
     assert torch.equal(o, o2) and torch.equal(o1[0], o[1])
 
 
+@pytest.mark.parametrize("Tq,Tk,spike", [(256, 256, None), (64, 64, None), (300, 128, 100), (256, 64, None), (1024, 1024, 900), (40, 192, -1)])
+def test_attention_head_dim_160_eight_wave_kernel(Tq, Tk, spike):
+    """attention_d160.hip (r06): head_dim 160 with eight waves sharing a (sample, head)'s K / V, K chunks / V blocks permuted in LDS.  One
+    tile (8x8 level), the 16x16 level, ragged and short query counts (waves without a query), a late dominating key, all-negative logits;
+    against fp32 SDPA, and BIT-EQUAL to the generic kernel (the same arithmetic in the same order: only the schedule and the LDS image differ)."""
+    from diff_mining_amd import engine as E
+    lib = E.load_library()
+    heads, B, D = 8, 3, 160
+    Cc = heads * D
+    q = U.f16_randn(B, Tq, Cc, seed=41)
+    k = U.f16_randn(B, Tk, Cc, seed=42)
+    v = U.f16_randn(B, Tk, Cc, seed=43)
+    if spike is not None and spike >= 0:
+        k[:, spike] = q[:, 7] * 2.0
+    if spike == -1:
+        k, q = -k.abs(), q.abs()
+
+    def split(t, T):
+        return t.float().view(B, T, heads, D).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(split(q, Tq), split(k, Tk), split(v, Tk)).transpose(1, 2).reshape(B, Tq, Cc)
+    d = U.dev()
+    qd, kd, vd = q.to(d), k.to(d), v.to(d)
+    try:
+        assert lib.dm_set_option(b"attn_pipe", 1) == 0
+        o = U.op_attention(qd, kd, vd, heads)
+        o1 = U.op_attention(qd[2:3].contiguous(), kd[2:3].contiguous(), vd[2:3].contiguous(), heads)
+        assert lib.dm_set_option(b"attn_pipe", 9) == 0
+        o_gen = U.op_attention(qd, kd, vd, heads)
+    finally:
+        lib.dm_set_option(b"attn_pipe", 1)
+    print(f"head_dim 160 Tq={Tq} Tk={Tk} spike={spike}: rel-L2 vs fp32 SDPA {U.rel_l2(o, ref):.2e}")
+    U.assert_close_fp16(o, ref, f"d160 attn Tq={Tq} Tk={Tk}", rel=3e-3, abs_frac=4e-3)
+    assert torch.equal(o, o_gen), f"not bit-equal to the generic kernel: max |diff| {(o.float() - o_gen.float()).abs().max().item():.3e}"
+    assert torch.equal(o1[0], o[2])
+
+
 @pytest.mark.parametrize("variant", [10, 12])
 @pytest.mark.parametrize("Tq,Tk,spike", [(4096, 4096, 3000), (300, 384, 300), (256, 320, None), (1000, 256, 100), (512, 1024, -1)])
 def test_attention_antiphase_kernel(variant, Tq, Tk, spike):
