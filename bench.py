@@ -579,7 +579,7 @@ def hbm_traffic_per_launch(launches_per_step):
     of them two kernel dispatches) from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950
     correction, + WRITE_SIZE): family bytes per step / launches per step.  rocprofv3 cannot run inside this process,
     so the number is the recorded one for this kernel build, or None when no record exists."""
-    for tag in ("r05_end", "r05_final", "r04_final", "r03_final", "r02_final"):          # the newest record that is committed
+    for tag in ("r06_end", "r05_end", "r05_final", "r04_final", "r03_final", "r02_final"):          # the newest record that is committed
         try:
             with open(os.path.join(ROOT, "profiles", tag + "_pmc.json")) as f:
                 k = json.load(f)["kernels"]["igemm_family"]

@@ -124,11 +124,18 @@ void attn_d160_kernel(AttnParams p, int nunits) {
     // slices of all heads, so neighbouring heads share 128-byte lines; with the heads scattered over the XCDs (block id mod 8) every such
     // line is fetched into two L2s.  XCD x owns the samples b = x, x + 8, ...; its blocks (slot = block id / 8) stride through the XCD's
     // list of (sample, head, query block) entries.
+    // (Only where the samples divide evenly over the eight XCDs and fill the launch: otherwise — a single image's 20 samples — the plain
+    // order u = block, block + grid, ... keeps the blocks balanced, which matters more than the shared lines.)
     const int upg = p.heads * nqb;                                  // units per sample
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int nslot = ((int)gridDim.x - xcd + 7) >> 3;              // blocks of this launch on the XCD
-    const int nent = ((p.B - xcd + 7) >> 3) * upg;                  // entries of the XCD's list
-    auto entry_unit = [&](int e) __attribute__((always_inline)) { const int gi = e / upg; return (xcd + 8 * gi) * upg + (e - gi * upg); };
+    const bool by_xcd = (p.B & 7) == 0 && nunits >= (int)gridDim.x && ((int)gridDim.x & 7) == 0;
+    const int xcd = by_xcd ? (int)(blockIdx.x & 7) : 0, slot = by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int nslot = by_xcd ? (int)gridDim.x >> 3 : (int)gridDim.x;           // blocks that share this block's list
+    const int nent = by_xcd ? (p.B >> 3) * upg : nunits;                        // entries of the list
+    auto entry_unit = [&](int e) __attribute__((always_inline)) {
+        if (!by_xcd) return e;
+        const int gi = e / upg;
+        return (xcd + 8 * gi) * upg + (e - gi * upg);
+    };
     int ent = slot;
     if (ent >= nent) return;
     int unit = entry_unit(ent);
@@ -258,7 +265,6 @@ void attn_d160_kernel(AttnParams p, int nunits) {
         unit = next;
         ent += nslot;
     }
-    (void)nunits;
 }
 
 // ---- the 77-key cross-attention at head_dim 160 (attn2 of the 1280-channel level) -----------------------------------------------------

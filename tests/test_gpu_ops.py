@@ -304,14 +304,17 @@ def test_attention_scores_on_32x32_mfma(Tq, Tk, spike):
     assert torch.equal(o, o2) and torch.equal(o1[0], o[1])
 
 
-@pytest.mark.parametrize("Tq,Tk,spike", [(256, 256, None), (64, 64, None), (300, 128, 100), (256, 64, None), (1024, 1024, 900), (40, 192, -1)])
-def test_attention_head_dim_160_eight_wave_kernel(Tq, Tk, spike):
+@pytest.mark.parametrize("Tq,Tk,spike,B", [(256, 256, None, 3), (64, 64, None, 3), (300, 128, 100, 3), (256, 64, None, 3), (1024, 1024, 900, 3), (40, 192, -1, 3),
+                                            (256, 256, 200, 40), (256, 256, None, 32), (64, 64, None, 64)])
+def test_attention_head_dim_160_eight_wave_kernel(Tq, Tk, spike, B):
     """attention_d160.hip (r06): head_dim 160 with eight waves sharing a (sample, head)'s K / V, K chunks / V blocks permuted in LDS.  One
     tile (8x8 level), the 16x16 level, ragged and short query counts (waves without a query), a late dominating key, all-negative logits;
-    against fp32 SDPA, and BIT-EQUAL to the generic kernel (the same arithmetic in the same order: only the schedule and the LDS image differ)."""
+    against fp32 SDPA, and BIT-EQUAL to the generic kernel (the same arithmetic in the same order: only the schedule and the LDS image differ).
+    B = 40 / 32 / 64: the persistent blocks walk several units each, in the order that keeps a sample's heads on one XCD (B % 8 == 0 and at
+    least one unit per block); B = 3: the plain order."""
     from diff_mining_amd import engine as E
     lib = E.load_library()
-    heads, B, D = 8, 3, 160
+    heads, D = 8, 160
     Cc = heads * D
     q = U.f16_randn(B, Tq, Cc, seed=41)
     k = U.f16_randn(B, Tk, Cc, seed=42)

@@ -56,6 +56,8 @@ def run():
     d = U.dev()
     g = torch.Generator(device="cuda").manual_seed(1)
     for si, (name, mode, H, W, C1, C2, Cout, epi, extra) in enumerate(SHAPES):
+        if os.environ.get("DM_PMC_FILTER") and os.environ["DM_PMC_FILTER"] not in name:
+            continue
         taps = 1 if mode == 0 else 9
         Cin = C1 + C2
         OH, OW = (2 * H, 2 * W) if mode in (3, 5) else (H, W)
@@ -123,8 +125,51 @@ def parse(dfetch, dwrite):
         print(f"{sh[0]:40s} {len(gf[i * REPS]):4d} {f / 1e6:8.1f} {rd / 1e6:8.1f} {f / rd:6.2f} {w / 1e6:8.1f} {wr / 1e6:8.1f} {w / wr:6.2f}")
 
 
+def parse_sq(dirs):
+    """SQ counters per shape (r06, VERDICT r05 #1: which unit saturates): `DM_PMC_FILTER=<substr> rocprofv3 --pmc <SQ set> ... pmc_shapes.py run`
+    once per counter set, then `pmc_shapes.py parse_sq <dir>...`.  One launch group per fill marker, REPS groups per shape; counters are
+    summed over a launch's dispatches and the median launch is printed, with the ratios that say where the wave cycles go."""
+    flt = os.environ.get("DM_PMC_FILTER", "")
+    shapes = [sh for sh in SHAPES if flt in sh[0]]
+    vals = {}
+    for d in dirs:
+        rows = load(d)
+        names = sorted({r["Counter_Name"] for r in rows})
+        for c in names:
+            gs, cur = [], []
+            for r in rows:
+                if r["Counter_Name"] != c:
+                    continue
+                if "igemm" in r["Kernel_Name"] or "splitk_reduce" in r["Kernel_Name"]:
+                    cur.append(float(r["Counter_Value"]))
+                elif cur:
+                    gs.append(cur)
+                    cur = []
+            if cur:
+                gs.append(cur)
+            assert len(gs) == REPS * len(shapes), (c, len(gs), len(shapes))
+            vals[c] = [sorted(sum(g) for g in gs[i * REPS:(i + 1) * REPS])[REPS // 2] for i in range(len(shapes))]
+    for i, sh in enumerate(shapes):
+        v = {c: vals[c][i] for c in vals}
+        print(sh[0])
+        for c in sorted(v):
+            print(f"    {c:30s} {v[c]:.4g}")
+        wc = v.get("SQ_WAVE_CYCLES")
+        if wc:
+            for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_INST_CYCLES_VMEM_RD"):
+                if c in v:
+                    print(f"    {c + ' / SQ_WAVE_CYCLES':42s} {v[c] / wc:.3f}")
+        if "SQ_BUSY_CYCLES" in v and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+            # SQ_BUSY_CYCLES is summed over the SEs / XCDs that report it; SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD with an MFMA in
+            # flight (MI355X_MICROARCH.md: = 16 x N_mfma for 16x16x32).  Their ratio per SIMD is the matrix-pipe duty.
+            print(f"    {'SQ_VALU_MFMA_BUSY_CYCLES / (4 x 256 SIMDs)':42s} {v['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024:.4g}   per-SIMD cycles with an MFMA executing")
+            print(f"    {'SQ_BUSY_CYCLES':42s} {v['SQ_BUSY_CYCLES']:.4g}")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run()
+    elif sys.argv[1] == "parse_sq":
+        parse_sq(sys.argv[2:])
     else:
         parse(sys.argv[2], sys.argv[3])

@@ -2,7 +2,7 @@
 # Regenerate the judged artifacts of a round on the GPU box:  bash tools/profile_round.sh <tag>
 # (run through gpurun; outputs land in gpurun_out/<tag>/, copy the summaries into profiles/).
 set -u
-TAG=${1:-r05_final}
+TAG=${1:-r06_end}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -20,7 +20,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
 done
 python tools/pmc_to_json.py $OUT 4 > $OUT/pmc.json    # a pass runs 4 steps: 1 warm-up + 1 timed + 2 of the grid-D2H leg
 # the graded line AFTER the counters: bench.py takes roofline.traffic from profiles/<tag>_pmc.json (the same library, the same box)
-mkdir -p profiles && cp $OUT/pmc.json profiles/${TAG}_pmc.json && cp $OUT/pmc.json profiles/r05_end_pmc.json      # (bench.py reads the newest tag first)
+mkdir -p profiles && cp $OUT/pmc.json profiles/${TAG}_pmc.json      # (bench.py reads the newest tag it knows first: hbm_traffic_per_launch)
 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2>> $OUT/bench.err
 # per-shape HBM traffic of the igemm family (cold caches per launch)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/pmcs_fetch -o pmc -- python tools/pmc_shapes.py run > /dev/null 2>&1
@@ -49,7 +49,12 @@ done
 python tools/pmc_to_json.py $OUT/d32 2 "bench.py --workload dift" > $OUT/dift_f32_pmc.json; rm -rf $OUT/d32
 for w in vae pixels; do python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline >> $OUT/side_workloads.jsonl 2>> $OUT/bench.err; done
 DM_BENCH_NOPROF=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-side > $OUT/bench_noprof.json 2>> $OUT/bench.err
-# the X-ray step with the r04 attention dispatch (attn_pipe = 9) and the r05 one (three anti-phase wave sets from 8192 keys), alternating
+# r06: the 3x3-convolution launches' SQ counters (which unit saturates), the operand-mix probe, the head_dim-160 scan
+bash tools/conv_pmc.sh $OUT/conv_pmc > /dev/null 2>&1; cp $OUT/conv_pmc/conv_sq.txt $OUT/conv_sq_counters.txt 2>/dev/null
+[ -x tools/probes/bin/probe_mix ] && ./tools/probes/bin/probe_mix > $OUT/probe_mix.txt 2>&1
+python tools/attn_d160_scan.py > $OUT/attn_d160_scan.txt 2>&1
+DM_BENCH_ITERS=10 python tools/ab_attn.py attn_pipe 9 1 > $OUT/ab_attn_r04_vs_r06.txt 2>&1
+# the X-ray step with the r04 attention dispatch (attn_pipe = 9) and the current one (three anti-phase wave sets from 8192 keys), alternating
 for i in 1 2; do for a in 9 1; do echo -n "attn_pipe=$a " >> $OUT/ab_xray_attn.txt; DM_ATTN_PIPE=$a python bench.py --workload xray --steps 5 --warmup 2 --no-cpu-baseline 2>> $OUT/bench.err | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['roofline']['attention_tflops'])" >> $OUT/ab_xray_attn.txt; done; done
 find $OUT/stats -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
 # raw traces are large; keep only the summaries
