@@ -87,6 +87,111 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const _Float16* __restrict_
     if (blockIdx.x == 5 && threadIdx.x == 0) { *reinterpret_cast<long long*>(sink + 4) = (long long)__builtin_readcyclecounter() - t_begin; }
 }
 
+// ---- r06: the two ideas no earlier round combined ---------------------------------------------------------------------------------
+// (a) r04's ring of four BK = 32 half-stages (the LDS-DMA pipe never drains: a half-stage is refilled three half-steps ahead), which LOST
+//     in the kernel because every half-step began with a burst of fragment reads behind a barrier in BOTH waves of a SIMD at once;
+// (b) the 8-phase GEMM template's stagger (cdna_hip_programming.md section 5): the two waves of a SIMD run the same program ONE barrier
+//     interval apart, so while one issues its 20 MFMAs the other issues its fragment reads and LDS-DMA pieces.
+// Per half-step and wave: phase P0 = {9 fragment reads (4 pixel + 5 weight fragments), pieces} | barrier | 20 MFMAs | barrier,
+// phase P1 = {5 reads (the other 80-channel half), pieces, counted vmcnt} | barrier | 20 MFMAs | barrier; waves 4..7 start one barrier late.
+// NP8: LDS-DMA pieces per EIGHT half-steps and wave (36 = the plain tile's 4.5 per half-step; 27 = the tap-reuse mix)
+template <int NP8, int STAGGER, int DMAINM = 0>
+__global__ __launch_bounds__(512, 2) void ring_ap_kernel(const _Float16* __restrict__ Wp, const _Float16* __restrict__ X, int K, int C, int nk,
+                                                         int tiles_c, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STG = (TP + TC) * 64;                       // 36 864 B per half-stage, four of them
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lrow = lane >> 2, lchunk = ((lane & 3) ^ ((lrow >> 2) & 3)) * 8;      // a 1 KiB piece = 16 rows x 64 B
+    const int b = blockIdx.x;
+    const int pt = b / tiles_c, ct = b % tiles_c;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int roff = ((wid & 3) * 64 + l15) * 64 + ((lg ^ ((l15 >> 2) & 3)) << 4);
+    for (int i = threadIdx.x; i < 4 * STG / 2; i += 512) {
+        unsigned hsh = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+        hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+        reinterpret_cast<_Float16*>(smem)[i] = (_Float16)(((float)(hsh & 0xFFFF) / 32768.0f - 1.0f) * 1.9f);
+    }
+    __syncthreads();
+    f4 acc[2][5][4];
+    for (int c = 0; c < 2; ++c) for (int i = 0; i < 5; ++i) for (int j = 0; j < 4; ++j) acc[c][i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    const int nh = 2 * nk;
+    const bool late = STAGGER && wid >= 4;
+    // piece i of this wave = piece pc = wid + 8 i of the half-stage (pc < 20: weight rows 16 pc .., else pixel rows): per-lane base pointers,
+    // the k offset advances by 32 halfs per half-step (the kernel's `woff += BK`); NP8 = 27 keeps the weights and fetches the pixel
+    // pieces only every third half-step (the tap-reuse mix)
+    const _Float16* base[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int pc = wid + 8 * i;
+        base[i] = (pc < 20) ? Wp + (size_t)(ct * TC + pc * 16 + lrow) * K + lchunk : X + (size_t)(pt * TP + ((pc - 20) & 15) * 16 + lrow) * C + lchunk;
+    }
+    const int npw = wid < 4 ? 5 : 4;                          // pieces 32..35 exist for waves 0..3 only
+    int kw = 96, kx = 96 % C;                                 // k offset of half-step h + 3
+    auto issue1 = [&](int h, int i) __attribute__((always_inline)) {      // piece i of half-step h + 3 into buffer (h + 3) & 3
+        const int pc = wid + 8 * i;
+        const bool isx = pc >= 20;
+        if (NP8 == 0 || i >= npw || (NP8 < 36 && isx && (h % 3) != 0)) return;
+        char* st = smem + ((h + 3) & 3) * STG;
+        __builtin_amdgcn_global_load_lds((gptr_t)(base[i] + (isx ? kx : kw)), (lptr_t)(st + pc * 1024), 16, 0, 0);
+    };
+    auto issue = [&](int h, int lo, int hi) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) if (i >= lo && i < hi) issue1(h, i);
+    };
+    const long long t_begin = (long long)__builtin_readcyclecounter();
+    if (late) asm volatile("s_barrier" ::: "memory");
+    for (int h = 0; h < nh; ++h) {
+        const char* cur = smem + (h & 3) * STG;
+        h8 fb[4], fa[5];
+        // ---- P0: load phase
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const h8*>(cur + 20480 + roff + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) fa[i] = *reinterpret_cast<const h8*>(cur + roff + i * 1024);
+        if (!DMAINM) issue(h, 0, 2);
+        asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (!DMAINM) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[0][i][j], 0, 0, 0);
+            if (DMAINM && i < 2) { issue1(h, i); __builtin_amdgcn_sched_barrier(0); }      // pieces ride between the MFMA groups, as in the shipped kernel
+        }
+        if (!DMAINM) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        // ---- P1: load phase (the other 80-channel half; the pixel fragments stay)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) fa[i] = *reinterpret_cast<const h8*>(cur + 5120 + roff + i * 1024);
+        if (!DMAINM) issue(h, 2, 5);
+        // half-step h + 1 must have landed: the pieces of h + 2 and h + 3 (<= 2 x 5 of this wave) may stay in flight
+        // (DMAINM: this half-step's second batch is issued after the wait, in the MFMA phase below: one batch fewer may stay)
+        if (DMAINM) { if (wid < 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else { if (wid < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (!DMAINM) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[1][i][j], 0, 0, 0);
+            if (DMAINM && i < 3) { issue1(h, 2 + i); __builtin_amdgcn_sched_barrier(0); }
+        }
+        if (!DMAINM) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        kw += 32; if (kw >= K) kw = 0;
+        kx += 32; if (kx >= C) kx = 0;
+    }
+    if (STAGGER && !late) asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float sum = 0.f;
+    for (int c = 0; c < 2; ++c) for (int i = 0; i < 5; ++i) for (int j = 0; j < 4; ++j) sum += acc[c][i][j][0] + acc[c][i][j][3];
+    if (sum == 1.2345f) sink[1] = 1;
+    if (blockIdx.x == 5 && threadIdx.x == 0) { *reinterpret_cast<long long*>(sink + 4) = (long long)__builtin_readcyclecounter() - t_begin; }
+}
+
 int main() {
     const int K = 5760, C = 640, Cout = 1280, M = 65536, tiles_c = Cout / TC, nblk = (M / TP) * tiles_c;   // 1024 tiles = 4 per CU
     _Float16 *W, *X; unsigned* sink;
@@ -136,5 +241,32 @@ int main() {
     runm("DMA only: 5 W + 1.67 X", mix_kernel<15, 5, 0, 0>, 53.3);
     runm("DMA only: 2.67 W + 2.67 X", mix_kernel<8, 8, 0, 0>, 42.7);
     runm("DMA + reads: 5 W + 1.67 X", mix_kernel<15, 5, 1, 0>, 53.3);
+    printf("--- r06: ring of four BK = 32 half-stages + the two waves of a SIMD one barrier interval apart (ns per 64-deep step = two half-steps)\n");
+    auto runr = [&](const char* name, auto kern, double kb) {
+        const size_t l4 = 4 * (TP + TC) * 64;
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), l4, 0, W, X, K, C, nk, tiles_c, sink);
+        float best = 1e9f;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0, 0);
+            for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), l4, 0, W, X, K, C, nk, tiles_c, sink);
+            hipEventRecord(e1, 0); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+            best = ms < best ? ms : best;
+        }
+        const double ns = best * 1e6 / (nblk / 256.0) / nk;
+        printf("%-66s %6.1f KB/step  %7.3f ms  per step: %5.0f ns  = %5.0f TFLOP/s\n", name, kb, best, ns, 2.0 * 256 * 320 * 64 / ns * 256 / 1e3);
+    };
+    runr("ring + stagger, plain mix (4.5 pieces / half-step)", (ring_ap_kernel<36, 1>), 72);
+    runr("ring, NO stagger, plain mix", (ring_ap_kernel<36, 0>), 72);
+    runr("ring + stagger, tap-reuse mix (3.4 pieces / half-step)", (ring_ap_kernel<27, 1>), 54);
+    runr("ring, NO stagger, tap-reuse mix", (ring_ap_kernel<27, 0>), 54);
+    runr("ring + stagger, no DMA", (ring_ap_kernel<0, 1>), 0);
+    runr("ring + stagger, pieces between the MFMAs, plain mix", (ring_ap_kernel<36, 1, 1>), 72);
+    runr("ring + stagger, pieces between the MFMAs, tap-reuse mix", (ring_ap_kernel<27, 1, 1>), 54);
+    runr("ring, NO stagger, pieces between the MFMAs, tap-reuse mix", (ring_ap_kernel<27, 0, 1>), 54);
+    runm("two stages, tap reuse (shipped) once more", mix_kernel<15, 5, 1, 1>, 53.3);
+    runr("ring + stagger, pieces between the MFMAs, tap-reuse mix (again)", (ring_ap_kernel<27, 1, 1>), 54);
+    runr("ring + stagger, tap-reuse mix once more", (ring_ap_kernel<27, 1>), 54);
     return 0;
 }
