@@ -454,7 +454,9 @@ def main():
                           "bytes_per_step": n_img * N_DRAWS * N_COND * 4 * LAT * LAT * 2}),
             "scores_checksum": float(all_scores.double().sum().item()),
         }
-        if eng is not None:
+        if eng is not None and not args.no_side:
+            # (skipped with --no-side, like the other legs behind the timed region: the rocprofv3 runs of tools/profile_round.sh use it, so the
+            # kernel-stats summary holds the step's kernels only)
             # the matrix cores' own ceiling on this box, measured right behind the timed steps (the chip is warm and at its power cap):
             # the igemm tile's MFMA stream with nothing else in the loop, random fp16 operands (~60 ms) and zeros (what a zero-filled
             # benchmark would see).  `frac` prices against the nominal 2.5 PFLOP/s; `frac_of_measured_mfma_rate` against this.
@@ -462,7 +464,7 @@ def main():
                 smp = ClockSampler(local_rank, period_s=0.01)
                 torch.cuda.synchronize()
                 smp.start()
-                pk = eng.measure_mfma_rate(120000, False)                     # ~170 ms: long enough for the clock to settle and be sampled
+                pk = eng.measure_mfma_rate(80000, False)                      # ~115 ms: long enough for the clock to settle and be sampled
                 ck = smp.stop()
                 pz = eng.measure_mfma_rate(20000, True)
                 out["roofline"].update({"mfma_only_tflops_measured": round(pk["tflops"], 1),
@@ -473,6 +475,7 @@ def main():
             except Exception as ex:                            # noqa: BLE001  (an optional measurement must not cost the line)
                 out["roofline"]["mfma_only_tflops_measured"] = None
                 out["roofline"]["mfma_only_note"] = f"{type(ex).__name__}: {ex}"
+        if eng is not None:
             out["engine_stats"] = eng.stats()
             from diff_mining_amd.engine import get_options
             # the algebraic rewrites / schedules the line was measured with (all numerically equivalent to the layer-by-layer order)

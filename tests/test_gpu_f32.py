@@ -404,6 +404,28 @@ def test_sdfeaturizer_from_pixels_in_fp32(net32, vae_sd, sd15_weights_torch):
     assert out.shape == mean_ref.shape and r < TOL_E2E
 
 
+def test_f32_score_conds_takes_the_product_surface_keywords(net32):
+    """`TypicalityScorer.compute_losses_batch` / `compute_submission` call `score_conds(..., latent_dtype=, slot_table=)`; the fp32 net
+    takes the same keywords: `slot_table` [n_cond, U] = the registered prompt of draw i in its k-th condition (rows k U + i, bit-equal to
+    `score` on the tiled batch with those slots), `latent_dtype` None / float32 only."""
+    h = w = 8
+    x, eps, t, c = synth.synth_inputs(1, 3, h, w, latent_dtype=np.float32)
+    x, eps, t, c = torch.from_numpy(x), torch.from_numpy(eps), torch.from_numpy(t), torch.from_numpy(c).float()
+    c3 = torch.cat([c, (c[:1] * 0.5 + c[1:2] * 0.5)])                          # three registered prompts
+    net32.set_prompts(c3)
+    table = torch.tensor([[2, 0, 2], [1, 1, 1]], dtype=torch.int32)
+    got = net32.score_conds(x, eps, t, 2, latent_dtype=torch.float32, slot_table=table)
+    want = net32.score(x, eps.repeat(2, 1, 1, 1), t.repeat(2), table.reshape(-1))
+    assert got.shape == (6, 4, h, w) and torch.equal(got, want)
+    plain = net32.score_conds(x, eps, t, 2)
+    assert torch.equal(plain, net32.score(x, eps.repeat(2, 1, 1, 1), t.repeat(2), torch.tensor([0, 0, 0, 1, 1, 1], dtype=torch.int32)))
+    assert not torch.equal(plain, got)
+    with pytest.raises(ValueError, match="latent_dtype"):
+        net32.score_conds(x, eps, t, 2, latent_dtype=torch.float16)
+    with pytest.raises(ValueError, match="slot_table"):
+        net32.score_conds(x, eps, t, 2, slot_table=torch.zeros(5, dtype=torch.int32))
+
+
 def test_f32_net_error_behaviour(sd15_weights_f16):
     """Failures are loud and named (no fallback): calls before finalize / set_prompts, a state dict with a tensor missing or of the
     wrong shape, a prompt slot outside the registered prompts, a batch that is not whole ensembles."""
