@@ -22,7 +22,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int TP = 256, TC = 320, NW = 8;
 
 // WP3 / XP3: weight / activation pieces per wave per THREE steps (15 / 12 = the plain tile, 15 / 5 = tap reuse)
-template <int WP3, int XP3, int RD, int MF>
+// BUF: the pieces go out as buffer_load_dwordx4 ... offen lds (a 128-bit resource in SGPRs + one 32-bit offset per lane) instead of
+// global_load_lds_dwordx4 (a 64-bit address per lane): half the address bytes per instruction on the VMEM issue path
+template <int WP3, int XP3, int RD, int MF, int BUF = 0>
 __global__ __launch_bounds__(512, 2) void mix_kernel(const _Float16* __restrict__ Wp, const _Float16* __restrict__ X, int K, int C, int nk,
                                                      int tiles_c, unsigned* sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -32,6 +34,10 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const _Float16* __restrict_
     const int pt = b / tiles_c, ct = b % tiles_c;
     const _Float16* wsrc = Wp + (size_t)(ct * TC + wid * 8 + lrow) * K + lchunk;
     const _Float16* xsrc = X + (size_t)(pt * TP + wid * 8 + lrow) * C + lchunk;
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, 0x7FFFFFFF, 0x00020000);
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned wvo = (unsigned)(((size_t)(ct * TC + wid * 8 + lrow) * K + lchunk) * 2);
+    const unsigned xvo = (unsigned)(((size_t)(pt * TP + wid * 8 + lrow) * C + lchunk) * 2);
     const int l15 = lane & 15, lg = lane >> 4;
     const int roff = ((wid & 3) * 64 + l15) * 128 + ((lg ^ (l15 & 7)) << 4);
     f4 acc[20];
@@ -72,8 +78,13 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const _Float16* __restrict_
                 if (piece < npieces) {
                     const int i = piece++;
                     const int kw = (kt + 1) % nk;
+                    if (BUF) {
+                        if (i < nw) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(st + (wid + i * NW) * 1024), 16, wvo + (unsigned)(i * NW * 8 * K + kw * 64) * 2u, 0, 0, 0);
+                        else __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(st + (wid + i * NW) * 1024), 16, xvo + (unsigned)((i - nw) * NW * 8 * C + ko) * 2u, 0, 0, 0);
+                    } else {
                     const _Float16* src = (i < nw) ? wsrc + (size_t)i * NW * 8 * K + kw * 64 : xsrc + (size_t)(i - nw) * NW * 8 * C + ko;
                     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + (wid + i * NW) * 1024), 16, 0, 0);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -241,6 +252,17 @@ int main() {
     runm("DMA only: 5 W + 1.67 X", mix_kernel<15, 5, 0, 0>, 53.3);
     runm("DMA only: 2.67 W + 2.67 X", mix_kernel<8, 8, 0, 0>, 42.7);
     runm("DMA + reads: 5 W + 1.67 X", mix_kernel<15, 5, 1, 0>, 53.3);
+    printf("--- r06: the same pieces as buffer_load ... lds (SGPR resource + 32-bit lane offset) instead of global_load_lds (64-bit lane address)\n");
+    runm("buffer form: DMA only 5 W + 4 X", (mix_kernel<15, 12, 0, 0, 1>), 72);
+    runm("global form: DMA only 5 W + 4 X", (mix_kernel<15, 12, 0, 0, 0>), 72);
+    runm("buffer form: DMA only 5 W + 1.67 X", (mix_kernel<15, 5, 0, 0, 1>), 53.3);
+    runm("global form: DMA only 5 W + 1.67 X", (mix_kernel<15, 5, 0, 0, 0>), 53.3);
+    runm("buffer form: tap reuse, MFMA + reads + DMA", (mix_kernel<15, 5, 1, 1, 1>), 53.3);
+    runm("global form: tap reuse, MFMA + reads + DMA", (mix_kernel<15, 5, 1, 1, 0>), 53.3);
+    runm("buffer form: plain tile, MFMA + reads + DMA", (mix_kernel<15, 12, 1, 1, 1>), 72);
+    runm("global form: plain tile, MFMA + reads + DMA", (mix_kernel<15, 12, 1, 1, 0>), 72);
+    runm("buffer form: tap reuse (again)", (mix_kernel<15, 5, 1, 1, 1>), 53.3);
+    runm("global form: tap reuse (again)", (mix_kernel<15, 5, 1, 1, 0>), 53.3);
     printf("--- r06: ring of four BK = 32 half-stages + the two waves of a SIMD one barrier interval apart (ns per 64-deep step = two half-steps)\n");
     auto runr = [&](const char* name, auto kern, double kb) {
         const size_t l4 = 4 * (TP + TC) * 64;
