@@ -49,6 +49,11 @@ PEAK_TFLOPS = 2500.0                    # MI355X dense fp16 MFMA (MI355X_MICROAR
 SCORE_DEVIATION_MAX = 1.0e-3            # north_star: "<= 1e-3 score deviation from reference" on the loss grid (vs exact fp32, same inputs)
 PEAK_TFLOPS_F32 = 157.3                 # MI355X fp32 matrix (v_mfma_f32_*_f32: 256 FLOP/clk/CU; MI355X_MICROARCH.md "Peak FP32 (matrix)")
 STUB = os.environ.get("DM_BENCH_STUB", "0") not in ("", "0")     # CPU test of the launcher / gather path (gloo, no engine)
+# Rehearsal of the N > 1 path on a ONE-GPU box (r06): N ranks with REAL engines, all on cuda:0, gloo instead of RCCL (RCCL refuses two ranks on
+# one device).  Everything the driver's `--gpus N` run goes through except the RCCL transport itself (tests/test_gpu_rccl.py covers that at
+# world 1): the launcher, the /dev/shm weight slab, N engines, the r::N image shards, the gather, the barrier / MAX timing, the JSON line.
+# The line says so (`rehearsal`); its rate is NOT a scaling number (the ranks share one GPU).
+ONE_GPU = os.environ.get("DM_BENCH_ONE_GPU", "0") not in ("", "0")
 
 
 class ClockSampler:
@@ -267,9 +272,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if not STUB:
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group("gloo" if STUB else "nccl", rank=rank, world_size=world)
+            torch.cuda.set_device(0 if ONE_GPU else local_rank)
+        dist.init_process_group("gloo" if (STUB or ONE_GPU) else "nccl", rank=rank, world_size=world)
+    if ONE_GPU:
+        local_rank = 0
     dev = torch.device("cpu") if STUB else torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if (STUB or ONE_GPU) else dev          # where the timing collectives' tensors live (gloo: host)
     sync = (lambda: None) if STUB else torch.cuda.synchronize
 
     from diff_mining_amd import synth
@@ -364,7 +372,7 @@ def main():
                                                     "attn_ms": 0.0, "attn_flops": 0.0, "attn_launches": 0}
     if eng is not None:
         eng.prof_enable(False)
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
     rank_ms = [dt / args.steps * 1e3]
     if world > 1:
         # every rank's own clock over the same barrier-bracketed region, so a straggler shows in the line; the reported time
@@ -493,6 +501,9 @@ def main():
                 out["rccl_version"] = f"unavailable ({type(ex).__name__})"
             out["rank_ms_per_step"] = {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3),
                                        "all": [round(v, 3) for v in rank_ms]}
+        if ONE_GPU and world > 1:
+            out["rehearsal"] = (f"{world} ranks with real engines on ONE GPU over gloo (DM_BENCH_ONE_GPU=1): a wiring check of the N > 1 path, "
+                                "NOT a scaling number — the ranks share the device")
         if STUB:
             out["data"] = "stub (DM_BENCH_STUB=1: launcher / gather path only, no engine)"
             out["weight_slab_check"] = slab_check

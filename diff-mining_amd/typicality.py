@@ -463,11 +463,15 @@ def _all_gather_padded(local: torch.Tensor, per: int, world: int) -> torch.Tenso
     """ONE all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests) of `local` [n_local, ...] padded to `per` rows;
     returns [world, per, ...]."""
     import torch.distributed as dist
-    buf = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    buf[: local.shape[0]] = local
+    # gloo has no all_gather for device tensors: a gloo group over GPU tensors (bench.py's one-GPU rehearsal of the N > 1 path) stages
+    # the few scalars through the host; RCCL ("nccl") gathers on the device
+    via_host = local.is_cuda and dist.get_backend() == "gloo"
+    dev = torch.device("cpu") if via_host else local.device
+    buf = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
+    buf[: local.shape[0]] = local.to(dev)
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)                      # the same call on RCCL and on gloo (the CPU tests exercise exactly this path)
-    return torch.stack(out, 0)
+    return torch.stack(out, 0).to(local.device)
 
 
 def gather_scores(local_scores: torch.Tensor, n_items: int, rank: int, world: int) -> torch.Tensor:

@@ -58,3 +58,26 @@ def test_rccl_all_gather_of_scores_world1():
     assert out["ok"] and out["backend"] == "nccl" and out["world"] == 1
     assert out["each"] == 1.25 and out["max"] == 1.25
     print("RCCL", out["rccl"])
+
+
+def test_bench_two_ranks_with_real_engines_on_one_gpu():
+    """Rehearsal of the driver's `bench.py --gpus N` on the 1-GPU box (r06): `DM_BENCH_ONE_GPU=1` runs N = 2 ranks with REAL engines, both on
+    cuda:0, over gloo (RCCL refuses two ranks on one device; its own calls are the test above).  Everything else is the N > 1 path as
+    the driver will run it: bench.py launching its own ranks, rank 0 writing the 1.7 GB weight slab to /dev/shm and rank 1 mapping it, two
+    engines, the r::2 image shards, the all-gather of T(x|c) in global image order, the barrier / MAX timing, ONE JSON line — and the slab gone."""
+    assert torch.cuda.is_available()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"DM_BENCH_ONE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    before = set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-side",
+                        "--no-parity"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["backend"] == "gloo" and "rehearsal" in out
+    assert len(out["rank_ms_per_step"]["all"]) == 2 and out["ms_per_step"] >= out["rank_ms_per_step"]["min"] - 1e-3
+    assert out["value"] > 0 and out["scores_checksum"] == out["scores_checksum"] and abs(out["scores_checksum"]) < 10.0      # 16 finite T(x|c)
+    assert out["config"]["parallelism"].startswith("image-sharded x2")
+    after = set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()
+    assert not [f for f in after - before if f.startswith("dm_bench_weights_")], after - before
