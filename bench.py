@@ -206,27 +206,58 @@ def launch_ranks(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def SLAB_PATHS() -> list:
+    # one name per launch (the launcher's port is unique per run on this node): two benches on one node do not collide.
+    # /dev/shm first (pages shared between the ranks, no disk), /tmp if the node's shm mount is too small or absent
+    name = f"dm_bench_weights_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}.slab"
+    return [os.path.join(d, name) for d in ("/dev/shm", "/tmp") if os.path.isdir(d)]
+
+
 def SLAB_PATH() -> str:
-    # one name per launch (the launcher's port is unique per run on this node): two benches on one node do not collide
-    return os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp",
-                        f"dm_bench_weights_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}.slab")
+    return SLAB_PATHS()[0]
+
+
+_slab_in_use = None        # the path rank 0 wrote (every rank knows it after node_state_dict), None = no slab this run
 
 
 def node_state_dict(rank: int, world: int, make=None):
     """The synthetic fp16 U-Net weights of this run.  One rank: synthesised in place.  N ranks of a node: rank 0 synthesises once and
     writes ONE 1.7 GB slab to /dev/shm, the others map it (same bytes by construction — the generator is a pure function of
-    (seed, name, index) — and 1/N of the host arithmetic and memory); removed again once every rank has loaded (main)."""
+    (seed, name, index) — and 1/N of the host arithmetic and memory); removed again once every rank has loaded (main).
+    A node whose /dev/shm and /tmp both refuse the slab (a 64 MB container shm, a full disk) is not an error: rank 0 tells the
+    others through the process group and every rank synthesises its own copy — the same bytes, N times the host work."""
+    global _slab_in_use
     from diff_mining_amd import synth
     import torch.distributed as dist
     make = make or (lambda: synth.synth_state_dict(seed=0, dtype=np.float16))
     if world == 1:
         return make()
-    path = SLAB_PATH()
+    paths = SLAB_PATHS()
+    which, sd = -1, None
     if rank == 0:
         sd = make()
-        synth.save_slab(sd, path)
-    dist.barrier()
-    return sd if rank == 0 else synth.load_slab(path)
+        if os.environ.get("DM_BENCH_NO_SLAB", "0") in ("", "0"):
+            for i, path in enumerate(paths):
+                try:
+                    synth.save_slab(sd, path)
+                    which = i
+                    break
+                except OSError as ex:
+                    print(f"bench.py: weight slab not written to {path} ({ex}); trying the next place", file=sys.stderr, flush=True)
+                    synth.remove_slab(path)
+    flag = torch.tensor([which], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.broadcast(flag, src=0)
+    which = int(flag.item())
+    _slab_in_use = paths[which] if which >= 0 else None
+    if rank == 0:
+        return sd
+    return synth.load_slab(_slab_in_use) if _slab_in_use else make()
+
+
+def drop_slab(rank: int) -> None:
+    if rank == 0 and _slab_in_use:
+        from diff_mining_amd import synth
+        synth.remove_slab(_slab_in_use)
 
 
 def main():
@@ -297,10 +328,11 @@ def main():
             allck = [torch.zeros_like(ck) for _ in range(world)]
             dist.all_gather(allck, ck)
             dist.barrier()
-            if rank == 0:
-                synth.remove_slab(SLAB_PATH())
-            slab_check = {"equal": all(a.item() == allck[0].item() for a in allck), "mapped": bool(rank == 0 or not fake["w0"].flags.writeable),
-                          "removed": not os.path.exists(SLAB_PATH())}
+            used = _slab_in_use
+            drop_slab(rank)
+            slab_check = {"equal": all(a.item() == allck[0].item() for a in allck),
+                          "mapped": bool(used is not None and (rank == 0 or not fake["w0"].flags.writeable)),
+                          "removed": not any(os.path.exists(q) for q in SLAB_PATHS()), "slab": used}
 
         def step():                       # stands in for the engine: rank-dependent fake T(x|c), same gather path
             return gather_scores(torch.arange(n_img, dtype=torch.float32) + 100.0 * rank, n_img * world, rank, world)
@@ -340,8 +372,7 @@ def main():
 
     if world > 1 and not STUB:
         dist.barrier()                     # every rank has copied its weights to its GPU: the node's slab in /dev/shm can go
-        if rank == 0:
-            synth.remove_slab(SLAB_PATH())
+        drop_slab(rank)
     if eng is not None and os.environ.get("DM_GRAPH", "0") not in ("", "0"):
         # hipGraph replay (diagnostic, with DM_BENCH_NOPROF=1: a replay carries no per-launch events): the legacy default
         # stream cannot be captured, so the steps run on a stream of their own

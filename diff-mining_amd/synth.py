@@ -200,21 +200,29 @@ def save_slab(sd: dict, path: str) -> None:
     """Writes {name: ndarray} to `path` (+ `path`.json) atomically (temporary name, then rename: a reader never sees a partial file)."""
     import json
     index, off = {}, 0
-    tmp = path + ".tmp%d" % os.getpid()
-    with open(tmp, "wb") as f:
-        for name, a in sd.items():
-            a = np.asarray(a)                                  # (tobytes() below is C order whatever the strides; 0-d stays 0-d)
-            pad = (-off) % 256
-            if pad:
-                f.write(b"\0" * pad)
-                off += pad
-            f.write(a.tobytes())
-            index[name] = {"dtype": a.dtype.str, "shape": list(a.shape), "offset": off}
-            off += a.nbytes
-    with open(path + ".json.tmp%d" % os.getpid(), "w") as f:
-        json.dump({"bytes": off, "tensors": index}, f)
-    os.replace(path + ".json.tmp%d" % os.getpid(), path + ".json")
-    os.replace(tmp, path)
+    tmp, jtmp = path + ".tmp%d" % os.getpid(), path + ".json.tmp%d" % os.getpid()
+    try:
+        with open(tmp, "wb") as f:
+            for name, a in sd.items():
+                a = np.asarray(a)                              # (tobytes() below is C order whatever the strides; 0-d stays 0-d)
+                pad = (-off) % 256
+                if pad:
+                    f.write(b"\0" * pad)
+                    off += pad
+                f.write(a.tobytes())
+                index[name] = {"dtype": a.dtype.str, "shape": list(a.shape), "offset": off}
+                off += a.nbytes
+        with open(jtmp, "w") as f:
+            json.dump({"bytes": off, "tensors": index}, f)
+        os.replace(jtmp, path + ".json")
+        os.replace(tmp, path)
+    except OSError:                                            # a full or absent mount: leave nothing behind, the caller decides
+        for q in (tmp, jtmp):
+            try:
+                os.remove(q)
+            except OSError:
+                pass
+        raise
 
 
 def load_slab(path: str) -> dict:

@@ -288,7 +288,15 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     assert len(rk["all"]) == 2 and rk["min"] <= rk["max"] and abs(rk["max"] - out["ms_per_step"]) < 1e-2
     assert "traffic_recorded_from" in out["roofline"]
     # VERDICT r05 #8b: one weight slab per node — rank 0 writes it to /dev/shm, rank 1 maps it, same bytes, removed afterwards
-    assert out["weight_slab_check"] == {"equal": True, "mapped": True, "removed": True}
+    ck = out["weight_slab_check"]
+    assert ck["equal"] and ck["mapped"] and ck["removed"] and ck["slab"] and ck["slab"].endswith(".slab"), ck
+    # a node that cannot hold the slab (container /dev/shm of 64 MB, full /tmp) must not hang the other ranks at the barrier: rank 0
+    # says so through the process group and every rank synthesises its own copy — same bytes, nothing left behind
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                        capture_output=True, text=True, env=dict(env, DM_BENCH_NO_SLAB="1"), timeout=300)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    ck1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])["weight_slab_check"]
+    assert ck1 == {"equal": True, "mapped": False, "removed": True, "slab": None}, ck1
     # a launcher that gives a different world size than --gpus asks for is refused, not silently reported
     env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
