@@ -6,6 +6,9 @@ effect on T does not average out over the draws the way rounding noise does — 
 medians of tools/t_deviation_gpu.py.
 
     python tools/t_deviation_fold.py [n_images] [option[,option...]=up_fold] > profiles/r04_T_deviation_up_fold_paired.txt
+
+An option may carry its two values (`attn_pipe=1:3`: "on" = 1, "off" = 3; default 1:0) — r06: the scores of head_dim-40 self-attention on
+32x32x16 MFMAs (attn_pipe 1) against r05's kernel (attn_pipe 3).
 """
 import os
 import sys
@@ -23,8 +26,10 @@ from diff_mining_amd.typicality import TypicalityScorer  # noqa: E402
 
 def main():
     n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-    opts = [o.encode() for o in (sys.argv[2] if len(sys.argv) > 2 else "up_fold").split(",")]      # several switches: toggled together
-    opt = b"+".join(opts)
+    spec = (sys.argv[2] if len(sys.argv) > 2 else "up_fold").split(",")                          # several switches: toggled together
+    opts = [o.split("=")[0].encode() for o in spec]
+    vals = {o.split("=")[0].encode(): (tuple(int(v) for v in o.split("=")[1].split(":")) if "=" in o else (1, 0)) for o in spec}
+    opt = "+".join(spec).encode()
     N, hw = 10, 64
     sdn = synth.synth_state_dict(seed=0, dtype=np.float16)
     e16, e32 = UNetEngine(0), UNetEngineF32(0)
@@ -42,11 +47,11 @@ def main():
         g = {}
         for v in (1, 0):
             for o in opts:
-                assert lib.dm_set_option(o, v) == 0
+                assert lib.dm_set_option(o, vals[o][0] if v else vals[o][1]) == 0
             g[v] = sc.compute_losses(x, c, noises=noises, timesteps=ts, to_host=False).float()
         ref = e32.score_conds(x, noises, ts, 2).view(2, N, 4, hw, hw).transpose(0, 1)        # fp32 net, switch off
         for o in opts:
-            lib.dm_set_option(o, 1)
+            lib.dm_set_option(o, vals[o][0])
         T32 = (ref[:, 1] - ref[:, 0]).double().mean().item()
         ml = ref.mean().item()
         T = {v: (g[v][:, 1] - g[v][:, 0]).double().mean().item() for v in (1, 0)}
