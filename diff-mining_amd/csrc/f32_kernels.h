@@ -44,6 +44,11 @@ hipError_t launch_gn_stats(const float* X, const float* X2, int N, int HW, int C
 hipError_t launch_gn_apply(const float* X, const float* X2, int N, int HW, int C, int C1, int G, const float* gamma, const float* beta,
                            const float* stats, int silu, float* Y, hipStream_t s);
 hipError_t launch_layernorm(const float* X, int rows, int C, const float* gamma, const float* beta, float eps, float* Y, hipStream_t s);
+// CLIP text tower glue (fp32): token + position embedding; causal attention of <= 80 tokens x heads of 64 on the stacked q|k|v rows
+// [n*T][3*heads*64] (q scaled by 1/8 inside); y * sigmoid(1.702 y) in place
+hipError_t launch_clip_embed(const int32_t* ids, const float* tok, const float* pos, int rows, int T, int C, int vocab, float* out, hipStream_t s);
+hipError_t launch_clip_attention(const float* qkv, int n, int T, int heads, float* out, hipStream_t s);
+hipError_t launch_quick_gelu(float* x, long long n, hipStream_t s);
 hipError_t launch_silu(const float* in, float* out, long long n, hipStream_t s);
 // Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): out [B][dim] = [cos | sin]
 hipError_t launch_timestep_embed(const int64_t* t, int B, int dim, float* out, hipStream_t s);

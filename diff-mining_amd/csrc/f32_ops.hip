@@ -261,6 +261,68 @@ __global__ __launch_bounds__(256) void ln32_kernel(const float* X, int rows, int
     for (int i = lane; i < C; i += 64) y[i] = (x[i] - mean) * rstd * gamma[i] + beta[i];
 }
 
+// ---- CLIP text tower glue in fp32 (`pipe.encode_prompt` of the featuriser's fp32 pipeline, dift.py:197-199, 222-226) ---------------------
+// token_embedding[ids] + position_embedding
+__global__ void clip32_embed_kernel(const int32_t* ids, const float* tok, const float* pos, int rows, int T, int C, int vocab, float* out) {
+    const int row = blockIdx.x;
+    if (row >= rows) return;
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float* a = tok + (size_t)id * C;
+    const float* b = pos + (size_t)(row % T) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) out[(size_t)row * C + c] = a[c] + b[c];
+}
+
+// causal self-attention over <= 80 tokens, heads of 64: one block per (prompt, head), one thread per query; qkv [n*T][3*heads*64];
+// q is scaled by head_dim^-0.5 = 1/8 AFTER its projection (bias included), as CLIPAttention does (a power of two: exact)
+constexpr int CLD = 64, CLT = 80;
+__global__ __launch_bounds__(128) void clip32_attn_kernel(const float* qkv, int T, int heads, float* out) {
+    __shared__ float Ks[CLT][CLD + 1], Vs[CLT][CLD + 1];
+    const int h = blockIdx.x, n = blockIdx.y;
+    const int C = heads * CLD;
+    const float* base = qkv + (size_t)n * T * 3 * C + h * CLD;
+    for (int i = threadIdx.x; i < T * CLD; i += blockDim.x) {
+        const int t = i / CLD, d = i - t * CLD;
+        Ks[t][d] = base[(size_t)t * 3 * C + C + d];
+        Vs[t][d] = base[(size_t)t * 3 * C + 2 * C + d];
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= T) return;
+    float q[CLD];
+#pragma unroll
+    for (int d = 0; d < CLD; ++d) q[d] = base[(size_t)t * 3 * C + d] * 0.125f;
+    float sc[CLT];
+    float m = -INFINITY;
+    for (int k = 0; k <= t; ++k) {                 // causal: keys 0..t
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < CLD; ++d) a = fmaf(q[d], Ks[k][d], a);
+        sc[k] = a;
+        m = fmaxf(m, a);
+    }
+    float l = 0.f;
+    for (int k = 0; k <= t; ++k) { sc[k] = expf(sc[k] - m); l += sc[k]; }
+    float o[CLD];
+#pragma unroll
+    for (int d = 0; d < CLD; ++d) o[d] = 0.f;
+    for (int k = 0; k <= t; ++k) {
+        const float pk = sc[k] / l;                // softmax output (fp32), then P V
+#pragma unroll
+        for (int d = 0; d < CLD; ++d) o[d] = fmaf(pk, Vs[k][d], o[d]);
+    }
+    float* dst = out + ((size_t)n * T + t) * C + h * CLD;
+#pragma unroll
+    for (int d = 0; d < CLD; ++d) dst[d] = o[d];
+}
+
+__global__ void quick_gelu32_kernel(float* x, long long n) {          // y * sigmoid(1.702 y)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float y = x[i];
+        x[i] = y / (1.0f + expf(-1.702f * y));
+    }
+}
+
 __global__ void silu32_kernel(const float* in, float* out, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float v = in[i];
@@ -430,6 +492,20 @@ hipError_t launch_gn_apply(const float* X, const float* X2, int N, int HW, int C
 }
 hipError_t launch_layernorm(const float* X, int rows, int C, const float* gamma, const float* beta, float eps, float* Y, hipStream_t s) {
     hipLaunchKernelGGL(ln32_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, X, rows, C, gamma, beta, eps, Y);
+    return hipGetLastError();
+}
+hipError_t launch_clip_embed(const int32_t* ids, const float* tok, const float* pos, int rows, int T, int C, int vocab, float* out, hipStream_t s) {
+    if (rows <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(clip32_embed_kernel, dim3(rows), dim3(256), 0, s, ids, tok, pos, rows, T, C, vocab, out);
+    return hipGetLastError();
+}
+hipError_t launch_clip_attention(const float* qkv, int n, int T, int heads, float* out, hipStream_t s) {
+    if (T <= 0 || T > CLT || n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(clip32_attn_kernel, dim3(heads, n), dim3(128), 0, s, qkv, T, heads, out);
+    return hipGetLastError();
+}
+hipError_t launch_quick_gelu(float* x, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(quick_gelu32_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, n);
     return hipGetLastError();
 }
 hipError_t launch_silu(const float* in, float* out, long long n, hipStream_t s) {

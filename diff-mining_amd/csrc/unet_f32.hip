@@ -61,6 +61,11 @@ struct Vae32 {
     size_t qw = NONE, qb = NONE;   // quant_conv [8][8], [8]
 };
 
+// CLIP ViT-L/14 text tower (`pipe.text_encoder` of the featuriser's fp32 pipeline: dift.py:197-199, 222-226)
+constexpr int CL_LAYERS = 12, CL_H = 768, CL_F = 3072, CL_HEADS = 12, CL_T = 77, CL_VOCAB = 49408;
+struct ClipLayer32 { Norm ln1, ln2; Conv qkv, o, fc1, fc2; };
+struct Clip32 { size_t tok = NONE, pos = NONE; ClipLayer32 layer[CL_LAYERS]; Norm final_ln; };
+
 struct T32 {                // NHWC fp32 activation in the arena
     size_t off = NONE; float* p = nullptr; int N = 0, H = 0, W = 0, C = 0;
     long long rows() const { return (long long)N * H * W; }
@@ -83,6 +88,10 @@ struct dm_f32_net {
     std::map<std::string, HostT>* cur_host = nullptr;      // the map the pack functions read (U-Net or VAE)
     float* vslab = nullptr; size_t vslab_floats = 0;
     Vae32 vae; bool vae_ready = false;
+    // optional CLIP text tower (dm_f32_load_clip_weight / dm_f32_finalize_clip): `pipe.encode_prompt` is fp32 there too (dift.py:222-226)
+    std::map<std::string, HostT> host_clip;
+    float* cslab = nullptr; size_t cslab_floats = 0;
+    Clip32 clip; bool clip_ready = false;
     Conv conv_in, conv_out, time1, time2, tproj_all;
     Norm norm_out;
     DownB down[NB]; Res mid_res[2]; Tfm mid_tf; UpB up[NB];
@@ -532,6 +541,42 @@ int run_vae32(dm_f32_net* e, const VaeArgs32& A, hipStream_t s, bool dry) {
     return 0;
 }
 
+// ---- CLIP text tower: token ids -> last_hidden_state, CLIPTextTransformer op by op in fp32 ---------------------------------------------
+// (embeddings; 12 x [LN1 -> q|k|v -> causal attention -> out_proj + residual -> LN2 -> fc1 -> quick_gelu -> fc2 + residual]; final LN)
+int run_clip32(dm_f32_net* e, const int32_t* ids, int n, float* out, hipStream_t s, bool dry) {
+    Fwd32 F{e, s, dry, e->cslab};
+    const Clip32& c = e->clip;
+    const int M = n * CL_T;
+    T32 x;
+    F_TRY(F.alloc(&x, 1, 1, M, CL_H));
+    if (!dry) F_HIP(e, launch_clip_embed(ids, F.P(c.tok), F.P(c.pos), M, CL_T, CL_H, CL_VOCAB, x.p, s));
+    for (int l = 0; l < CL_LAYERS; ++l) {
+        const ClipLayer32& L = c.layer[l];
+        T32 h, qkv, a, x1, f, x2;
+        F_TRY(F.layernorm(L.ln1, x, &h));
+        F_TRY(F.dense(L.qkv, h, nullptr, nullptr, &qkv));
+        F.free(h);
+        F_TRY(F.alloc(&a, 1, 1, M, CL_H));
+        if (!dry) F_HIP(e, launch_clip_attention(qkv.p, n, CL_T, CL_HEADS, a.p, s));
+        F.free(qkv);
+        F_TRY(F.dense(L.o, a, nullptr, &x, &x1));
+        F.free(a); F.free(x);
+        F_TRY(F.layernorm(L.ln2, x1, &h));
+        F_TRY(F.dense(L.fc1, h, nullptr, nullptr, &f));
+        F.free(h);
+        if (!dry) F_HIP(e, launch_quick_gelu(f.p, (long long)M * CL_F, s));
+        F_TRY(F.dense(L.fc2, f, nullptr, &x1, &x2));
+        F.free(f); F.free(x1);
+        x = x2;
+    }
+    T32 y;
+    F_TRY(F.layernorm(c.final_ln, x, &y));
+    F.free(x);
+    if (!dry) F_HIP(e, hipMemcpyAsync(out, y.p, (size_t)M * CL_H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    F.free(y);
+    return 0;
+}
+
 template <class RunDry>
 int ensure_arena_for32(dm_f32_net* e, hipStream_t s, const std::vector<long long>& key, RunDry run_dry) {
     size_t need;
@@ -612,6 +657,7 @@ void dm_f32_destroy(dm_f32_net* e) {
     (void)hipDeviceSynchronize();
     if (e->slab) (void)hipFree(e->slab);
     if (e->vslab) (void)hipFree(e->vslab);
+    if (e->cslab) (void)hipFree(e->cslab);
     if (e->sched_tab) (void)hipFree(e->sched_tab);
     if (e->score_tmp) (void)hipFree(e->score_tmp);
     if (e->arena_base) (void)hipFree(e->arena_base);
@@ -898,6 +944,89 @@ int dm_f32_vae_encode(dm_f32_net* e, const void* image_dev, const void* noise_de
     return 0;
 }
 
+int dm_f32_load_clip_weight(dm_f32_net* e, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim) {
+    if (!e || !name || !host_ptr || !shape) return 1;
+    if (e->clip_ready) F_FAIL(e, "load_clip_weight after finalize_clip");
+    std::string nm(name);
+    for (const char* pre : {"text_encoder.", "text_model."}) if (nm.rfind(pre, 0) == 0) nm = nm.substr(strlen(pre));
+    if (nm.size() >= 12 && nm.compare(nm.size() - 12, 12, "position_ids") == 0) return 0;          // index buffer
+    HostT t;
+    t.shape.assign(shape, shape + ndim);
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    t.data.resize(n);
+    if (dtype == DM_F32) memcpy(t.data.data(), host_ptr, n * sizeof(float));
+    else if (dtype == DM_F16) { const _Float16* h = (const _Float16*)host_ptr; for (size_t i = 0; i < n; ++i) t.data[i] = (float)h[i]; }
+    else F_FAIL(e, "unsupported dtype %d for %s", dtype, name);
+    e->host_clip[nm] = std::move(t);
+    return 0;
+}
+
+int dm_f32_finalize_clip(dm_f32_net* e) {
+    if (!e) return 1;
+    if (e->clip_ready) return 0;
+    F_HIP(e, hipSetDevice(e->device));
+    e->cur_host = &e->host_clip;
+    e->blob.clear();
+    struct Reset { dm_f32_net* e; ~Reset() { e->cur_host = nullptr; } } reset{e};
+    Clip32& c = e->clip;
+    {
+        HostT* tok = get(e, "embeddings.token_embedding.weight", {CL_VOCAB, CL_H});
+        HostT* pos = get(e, "embeddings.position_embedding.weight", {CL_T, CL_H});
+        if (!tok || !pos) return 1;
+        c.tok = put(e, tok->data.data(), tok->data.size());
+        c.pos = put(e, pos->data.data(), pos->data.size());
+    }
+    for (int l = 0; l < CL_LAYERS; ++l) {
+        ClipLayer32& L = c.layer[l];
+        const std::string b = "encoder.layers." + std::to_string(l);
+        F_TRY(pack_norm(e, b + ".layer_norm1", CL_H, &L.ln1));
+        F_TRY(pack_stack(e, {b + ".self_attn.q_proj", b + ".self_attn.k_proj", b + ".self_attn.v_proj"}, CL_H, CL_H, &L.qkv));
+        std::vector<float> qb;
+        for (const char* leaf : {".self_attn.q_proj", ".self_attn.k_proj", ".self_attn.v_proj"}) {
+            HostT* bt = get(e, b + leaf + ".bias", {CL_H});
+            if (!bt) return 1;
+            qb.insert(qb.end(), bt->data.begin(), bt->data.end());
+        }
+        L.qkv.b = put(e, qb.data(), qb.size());
+        F_TRY(pack_dense(e, b + ".self_attn.out_proj", CL_H, CL_H, false, true, &L.o));
+        F_TRY(pack_norm(e, b + ".layer_norm2", CL_H, &L.ln2));
+        F_TRY(pack_dense(e, b + ".mlp.fc1", CL_F, CL_H, false, true, &L.fc1));
+        F_TRY(pack_dense(e, b + ".mlp.fc2", CL_H, CL_F, false, true, &L.fc2));
+    }
+    F_TRY(pack_norm(e, "final_layer_norm", CL_H, &c.final_ln));
+    for (auto& kv : e->host_clip)
+        if (!kv.second.used) F_FAIL(e, "unexpected tensor in the CLIP text state dict: %s", kv.first.c_str());
+    if (e->host_clip.size() != 196) F_FAIL(e, "expected 196 CLIP text tensors, got %zu", e->host_clip.size());
+    e->cslab_floats = e->blob.size();
+    F_HIP(e, hipMalloc((void**)&e->cslab, e->cslab_floats * sizeof(float)));
+    F_HIP(e, hipMemcpy(e->cslab, e->blob.data(), e->cslab_floats * sizeof(float), hipMemcpyHostToDevice));
+    e->blob.clear(); e->blob.shrink_to_fit();
+    e->host_clip.clear();
+    e->clip_ready = true;
+    return 0;
+}
+
+/* `text_encoder(input_ids)[0]` in fp32 — what `pipe.encode_prompt` of the featuriser's fp32 pipeline returns (dift.py:222-226):
+ * input_ids_dev [n_prompts, 77] int32 (tokenizer output, padding="max_length"); out_f32_dev [n_prompts, 77, 768] fp32 */
+int dm_f32_clip_encode(dm_f32_net* e, const int32_t* input_ids_dev, int n_prompts, int seq_len, void* out_f32_dev, void* stream) {
+    if (!e) return 1;
+    if (!e->clip_ready) F_FAIL(e, "dm_f32_clip_encode: CLIP text weights not loaded (dm_f32_load_clip_weight / dm_f32_finalize_clip)");
+    if (!input_ids_dev || !out_f32_dev || n_prompts <= 0) F_FAIL(e, "dm_f32_clip_encode: bad argument");
+    if (seq_len != CL_T) F_FAIL(e, "dm_f32_clip_encode: seq_len must be %d (padding=\"max_length\")", CL_T);
+    F_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int chunk = 128;                                   // prompts per pass (workspace ~ 0.5 GB)
+    for (int n0 = 0; n0 < n_prompts; n0 += chunk) {
+        const int n = (n_prompts - n0 < chunk) ? (n_prompts - n0) : chunk;
+        const int32_t* ids = input_ids_dev + (size_t)n0 * CL_T;
+        float* o = (float*)out_f32_dev + (size_t)n0 * CL_T * CL_H;
+        F_TRY(ensure_arena_for32(e, s, {2, n, 0, 0, 0}, [&]() { return run_clip32(e, ids, n, o, s, true); }));
+        F_TRY(run_clip32(e, ids, n, o, s, false));
+    }
+    return 0;
+}
+
 int dm_f32_prof_enable(dm_f32_net* e, int on) {
     if (!e) return 1;
     e->prof = on != 0;
@@ -932,7 +1061,7 @@ int dm_f32_prof_read(dm_f32_net* e, double* gemm_ms, double* gemm_flops, int64_t
 
 int dm_f32_memory(dm_f32_net* e, size_t* weights_bytes, size_t* arena_bytes) {
     if (!e) return 1;
-    if (weights_bytes) *weights_bytes = (e->slab_floats + e->vslab_floats) * sizeof(float);
+    if (weights_bytes) *weights_bytes = (e->slab_floats + e->vslab_floats + e->cslab_floats) * sizeof(float);
     if (arena_bytes) *arena_bytes = e->arena_cap;
     return 0;
 }

@@ -16,7 +16,8 @@ Arithmetic: the reference's featuriser is fp32 end to end (dift.py:197-199: no t
 `UNetEngineF32` the U-Net runs in that arithmetic (`self.dtype == torch.float32`, matches the CPU oracle in fp32 mode to ~1e-6); built over
 the fp16 `UNetEngine` it is the fast reduced-precision mode (descriptor cosine >= 1 - 5e-7), which also
 carries the VAE encoder and the CLIP text tower for image / string inputs.  `SDFeaturizer(f32_net, aux=fp16_engine)` combines
-them: fp32 U-Net, the fp16 engine only for `vae_encode` / `clip_encode` / `patch_embed`.
+them: fp32 U-Net, the fp16 engine only for `vae_encode` / `clip_encode` / `patch_embed`; an fp32 net that holds its own VAE / CLIP
+weights (`load_vae_state_dict`, `load_clip_state_dict`) runs those stages in fp32 too, as the reference does.
 """
 from __future__ import annotations
 
@@ -106,15 +107,16 @@ class SDFeaturizer:
         if hit is not None:
             self._prompt_cache.move_to_end(prompt)
             return hit
-        if self.tokenizer is None or self.aux is None:
-            raise ValueError("a string prompt needs SDFeaturizer(engine, tokenizer=...) and CLIP text weights on the fp16 engine "
-                             "(engine.load_clip_state_dict; `aux=` when `engine` is the fp32 net); pass the [1,77,768] hidden states otherwise")
+        # the fp32 net's own text tower when it holds the weights (r06: `pipe.encode_prompt` of the reference's featuriser is fp32,
+        # dift.py:197-199, 222-226 — 2e-6 from transformers' fp32 output), else the fp16 engine's (1.1e-3 from it, DESIGN.md section 2:
+        # the one reduced-precision stage of an otherwise fp32 featuriser); hidden states passed as a tensor are used as they are
+        tower = self.engine if (isinstance(self.engine, UNetEngineF32) and getattr(self.engine, "_clip_ready", False)) else self.aux
+        if self.tokenizer is None or tower is None:
+            raise ValueError("a string prompt needs SDFeaturizer(engine, tokenizer=...) and CLIP text weights (engine.load_clip_state_dict on "
+                             "the fp32 net, or on the fp16 engine passed as `aux=`); pass the [1,77,768] hidden states otherwise")
         tok = self.tokenizer
         ids = tok([prompt], max_length=tok.model_max_length, padding="max_length", truncation=True, return_tensors="pt").input_ids
-        # NOTE: the text tower runs on the fp16 engine also when `engine` is the fp32 net — the one fp16 stage of an
-        # otherwise fp32 featuriser (the reference's `pipe.encode_prompt` is fp32, dift.py:222-226); hidden states passed as a
-        # tensor are used as they are.  The engine's tower is 1.1e-3 (rel-L2) from transformers' fp32 output.
-        emb = self.aux.clip_encode(ids)
+        emb = tower.clip_encode(ids)
         self._prompt_cache[prompt] = emb
         while len(self._prompt_cache) > 256:
             self._prompt_cache.popitem(last=False)

@@ -32,7 +32,7 @@ SYMBOLS = [
     "dm_f32_create", "dm_f32_destroy", "dm_f32_last_error", "dm_f32_load_weight", "dm_f32_finalize", "dm_f32_set_prompts",
     "dm_f32_unet_forward", "dm_f32_dift", "dm_f32_prof_enable", "dm_f32_prof_read", "dm_f32_memory", "dm_f32_op_gemm",
     "dm_f32_op_attention", "dm_f32_op_groupnorm", "dm_f32_op_layernorm", "dm_f32_load_vae_weight", "dm_f32_finalize_vae",
-    "dm_f32_vae_encode", "dm_f32_score",
+    "dm_f32_vae_encode", "dm_f32_score", "dm_f32_load_clip_weight", "dm_f32_finalize_clip", "dm_f32_clip_encode",
 ]
 
 
@@ -154,6 +154,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         lib.dm_f32_load_vae_weight.argtypes = [vp, C.c_char_p, vp, i32, C.POINTER(i64), i32]
         lib.dm_f32_finalize_vae.argtypes = [vp]
         lib.dm_f32_vae_encode.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.c_float, vp, vp, vp]
+        lib.dm_f32_load_clip_weight.argtypes = [vp, C.c_char_p, vp, i32, C.POINTER(i64), i32]
+        lib.dm_f32_finalize_clip.argtypes = [vp]
+        lib.dm_f32_clip_encode.argtypes = [vp, vp, i32, i32, vp, vp]
         lib.dm_f32_score.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     if path is None:
         _lib = lib
@@ -649,6 +652,26 @@ class UNetEngineF32:
         UNetEngine._load(self, self.lib.dm_f32_load_vae_weight, sd, "f32_load_vae_weight")
         self._check(self.lib.dm_f32_finalize_vae(self._h), "f32_finalize_vae")
         self._vae_ready = True
+
+    def load_clip_state_dict(self, sd: Dict[str, "np.ndarray"]):
+        """sd: `CLIPTextModel.state_dict()` (`pipe.text_encoder`); the featuriser's pipeline keeps it in fp32 (dift.py:197-199).  Optional."""
+        UNetEngine._load(self, self.lib.dm_f32_load_clip_weight, sd, "f32_load_clip_weight")
+        self._check(self.lib.dm_f32_finalize_clip(self._h), "f32_finalize_clip")
+        self._clip_ready = True
+
+    def clip_encode(self, input_ids, out_dtype=None):
+        """`text_encoder(input_ids)[0]` in fp32 — `pipe.encode_prompt(prompt)[0]` of the reference's featuriser (dift.py:222-226):
+        input_ids [n, 77] (tokenizer output, padding="max_length") -> last_hidden_state [n, 77, 768] fp32 on the GPU."""
+        torch = self._torch
+        if out_dtype not in (None, torch.float32):
+            raise ValueError("the fp32 net's text tower returns fp32 hidden states")
+        ids = torch.as_tensor(input_ids).to(self.device, torch.int32).contiguous()
+        if ids.dim() != 2 or ids.shape[1] != 77:
+            raise ValueError(f"input_ids must be [n, 77], got {tuple(ids.shape)}")
+        out = torch.empty(ids.shape[0], 77, 768, dtype=torch.float32, device=self.device)
+        self._check(self.lib.dm_f32_clip_encode(self._h, C.c_void_p(ids.data_ptr()), ids.shape[0], 77, C.c_void_p(out.data_ptr()),
+                                                self._stream()), "dm_f32_clip_encode")
+        return out
 
     def vae_encode(self, image, noise=None, scaling_factor: float = 0.18215, return_moments=False, draws_per_image: int = 1):
         """`vae.encode(image).latent_dist.sample() * scaling_factor` in fp32 (dift.py:187) with the N(0,1) draw injected (`noise`

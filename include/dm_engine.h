@@ -418,6 +418,14 @@ int dm_f32_load_vae_weight(dm_f32_net* e, const char* name, const void* host_ptr
 int dm_f32_finalize_vae(dm_f32_net* e);
 int dm_f32_vae_encode(dm_f32_net* e, const void* image_dev, const void* noise_dev, int batch, int draws_per_image, int H, int W,
                       float scaling_factor, void* latent_dev, void* moments_dev, void* stream);
+/* optional CLIP ViT-L/14 text tower in fp32: `pipe.encode_prompt(prompt, ...)[0]` of the featuriser (dift.py:222-226) — its pipeline is built
+ * with no torch_dtype (dift.py:197-199), so `text_encoder(input_ids)[0]` is fp32 there; replaces transformers' CLIPTextModel.forward for that
+ * call (12 layers, causal attention over 77 tokens, quick-GELU, final LayerNorm; fp32 GEMMs on the fp32 matrix cores).  State-dict names as
+ * dm_engine_load_clip_weight (196 tensors; `text_model.` / `text_encoder.` prefixes and `position_ids` accepted).  input_ids_dev
+ * [n_prompts, 77] int32 (tokenizer output, padding="max_length"); out_f32_dev [n_prompts, 77, 768] fp32 last_hidden_state. */
+int dm_f32_load_clip_weight(dm_f32_net* e, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim);
+int dm_f32_finalize_clip(dm_f32_net* e);
+int dm_f32_clip_encode(dm_f32_net* e, const int32_t* input_ids_dev, int n_prompts, int seq_len, void* out_f32_dev, void* stream);
 int dm_f32_prof_enable(dm_f32_net* e, int on);
 int dm_f32_prof_read(dm_f32_net* e, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches, double* attn_ms,
                      double* attn_flops, int64_t* attn_launches);

@@ -404,6 +404,88 @@ def test_sdfeaturizer_from_pixels_in_fp32(net32, vae_sd, sd15_weights_torch):
     assert out.shape == mean_ref.shape and r < TOL_E2E
 
 
+@pytest.fixture(scope="module")
+def clip_sd():
+    return synth.synth_clip_state_dict(seed=0, dtype=np.float16)
+
+
+def test_clip32_matches_transformers_fixture(net32, clip_sd):
+    """`pipe.encode_prompt(prompt)[0]` of the featuriser's fp32 pipeline (dift.py:197-199, 222-226) = `CLIPTextModel(input_ids)[0]` in
+    fp32: the fp32 net's text tower against the fixture `transformers.CLIPTextModel` ITSELF produced (tests/golden/clip_text.npz — the one
+    pinned oracle of the path) and against the CPU restatement in fp32 mode, at fp32 round-off; the fp16 engine's tower is 1.1e-3 from it."""
+    import os
+    from oracle import clip_ref
+    if not getattr(net32, "_clip_ready", False):
+        net32.load_clip_state_dict(clip_sd)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "clip_text.npz"))
+    ids = torch.from_numpy(g["input_ids"])
+    ref = torch.from_numpy(g["last_hidden_state"])
+    out = net32.clip_encode(ids)
+    assert out.shape == (3, 77, 768) and out.dtype == torch.float32 and out.is_cuda
+    r = U.rel_l2(out, ref)
+    sdt = {k: torch.from_numpy(v).float() for k, v in clip_sd.items()}
+    ro = U.rel_l2(out, clip_ref.clip_text_forward(sdt, ids, autocast=False))
+    print(f"fp32 text tower: rel-L2 vs transformers fp32 {r:.2e}, vs the fp32 restatement {ro:.2e}")
+    assert r < TOL_E2E and ro < TOL_E2E
+    # properties: deterministic; a prompt's states do not depend on its position in the batch; causal (later tokens cannot matter);
+    # more prompts than one pass holds (chunked) = the same rows
+    ids5 = torch.from_numpy(synth.synth_token_ids(5, seed=11))
+    a = net32.clip_encode(ids5)
+    assert torch.equal(a, net32.clip_encode(ids5))
+    perm = torch.tensor([3, 0, 4, 1, 2])
+    assert torch.equal(net32.clip_encode(ids5[perm]), a[perm])
+    ids2 = ids5.clone()
+    ids2[:, 40:] = 1234
+    b = net32.clip_encode(ids2)
+    assert torch.equal(a[:, :40], b[:, :40]) and not torch.equal(a[:, 40:], b[:, 40:])
+    many = ids5.repeat(27, 1)                                                # 135 prompts > the 128 of one pass
+    assert torch.equal(net32.clip_encode(many), a.repeat(27, 1, 1))
+    with pytest.raises(ValueError):
+        net32.clip_encode(ids5[:, :50])
+    with pytest.raises(ValueError):
+        net32.clip_encode(ids5, out_dtype=torch.float16)
+
+
+def test_sdfeaturizer_string_prompt_in_fp32(net32, clip_sd):
+    """VERDICT r05 "missing 4": a STRING prompt through an fp32 featuriser ran the text tower on the fp16 engine.  With CLIP weights on the
+    fp32 net the whole of `SDFeaturizer.forward(img, prompt: str, ...)` is fp32 (dift.py:214-232); measured here: what the fp16 tower cost —
+    the DIFT feature from fp16-tower hidden states against the one from fp32-tower hidden states."""
+    from diff_mining_amd.dift import SDFeaturizer
+    from diff_mining_amd.engine import UNetEngine
+    if not getattr(net32, "_clip_ready", False):
+        net32.load_clip_state_dict(clip_sd)
+    ids = torch.from_numpy(synth.synth_token_ids(1, seed=5))
+
+    class Tok:                                   # stands in for CLIPTokenizer (the vocabulary is not in the image): fixed ids
+        model_max_length = 77
+        calls = 0
+
+        def __call__(self, prompts, max_length, padding, truncation, return_tensors):
+            assert max_length == 77 and padding == "max_length" and truncation and return_tensors == "pt" and len(prompts) == 1
+            Tok.calls += 1
+            return type("Enc", (), {"input_ids": ids.long()})()
+
+    f = SDFeaturizer(net32, tokenizer=Tok())
+    lat, n = _randn(1, 4, 16, 16, seed=3), _randn(2, 4, 16, 16, seed=4)
+    out = f.forward(lat, "A car from the 1970s.", t=261, up_ft_index=1, ensemble_size=2, noise=n)
+    ref = SDFeaturizer(net32).forward(lat, net32.clip_encode(ids), t=261, up_ft_index=1, ensemble_size=2, noise=n)
+    assert out.dtype == torch.float32 and torch.equal(out, ref) and Tok.calls == 1          # the string took the fp32 tower
+    f.forward(lat, "A car from the 1970s.", t=261, up_ft_index=1, ensemble_size=2, noise=n)
+    assert Tok.calls == 1                                                                    # cached per distinct string
+    e16 = UNetEngine(0)
+    try:
+        e16.load_clip_state_dict(clip_sd)
+        c16 = e16.clip_encode(ids)
+    finally:
+        e16.close()
+    c32 = net32.clip_encode(ids)
+    out16 = SDFeaturizer(net32).forward(lat, c16, t=261, up_ft_index=1, ensemble_size=2, noise=n)
+    rc, rf = U.rel_l2(c16, c32), U.rel_l2(out16, out)
+    cos = F.cosine_similarity(out16[0].flatten(1).T.double(), out[0].flatten(1).T.double(), dim=1).min().item()      # per feature-map cell, over the 1280 channels
+    print(f"fp16 text tower inside the fp32 featuriser: hidden states rel-L2 {rc:.2e} -> DIFT feature rel-L2 {rf:.2e}, min per-pixel cosine {cos:.7f}")
+    assert 2e-4 < rc < 3e-3 and rf < 3e-3 and cos > 1 - 1e-5
+
+
 def test_f32_score_conds_takes_the_product_surface_keywords(net32):
     """`TypicalityScorer.compute_losses_batch` / `compute_submission` call `score_conds(..., latent_dtype=, slot_table=)`; the fp32 net
     takes the same keywords: `slot_table` [n_cond, U] = the registered prompt of draw i in its k-th condition (rows k U + i, bit-equal to
