@@ -360,13 +360,27 @@ def main():
         emb = torch.stack([torch.stack([cats[j], c[1]]) for j in range(n_img)]).contiguous()       # [n_img, 2, 77, 768]
         from diff_mining_amd.typicality import TypicalityScorer
         scorer = TypicalityScorer(eng, seed=42, N=N_DRAWS, t_min=0.1, t_max=0.7, latent_dtype=ldt)
-        last = {}
+        last = {"k": 0}
+        # The reference hands every grid to the host (compute.py:156,160).  `value` keeps them on the device (the task's rule: a
+        # PCIe-inclusive rate is never `value`); the leg behind the timed region measures the hand-over both ways — overlapped (the grid
+        # of step k leaves on a copy stream into one of two pinned buffers while step k + 1 computes) and blocking (`.cpu()` per call).
+        # DM_BENCH_D2H=1 puts the overlapped hand-over INSIDE the timed steps (same-box ABBA: +0.8 ms per step, of which +0.4 is the
+        # cross-stream event alone: profiles/r06_ab_d2h_modes.txt)
+        d2h = {"on": os.environ.get("DM_BENCH_D2H", "0") not in ("", "0")}
+        copy_stream = torch.cuda.Stream(device=dev)
+        host_grids = [torch.empty(n_img, N_DRAWS, N_COND, 4, LAT, LAT, dtype=torch.float16).pin_memory() for _ in range(2)]
 
         def step():
             # the product surface: D.compute_losses for the 8 images of the work-list slice in ONE engine call; the same N draws for
             # every image (manual_seed(42) precedes each image's draws, compute.py:139-141)
             grids = scorer.compute_losses_batch(x, emb, noises=eps, timesteps=t, to_host=False)    # [n_img, 10, 2, 4, 64, 64] fp16
             _, scores = eng.reduce_typicality_batched(grids, n_img, N_DRAWS, N_COND)               # one launch, no torch glue
+            if d2h["on"]:
+                copy_stream.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(copy_stream):
+                    host_grids[last["k"] & 1].copy_(grids, non_blocking=True)
+                grids.record_stream(copy_stream)         # the allocator must not hand the block to step k + 1 before the copy has read it
+                last["k"] += 1
             last["grids"], last["loss"] = grids, scorer.last_loss32
             return gather_scores(scores, n_img * world, rank, world)     # world 1: the tensor itself (no kernel)
 
@@ -427,18 +441,33 @@ def main():
         sync()
         ag_ms = (time.perf_counter() - t1) / 20 * 1e3
 
-    # secondary: the reference also hands the fp16 grids [N,2,4,h,w] to the host (compute.py:156,160); `value` keeps
-    # the scores on the device, so the D2H-inclusive rate is reported beside it (torch cast / permute / copy glue)
-    d2h = None
+    # secondary: the fp16 grids handed to the host as the reference does (compute.py:156,160), outside `value`: overlapped on a copy
+    # stream (what a pipelined caller gets), and blocking behind every call (the reference's own `.cpu()`); the last grid that reached
+    # the host is compared with the one the device holds
+    d2h_ms = {"overlapped": None, "blocking": None}
+    d2h_equal = None
+    d2h_in_value = False
+    if eng is not None:
+        d2h_in_value = d2h["on"]
     if eng is not None and world == 1:
-        host = torch.empty(n_img, N_DRAWS, N_COND, 4, LAT, LAT, dtype=torch.float16).pin_memory()
+        was = d2h["on"]
+        d2h["on"] = True
+        step()
         sync()
+        t1 = time.perf_counter()
+        for _ in range(4):
+            step()
+        sync()
+        d2h_ms["overlapped"] = (time.perf_counter() - t1) / 4 * 1e3
+        d2h_equal = bool(torch.equal(host_grids[(last["k"] - 1) & 1], last["grids"].cpu()))
+        d2h["on"] = False
         t1 = time.perf_counter()
         for _ in range(2):
             step()
-            host.copy_(last["grids"])
+            host_grids[0].copy_(last["grids"])
         sync()
-        d2h = (time.perf_counter() - t1) / 2
+        d2h_ms["blocking"] = (time.perf_counter() - t1) / 2 * 1e3
+        d2h["on"] = was
 
     if rank == 0:
         total_images = n_img * world * args.steps
@@ -487,9 +516,13 @@ def main():
                          "whole_path_frac_at_sustained_clock": (round(executed / step_s / 1e12 / (PEAK_TFLOPS * smi["sclk_mhz_mean"] / NOMINAL_SCLK_MHZ), 4)
                                                                 if smi.get("sclk_mhz_mean") else None)},
             "allgather_ms": None if ag_ms is None else round(ag_ms, 4),
-            "grid_d2h": ("excluded from `value` (scores are reduced on the device)" if d2h is None else
-                         {"in_value": False, "ms_per_step_with_fp16_grid_d2h": round(d2h * 1e3, 3),
-                          "images_per_s_with_fp16_grid_d2h": round(n_img / d2h, 4),
+            "grid_d2h": ("stub run" if eng is None else
+                         {"in_value": bool(d2h_in_value),
+                          "ms_per_step_with_overlapped_d2h": None if d2h_ms["overlapped"] is None else round(d2h_ms["overlapped"], 3),
+                          "images_per_s_with_overlapped_d2h": None if d2h_ms["overlapped"] is None else round(n_img / d2h_ms["overlapped"] * 1e3, 4),
+                          "ms_per_step_with_blocking_d2h": None if d2h_ms["blocking"] is None else round(d2h_ms["blocking"], 3),
+                          "images_per_s_with_blocking_d2h": None if d2h_ms["blocking"] is None else round(n_img / d2h_ms["blocking"] * 1e3, 4),
+                          "last_host_grid_equals_device": d2h_equal,
                           "bytes_per_step": n_img * N_DRAWS * N_COND * 4 * LAT * LAT * 2}),
             "scores_checksum": float(all_scores.double().sum().item()),
         }
