@@ -318,7 +318,7 @@ void attn_pipe80_kernel(AttnParams p) {
         constexpr int NMA = KS * 4 * QF;                      // 24
         static_for<NMA>([&](auto M) __attribute__((always_inline)) {
             constexpr int m = decltype(M)::value;
-            constexpr int s = m >> 3, f = (m >> 1) & 3, jq = m & 1;
+            constexpr int s = m >> 3, f = (m >> 1) & 3, jq = (m & 1) ^ (DM_MFMA_SNAKE ? (f & 1) : 0);       // snake: one operand changes per MFMA (igemm_pers_tile.h)
             if (next) {
                 if constexpr (KS > 2 && m == 8) {             // k steps >= 2: fragments fetched once step 0 has issued
 #pragma unroll
@@ -364,7 +364,7 @@ void attn_pipe80_kernel(AttnParams p) {
         constexpr int NMB = 2 * EF * QF;                      // 24
         static_for<NMB>([&](auto M) __attribute__((always_inline)) {
             constexpr int m = decltype(M)::value;
-            constexpr int ss = m / (EF * QF), e = (m % (EF * QF)) >> 1, jq = m & 1;
+            constexpr int ss = m / (EF * QF), e = (m % (EF * QF)) >> 1, jq = (m & 1) ^ (DM_MFMA_SNAKE ? (e & 1) : 0);
             if constexpr (m == EF * QF) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);

@@ -258,14 +258,14 @@ void attn_pp_kernel(AttnParams p) {
         if (next && !(ABL & 1)) {
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
-                const int s = m >> 3, f = (m >> 1) & 3, jq = m & 1;
+                const int s = m >> 3, f = (m >> 1) & 3, jq = (m & 1) ^ (DM_MFMA_SNAKE ? (f & 1) : 0);      // snake: one operand changes per MFMA (igemm_pers_tile.h)
                 S[f][jq] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[s][f], qf[jq][s], s == 0 ? floatx4{0, 0, 0, 0} : S[f][jq], 0, 0, 0);
             }
         }
         if (pv && !(ABL & 1)) {
 #pragma unroll
             for (int m = 0; m < 12; ++m) {
-                const int ss = m / 6, e = (m % 6) >> 1, jq = m & 1;
+                const int ss = m / 6, e = (m % 6) >> 1, jq = (m & 1) ^ (DM_MFMA_SNAKE ? (e & 1) : 0);
                 half8 va, pbv;
                 __builtin_memcpy(&va, &vraw[ss][e][0], 8);
                 __builtin_memcpy(reinterpret_cast<char*>(&va) + 8, &vraw[ss][e][1], 8);

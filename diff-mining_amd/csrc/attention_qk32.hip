@@ -283,7 +283,8 @@ void attn_qk32_kernel(AttnParams p) {
         float mx = 0.f;
 #pragma unroll
         for (int m = 0; m < 12; ++m) {
-            const int ss = m / 6, e = (m % 6) >> 1, jq = m & 1;
+            // snake over the two query blocks (DM_MFMA_SNAKE, igemm_pers_tile.h): (e0,q0) (e0,q1) (e1,q1) (e1,q0) ... — one operand changes per MFMA
+            const int ss = m / 6, e = (m % 6) >> 1, jq = (m & 1) ^ (DM_MFMA_SNAKE ? (e & 1) : 0);
             half8 va, pbv;
             __builtin_memcpy(&va, &vraw[ss][e][0], 8);
             __builtin_memcpy(reinterpret_cast<char*>(&va) + 8, &vraw[ss][e][1], 8);

@@ -8,6 +8,12 @@
 #include <atomic>
 #include <vector>
 
+// order of the four pixel-fragment MFMAs of a weight-fragment group in the igemm tiles: 1 = alternating 0..3 / 3..0 (one operand
+// changes per MFMA), 0 = always 0..3 (r01-r05); same bits either way
+#ifndef DM_MFMA_SNAKE
+#define DM_MFMA_SNAKE 1
+#endif
+
 namespace dm {
 
 typedef _Float16 f16;

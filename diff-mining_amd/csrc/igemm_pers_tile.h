@@ -424,8 +424,14 @@ void igemm_pers_kernel(IGemmParams p, int ntiles, int cset) {
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int jj = 0; jj < 4; ++jj) {
+                    // snake order over the pixel fragments (DM_MFMA_SNAKE): between consecutive MFMAs exactly ONE operand changes — at a
+                    // group change the weight fragment, inside a group the pixel fragment — instead of both at every group change.  Every
+                    // accumulator gets the same products in the same k order (bit-identical); the matrix cores are power-bound on dense
+                    // fp16 streams and operand toggling is a visible share of it (tools/probes/probe_order.hip: +1.7 % on the MFMA stream alone)
+                    const int j = (DM_MFMA_SNAKE && ((q * 5 + i) & 1)) ? 3 - jj : jj;
                     acc[h][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], sidx ? b1[j] : b0[j], acc[h][i][j], 0, 0, 0);
+                }
                 if (q + 1 < 2 * CH) {          // fragment i of the next quarter replaces the one just consumed
                     const int nq = q + 1, ns = nq / CH, nh = nq % CH;
                     a[i] = *reinterpret_cast<const half8*>(wt + a_row_off + nh * (80 * 128) + i * 2048 + (ns ? koff1 : koff0));

@@ -170,6 +170,7 @@ void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
     // one k step: weights of stage wcur, activation stage xcur read shifted by dx rows; the LDS-DMA of the next k step's weights
     // (adv = distance to the step after that) and pieces 2 dx, 2 dx + 1 (dx = 2: piece 4 only) of the
     // next activation stage interleaved.  dx is a run-time value on purpose: unrolled by three the k loop's register allocation spills accumulators.
+    constexpr bool SNAKE = DM_MFMA_SNAKE && !(EXTRA == PX_TEMB && WIMG == 64 && UNROLL);
     auto step = [&](int wcur, int xcur, auto dxv, int adv) __attribute__((always_inline)) {
         const int dx = dxv;                  // an int (run-time loop) or an integral_constant (unrolled loop: everything below folds)
         const char* wt = smem + wcur * WBYTES;
@@ -208,8 +209,13 @@ void igemm_pers_tr_kernel(IGemmParams p, int ntiles, int cset) {
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int jj = 0; jj < 4; ++jj) {
+                    // snake order over the pixel fragments (igemm_pers_tile.h): one operand changes per MFMA.  Starting reversed (even groups)
+                    // is the parity at which no instantiation but one spills; that one — the GroupNorm-block-emitting PX_TEMB kernel of
+                    // 64-pixel-wide images, 255 registers — spills 4-12 registers under every reordering and keeps the ascending order
+                    const int j = (SNAKE && !(i & 1)) ? 3 - jj : jj;
                     acc[h][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], sidx ? b1[j] : b0[j], acc[h][i][j], 0, 0, 0);
+                }
                 if (q + 1 < 2 * CH) {
                     const int nq = q + 1, ns = nq / CH, nh = nq % CH;
                     a[i] = *reinterpret_cast<const half8*>(wt + a_row_off + nh * (80 * 128) + i * 2048 + (ns ? koff1 : koff0));

@@ -417,9 +417,11 @@ void igemm_kernel(IGemmParams p) {
                 for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const half8*>(xt + b_row_off + j * 2048 + koff1);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = (DM_MFMA_SNAKE && (g & 1)) ? 3 - jj : jj;        // snake order: one operand changes per MFMA (igemm_pers_tile.h)
                 acc[i][j] = (g < NI) ? __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[i], b0[j], acc[i][j], 0, 0, 0)
                                     : __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+            }
             if (more && g < NL) load_piece(cur ^ 1, g);
             if (LN && g >= 2 && g < 6) {
                 if (ln_ink) {

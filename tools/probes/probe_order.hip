@@ -1,0 +1,170 @@
+// r06: does the ORDER of a wave tile's MFMAs change what the matrix cores deliver at the package power limit?
+// The igemm k step issues, per wave and 32-deep half step, 4 x 10 MFMAs over 4 pixel fragments x 10 channel fragments.  The order in which the
+// (pixel, channel) pairs are visited decides how many operand registers change between consecutive MFMAs (both / one / none) and nothing else:
+// every accumulator still gets the same products in the same k order, so any order is bit-identical.  The chip is power-bound on dense random
+// fp16 MFMA streams (1.97 PFLOP/s at ~1.97 GHz instead of 2.5 at 2.4, bench.py `mfma_only_tflops_measured`): if operand-bus toggling is a
+// visible share of the matrix power, an order that keeps one operand stationary buys clock.
+//   ORDER 0: row-major — for a in 0..4: for b in 0..3 (b changes every MFMA, a AND b at the row change)       [probe_peak / the kernel's form]
+//   ORDER 1: snake     — b runs 0..3, 3..0, 0..3 ... (exactly ONE operand changes at every step)
+//   ORDER 2: diagonal  — (n % 5, n % 4), n = 0..19 (BOTH operands change at every step)
+//   ORDER 3: fixed     — (0, 0) for all twenty accumulators (no operand changes at all: the floor of operand toggling, same random data)
+//   ORDER 4: snake, roles swapped — b outer (4), a inner 0..4, 4..0 ... (srcA changes 4 of 5 steps instead of srcB 3 of 4: are the two operand paths alike?)
+//   ORDER 7: the same flops on v_mfma_f32_32x32x16_f16 (2 pixel x 5 channel blocks of 32 x 32, snake): half the operand reads per flop, twice the
+//            accumulator traffic, half the instructions — what would the tile's MFMA stream deliver at the power limit on the other shape?
+//   ORDER 5: a fixed, b cycling (only srcB ever changes);  ORDER 6: b fixed, a cycling (only srcA ever changes)
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/probe_order.hip -o tools/probes/bin/probe_order && tools/probes/bin/probe_order
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int ORDER>
+__global__ __launch_bounds__(512, 2) void order_kernel(int steps, int zero_operands, float* sink) {
+    const unsigned lane = threadIdx.x, blk = blockIdx.x;
+    half8 a[5], b[4];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            unsigned h = (lane * 9u + (unsigned)i) * 2654435761u + blk * 40503u + (unsigned)k * 2246822519u;
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            const float v = zero_operands ? 0.f : ((float)(h & 0xFFFF) + (float)(h >> 16)) / 32768.0f - 2.0f;
+            if (i < 5) a[i][k] = (_Float16)v; else b[i - 5][k] = (_Float16)v;
+        }
+    floatx4 acc[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("" : "+v"(a[0]), "+v"(b[0]));
+    for (int s = 0; s < steps; ++s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int n = 0; n < 20; ++n) {
+                int i, j;
+                if (ORDER == 0) { i = n / 4; j = n % 4; }
+                else if (ORDER == 1) { i = n / 4; j = (i & 1) ? 3 - n % 4 : n % 4; }
+                else if (ORDER == 4) { j = n / 5; i = (j & 1) ? 4 - n % 5 : n % 5; }
+                else { i = n % 5; j = n % 4; }
+                const int oi = (ORDER == 3 || ORDER == 5) ? 0 : i, oj = (ORDER == 3 || ORDER == 6) ? 0 : j;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[oi], b[oj], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);          // the order written here is the order issued
+            }
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][3];
+    if (sum == 1.2345e-30f) sink[0] = sum;
+}
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(512, 2) void order32_kernel(int steps, int zero_operands, float* sink) {
+    const unsigned lane = threadIdx.x, blk = blockIdx.x;
+    half8 a[2], b[5];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            unsigned h = (lane * 9u + (unsigned)i) * 2654435761u + blk * 40503u + (unsigned)k * 2246822519u;
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            const float v = zero_operands ? 0.f : ((float)(h & 0xFFFF) + (float)(h >> 16)) / 32768.0f - 2.0f;
+            if (i < 2) a[i][k] = (_Float16)v; else b[i - 2][k] = (_Float16)v;
+        }
+    floatx16 acc[2][5];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    asm volatile("" : "+v"(a[0]), "+v"(b[0]));
+    for (int s = 0; s < steps; ++s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int n = 0; n < 10; ++n) {
+                const int j = n / 2, i = (j & 1) ? 1 - n % 2 : n % 2;          // snake: one operand changes per MFMA
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) sum += acc[i][j][0] + acc[i][j][15];
+    if (sum == 1.2345e-30f) sink[0] = sum;
+}
+
+double run32(int n_cu, int steps, int zero, float* sink) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(order32_kernel, dim3(n_cu), dim3(512), 0, 0, steps / 8 + 1, zero, sink);
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(order32_kernel, dim3(n_cu), dim3(512), 0, 0, steps, zero, sink);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return (double)n_cu * steps * 8.0 * 40.0 * (2.0 * 32 * 32 * 16) / (ms * 1e-3) / 1e12;
+}
+
+template <int ORDER>
+double run(int n_cu, int steps, int zero, float* sink) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(order_kernel<ORDER>, dim3(n_cu), dim3(512), 0, 0, steps / 8 + 1, zero, sink);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(order_kernel<ORDER>, dim3(n_cu), dim3(512), 0, 0, steps, zero, sink);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return (double)n_cu * steps * 8.0 * 80.0 * (2.0 * 16 * 16 * 32) / (ms * 1e-3) / 1e12;
+}
+
+int main(int argc, char** argv) {
+    const int steps = argc > 1 ? atoi(argv[1]) : 120000;       // ~ 190 ms per launch
+    const int rounds = argc > 2 ? atoi(argv[2]) : 4;
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    const int n_cu = p.multiProcessorCount;
+    float* sink;
+    hipMalloc(&sink, 64);
+    printf("# %d CUs, %d steps of 80 MFMAs per wave, 8 waves per CU; TFLOP/s per launch, arms in mirrored order\n", n_cu, steps);
+    const char* names[10] = {"row-major", "snake", "diagonal", "fixed", "snake-swapped", "only-srcB-changes", "only-srcA-changes", "zeros", "32x32x16-snake", "32x32x16-zeros"};
+    double sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < rounds; ++r) {
+        double v[10];
+        auto one = [&](int k) {
+            switch (k) {
+                case 0: v[0] = run<0>(n_cu, steps, 0, sink); break;
+                case 1: v[1] = run<1>(n_cu, steps, 0, sink); break;
+                case 2: v[2] = run<2>(n_cu, steps, 0, sink); break;
+                case 3: v[3] = run<3>(n_cu, steps, 0, sink); break;
+                case 4: v[4] = run<4>(n_cu, steps, 0, sink); break;
+                case 5: v[5] = run<5>(n_cu, steps, 0, sink); break;
+                case 6: v[6] = run<6>(n_cu, steps, 0, sink); break;
+                case 7: v[7] = run<0>(n_cu, steps, 1, sink); break;
+                case 8: v[8] = run32(n_cu, steps, 0, sink); break;
+                default: v[9] = run32(n_cu, steps, 1, sink); break;
+            }
+        };
+        if (r & 1) for (int k = 9; k >= 0; --k) one(k); else for (int k = 0; k < 10; ++k) one(k);
+        printf("round %d:", r);
+        for (int k = 0; k < 10; ++k) { printf("  %s %.1f", names[k], v[k]); sum[k] += v[k]; }
+        printf("\n");
+    }
+    printf("mean   :");
+    for (int k = 0; k < 10; ++k) printf("  %s %.1f", names[k], sum[k] / rounds);
+    printf("\n");
+    return 0;
+}
