@@ -11,6 +11,7 @@
 //   ORDER 4: snake, roles swapped — b outer (4), a inner 0..4, 4..0 ... (srcA changes 4 of 5 steps instead of srcB 3 of 4: are the two operand paths alike?)
 //   ORDER 7: the same flops on v_mfma_f32_32x32x16_f16 (2 pixel x 5 channel blocks of 32 x 32, snake): half the operand reads per flop, twice the
 //            accumulator traffic, half the instructions — what would the tile's MFMA stream deliver at the power limit on the other shape?
+//   PRIO 1 / 2 (on the snake): s_setprio 3 around every group of four / all twenty MFMAs — does it matter which wave of the SIMD the pipe takes its next MFMA from?
 //   ORDER 5: a fixed, b cycling (only srcB ever changes);  ORDER 6: b fixed, a cycling (only srcA ever changes)
 //   hipcc --offload-arch=gfx950 -O3 tools/probes/probe_order.hip -o tools/probes/bin/probe_order && tools/probes/bin/probe_order
 #include <hip/hip_runtime.h>
@@ -19,7 +20,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-template <int ORDER>
+template <int ORDER, int PRIO = 0>
 __global__ __launch_bounds__(512, 2) void order_kernel(int steps, int zero_operands, float* sink) {
     const unsigned lane = threadIdx.x, blk = blockIdx.x;
     half8 a[5], b[4];
@@ -49,7 +50,11 @@ __global__ __launch_bounds__(512, 2) void order_kernel(int steps, int zero_opera
                 else if (ORDER == 4) { j = n / 5; i = (j & 1) ? 4 - n % 5 : n % 5; }
                 else { i = n % 5; j = n % 4; }
                 const int oi = (ORDER == 3 || ORDER == 5) ? 0 : i, oj = (ORDER == 3 || ORDER == 6) ? 0 : j;
+                if (PRIO == 1 && n % 4 == 0) __builtin_amdgcn_s_setprio(3);          // a group's four MFMAs back to back from ONE wave of the SIMD
+                if (PRIO == 2 && n == 0) __builtin_amdgcn_s_setprio(3);              // ... or all twenty
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[oi], b[oj], acc[i][j], 0, 0, 0);
+                if (PRIO == 1 && n % 4 == 3) __builtin_amdgcn_s_setprio(0);
+                if (PRIO == 2 && n == 19) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);          // the order written here is the order issued
             }
         }
@@ -116,13 +121,13 @@ double run32(int n_cu, int steps, int zero, float* sink) {
     return (double)n_cu * steps * 8.0 * 40.0 * (2.0 * 32 * 32 * 16) / (ms * 1e-3) / 1e12;
 }
 
-template <int ORDER>
+template <int ORDER, int PRIO = 0>
 double run(int n_cu, int steps, int zero, float* sink) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(order_kernel<ORDER>, dim3(n_cu), dim3(512), 0, 0, steps / 8 + 1, zero, sink);
+    hipLaunchKernelGGL((order_kernel<ORDER, PRIO>), dim3(n_cu), dim3(512), 0, 0, steps / 8 + 1, zero, sink);
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(order_kernel<ORDER>, dim3(n_cu), dim3(512), 0, 0, steps, zero, sink);
+    hipLaunchKernelGGL((order_kernel<ORDER, PRIO>), dim3(n_cu), dim3(512), 0, 0, steps, zero, sink);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0.f;
@@ -140,10 +145,10 @@ int main(int argc, char** argv) {
     float* sink;
     hipMalloc(&sink, 64);
     printf("# %d CUs, %d steps of 80 MFMAs per wave, 8 waves per CU; TFLOP/s per launch, arms in mirrored order\n", n_cu, steps);
-    const char* names[10] = {"row-major", "snake", "diagonal", "fixed", "snake-swapped", "only-srcB-changes", "only-srcA-changes", "zeros", "32x32x16-snake", "32x32x16-zeros"};
-    double sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const char* names[12] = {"row-major", "snake", "diagonal", "fixed", "snake-swapped", "only-srcB-changes", "only-srcA-changes", "zeros", "32x32x16-snake", "32x32x16-zeros", "snake+prio-per-4", "snake+prio-per-20"};
+    double sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int r = 0; r < rounds; ++r) {
-        double v[10];
+        double v[12];
         auto one = [&](int k) {
             switch (k) {
                 case 0: v[0] = run<0>(n_cu, steps, 0, sink); break;
@@ -155,16 +160,18 @@ int main(int argc, char** argv) {
                 case 6: v[6] = run<6>(n_cu, steps, 0, sink); break;
                 case 7: v[7] = run<0>(n_cu, steps, 1, sink); break;
                 case 8: v[8] = run32(n_cu, steps, 0, sink); break;
-                default: v[9] = run32(n_cu, steps, 1, sink); break;
+                case 9: v[9] = run32(n_cu, steps, 1, sink); break;
+                case 10: v[10] = run<1, 1>(n_cu, steps, 0, sink); break;
+                default: v[11] = run<1, 2>(n_cu, steps, 0, sink); break;
             }
         };
-        if (r & 1) for (int k = 9; k >= 0; --k) one(k); else for (int k = 0; k < 10; ++k) one(k);
+        if (r & 1) for (int k = 11; k >= 0; --k) one(k); else for (int k = 0; k < 12; ++k) one(k);
         printf("round %d:", r);
-        for (int k = 0; k < 10; ++k) { printf("  %s %.1f", names[k], v[k]); sum[k] += v[k]; }
+        for (int k = 0; k < 12; ++k) { printf("  %s %.1f", names[k], v[k]); sum[k] += v[k]; }
         printf("\n");
     }
     printf("mean   :");
-    for (int k = 0; k < 10; ++k) printf("  %s %.1f", names[k], sum[k] / rounds);
+    for (int k = 0; k < 12; ++k) printf("  %s %.1f", names[k], sum[k] / rounds);
     printf("\n");
     return 0;
 }
