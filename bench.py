@@ -449,7 +449,7 @@ def main():
     d2h_in_value = False
     if eng is not None:
         d2h_in_value = d2h["on"]
-    if eng is not None and world == 1:
+    if eng is not None and world == 1 and not args.no_side:       # (--no-side: the profiler passes hold warm-up + timed steps only)
         was = d2h["on"]
         d2h["on"] = True
         step()

@@ -12,7 +12,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 what = sys.argv[3] if len(sys.argv) > 3 else "bench.py"          # e.g. "bench.py --workload dift" (the fp32 net)
 
 
@@ -48,7 +48,7 @@ for f in glob.glob(root + "/pmc_*/**/*counter_collection.csv", recursive=True):
 out = {
     "command": f"rocprofv3 --pmc <set> --kernel-trace -f csv -- python {what} --steps 1 --warmup 1 --no-cpu-baseline "
                "(separate process per counter set: FETCH_SIZE | WRITE_SIZE | SQ set A | SQ set B; each pass = "
-               f"{steps} steps" + (": 1 warm-up + 1 timed + 2 of the grid-D2H leg)" if what == "bench.py" else ": 1 warm-up + 1 timed)"),
+               f"{steps} steps: 1 warm-up + 1 timed)",
     "steps_in_pass": steps,
     "units": "FETCH_SIZE/WRITE_SIZE in KiB; FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads, "
              "MI355X_MICROARCH.md HBM section); WRITE_SIZE uncorrected; SQ_* as reported",

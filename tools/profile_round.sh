@@ -18,7 +18,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
         > $OUT/pmc_$i.json 2> $OUT/pmc_$i.err
     i=$((i+1))
 done
-python tools/pmc_to_json.py $OUT 4 > $OUT/pmc.json    # a pass runs 4 steps: 1 warm-up + 1 timed + 2 of the grid-D2H leg
+python tools/pmc_to_json.py $OUT 2 > $OUT/pmc.json    # a pass runs 2 steps: 1 warm-up + 1 timed (--no-side: no grid-D2H leg since r06)
 # the graded line AFTER the counters: bench.py takes roofline.traffic from profiles/<tag>_pmc.json (the same library, the same box)
 mkdir -p profiles && cp $OUT/pmc.json profiles/${TAG}_pmc.json      # (bench.py reads the newest tag it knows first: hbm_traffic_per_launch)
 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2>> $OUT/bench.err
